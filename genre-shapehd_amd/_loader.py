@@ -1,0 +1,167 @@
+"""ctypes binding of libgenre_hip.so (the C ABI declared in include/genre_hip.h).
+
+This is the only place the Python host side touches native code.  There is NO
+CPU fallback: if the library is missing (not built) the import fails loudly,
+and every op refuses non-CUDA tensors.  The three objects exported at the
+bottom -- ``cam_bp_lib``, ``calc_prob_lib``, ``my_lib`` -- carry the same
+function names and argument orders as the reference's cffi modules
+(toolbox/cam_bp/cam_bp/src/back_projection.h:1-5, calc_prob.h:1-2,
+my_lib_cuda.h:1-4), so the autograd Functions read like the reference's.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgenre_hip.so")
+ABI_VERSION = 1
+_MAX_DIMS = 5
+_F32, _I32 = 0, 1
+
+
+class GenreTensor(C.Structure):
+    """struct genre_tensor of include/genre_hip.h"""
+    _fields_ = [("data", C.c_void_p), ("ndim", C.c_int32), ("dtype", C.c_int32),
+                ("size", C.c_int64 * _MAX_DIMS), ("stride", C.c_int64 * _MAX_DIMS)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "genre-shapehd_amd: %s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C genre-shapehd_amd/csrc` (hipcc, --offload-arch=gfx950). "
+            "There is no CPU fallback for these ops." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.genre_abi_version.restype = C.c_int
+    lib.genre_last_error.restype = C.c_char_p
+    if lib.genre_abi_version() != ABI_VERSION:
+        raise ImportError("libgenre_hip.so ABI %d != expected %d -- rebuild" % (lib.genre_abi_version(), ABI_VERSION))
+    T, V = C.POINTER(GenreTensor), C.c_void_p
+    for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
+                        ("genre_get_surface_mask", 5), ("genre_spherical_back_proj_forward", 4),
+                        ("genre_spherical_back_proj_backward", 5), ("genre_calc_prob_forward", 2),
+                        ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
+                        ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
+                        ("genre_render_spherical_forward", 3), ("genre_render_spherical_backward", 4)):
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue
+        fn.argtypes = [T] * nargs + [V]
+        fn.restype = C.c_int
+    return lib
+
+
+_lib = _load()
+
+
+def _desc(t, what):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s: expected a torch.Tensor, got %r" % (what, type(t)))
+    if not t.is_cuda:
+        raise RuntimeError("%s: tensor is on %s; the MI355X ops take CUDA (HIP) tensors only -- "
+                           "there is no CPU path" % (what, t.device))
+    if t.dtype == torch.float32:
+        dt = _F32
+    elif t.dtype == torch.int32:
+        dt = _I32
+    else:
+        raise RuntimeError("%s: dtype %s not supported (fp32 data, int32 indices)" % (what, t.dtype))
+    if t.dim() > _MAX_DIMS:
+        raise RuntimeError("%s: more than %d dims" % (what, _MAX_DIMS))
+    d = GenreTensor()
+    d.data = t.data_ptr()
+    d.ndim = t.dim()
+    d.dtype = dt
+    for i in range(t.dim()):
+        d.size[i] = t.size(i)
+        d.stride[i] = t.stride(i)
+    return d
+
+
+def _call(name, *tensors):
+    """Enqueue `name` on torch's current stream of the tensors' device; raise on failure
+    (the reference raised via THError("aborting"), back_projection.c:13-15)."""
+    dev = tensors[0].device
+    descs = []
+    for k, t in enumerate(tensors):
+        if t.device != dev:
+            raise RuntimeError("%s: tensors are on different GPUs (%s vs %s)" % (name, dev, t.device))
+        descs.append(_desc(t, "%s arg %d" % (name, k)))
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ok = getattr(_lib, name)(*[C.byref(d) for d in descs], C.c_void_p(stream))
+    if ok != 1:
+        raise RuntimeError("%s failed: %s" % (name, _lib.genre_last_error().decode()))
+    return 1
+
+
+def has_symbol(name):
+    return hasattr(_lib, name)
+
+
+class _CamBpLib:
+    """stands in for toolbox/cam_bp/cam_bp/_ext/cam_bp_lib (back_projection.h:1-5)"""
+
+    @staticmethod
+    def back_projection_forward(depth, camdist, fl, voxel, cnt):
+        return _call("genre_back_projection_forward", depth, camdist, fl, voxel, cnt)
+
+    @staticmethod
+    def back_projection_backward(depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl):
+        return _call("genre_back_projection_backward", depth, fl, camdist, cnt, grad_in, grad_depth,
+                     grad_camdist, grad_fl)
+
+    @staticmethod
+    def get_surface_mask(depth, camdist, fl, cnt, mask):
+        return _call("genre_get_surface_mask", depth, camdist, fl, cnt, mask)
+
+    @staticmethod
+    def spherical_back_proj_forward(depth, grid_in, voxel, cnt):
+        return _call("genre_spherical_back_proj_forward", depth, grid_in, voxel, cnt)
+
+    @staticmethod
+    def spherical_back_proj_backward(depth, grid_in, cnt, grad_in, grad_depth):
+        return _call("genre_spherical_back_proj_backward", depth, grid_in, cnt, grad_in, grad_depth)
+
+
+class _CalcProbLib:
+    """stands in for toolbox/calc_prob/calc_prob/_ext/calc_prob_lib (calc_prob.h:1-2)"""
+
+    @staticmethod
+    def calc_prob_forward(prob_in, prob_out):
+        return _call("genre_calc_prob_forward", prob_in, prob_out)
+
+    @staticmethod
+    def calc_prob_backward(prob_in, stop_prob_weighted, grad_out):
+        return _call("genre_calc_prob_backward", prob_in, stop_prob_weighted, grad_out)
+
+    @staticmethod
+    def calc_prob_backward_fused(prob_in, stop_prob, grad_in, grad_out):
+        """extension: forms stop_prob*grad_in in-kernel (calc_prob.py:27 folded in)"""
+        return _call("genre_calc_prob_backward_fused", prob_in, stop_prob, grad_in, grad_out)
+
+
+class _MyLib:
+    """stands in for nndistance/_ext/my_lib (my_lib.h:3-5, my_lib_cuda.h:1-4).
+    The reference's CPU entry points exist here only to fail loudly."""
+
+    @staticmethod
+    def nnd_forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2):
+        return _call("genre_nnd_forward", xyz1, xyz2, dist1, dist2, idx1, idx2)
+
+    @staticmethod
+    def nnd_backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+        return _call("genre_nnd_backward", xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
+
+    @staticmethod
+    def nnd_forward(*args):
+        raise RuntimeError("nnd_forward (CPU, my_lib.c:30-49) is not part of the MI355X build; "
+                           "move the clouds to the GPU -- there is no CPU fallback")
+
+    nnd_backward = nnd_forward
+
+
+cam_bp_lib = _CamBpLib()
+calc_prob_lib = _CalcProbLib()
+my_lib = _MyLib()

@@ -1,0 +1,482 @@
+// cam_bp.hip -- depth-map / spherical-map  ->  voxel TDF back-projection for gfx950.
+//
+// Replaces toolbox/cam_bp/cam_bp/src/back_projection_kernel.cu of the reference
+// (kernels K1-K6, wrappers :629-963).  Not a translation: the reference's
+// pipeline per forward is  zero(cnt) + zero(tdf) + add 1/res (Python)  ->
+// zero(cnt) again  ->  K1 scatter  ->  K2 full-volume divide with 5 div/mod per
+// voxel and n-fastest (uncoalesced) indexing.  Here a forward is
+//   (1) one float4 streaming fill of tdf and cnt (the only full-volume pass;
+//       16 B/lane stores, the algorithmic minimum of 2 x 4 B per voxel),
+//   (2) the scatter, one lane per pixel, hardware fp32 atomics at L2,
+//   (3) a per-PIXEL normalise that touches only the voxels that were hit
+//       (<= H*W of them) instead of re-streaming the whole volume.
+// (3) needs to know whether a voxel still holds a raw sum or was already
+// normalised by another pixel of the same voxel.  Raw sums are accumulated
+// NEGATED (the first arriver, detected by cnt's atomic return value, also
+// cancels the prefill), so "raw" == negative and "done" == non-negative, and
+// the race between two pixels of one voxel is benign: both compute the same
+// value from the same final (sum, cnt).  No scratch memory, no grid barrier.
+//
+// Index arithmetic (voxel index, centre, distance) is the reference's fp32
+// sequence, compiled with contraction OFF so that the voxel a point lands in
+// is bit-identical to the reference/oracle; `cnt` is therefore exact, and the
+// per-point distances are bit-exact (only the order of the float atomics,
+// which the reference does not define either, can differ).
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace genre {
+namespace {
+
+constexpr int kBlock = 256;
+
+// back_projection_kernel.cu:36-37,74-75 (FLOOR_I, VOXIND_TO_VOXC)
+__device__ __forceinline__ int floor_i(float a) { return (a < 0.0f) ? (int)a - 1 : (int)a; }
+__device__ __forceinline__ int vox_index(float g, int res) { return floor_i((g + 0.5f) * (float)res); }
+// :195-196 (vec3d_norm): left-to-right sum, correctly rounded sqrt
+__device__ __forceinline__ float norm3(float a, float b, float c) { return sqrtf(a * a + b * b + c * c); }
+// fp32 centre (:258-260) and the fp64-literal variant used by K3/K4/K6 (:336-338,:428-430,:596-598)
+__device__ __forceinline__ float centre_f(int i, int R) { return (((float)i + 0.5f) / (float)R) - 0.5f; }
+__device__ __forceinline__ float centre_d(int i, int R)
+{
+    return (float)((((double)(float)i + 0.5) / (double)(float)R) - 0.5);
+}
+
+struct Dims { int N, NC, H, W, X, Y, Z; };
+
+// Back-projected point of pixel (h,w): camera model of :231-242, or grid*d (:506-508).
+template <bool SPH>
+__device__ __forceinline__ bool pixel_point(const Dims &D, const View4 &depth, const View2 &camdist,
+                                            const View2 &fl, const View5 &grid, int n, int c, int h, int w,
+                                            float &d_raw, float &gx, float &gy, float &gz,
+                                            float &u_h, float &u_w, float &f)
+{
+    d_raw = depth.p[n * depth.s0 + c * depth.s1 + h * depth.s2 + w * depth.s3];
+    if (d_raw < 0.0f) return false;                                  // :225 / :501
+    if (SPH) {
+        const float *gp = grid.p + n * grid.s0 + c * grid.s1 + h * grid.s2 + w * grid.s3;
+        gx = gp[0] * d_raw; gy = gp[grid.s4] * d_raw; gz = gp[2 * grid.s4] * d_raw;
+        u_h = u_w = f = 0.0f;
+    } else {
+        f = fl.p[n * fl.s0 + c * fl.s1];
+        float cam_dist = camdist.p[n * camdist.s0 + c * camdist.s1];
+        u_h = (float)h - ((float)D.H - 1.0f) / 2.0f;
+        u_w = (float)w - ((float)D.W - 1.0f) / 2.0f;
+        float cos_theta = f / norm3(u_h, u_w, f);
+        float d = d_raw * cos_theta;
+        gy = -d * u_w / f;
+        gz = -d * u_h / f;
+        gx = d - cam_dist;
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool in_grid(const Dims &D, int ix, int iy, int iz)
+{
+    return ix >= 0 && ix < D.X && iy >= 0 && iy < D.Y && iz >= 0 && iz < D.Z;
+}
+
+__device__ __forceinline__ void decode_pixel(const Dims &D, int64_t idx, int &n, int &c, int &h, int &w)
+{
+    w = (int)(idx % D.W); idx /= D.W;
+    h = (int)(idx % D.H); idx /= D.H;
+    c = (int)(idx % D.NC);
+    n = (int)(idx / D.NC);
+}
+
+// ---- (1) fill -----------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fill2_vec4_kernel(float4 *__restrict__ a, float va,
+                                                             float4 *__restrict__ b, float vb, int64_t n4)
+{
+    const float4 fa = make_float4(va, va, va, va), fb = make_float4(vb, vb, vb, vb);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+        a[i] = fa;
+        b[i] = fb;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void fill2_strided_kernel(Dims D, View5 a, float va, View5 b, float vb)
+{
+    const int64_t total = (int64_t)D.N * D.NC * D.X * D.Y * D.Z;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        int64_t r = i;
+        int z = (int)(r % D.Z); r /= D.Z;
+        int y = (int)(r % D.Y); r /= D.Y;
+        int x = (int)(r % D.X); r /= D.X;
+        int c = (int)(r % D.NC);
+        int n = (int)(r / D.NC);
+        a.p[n * a.s0 + c * a.s1 + x * a.s2 + y * a.s3 + z * a.s4] = va;
+        b.p[n * b.s0 + c * b.s1 + x * b.s2 + y * b.s3 + z * b.s4] = vb;
+    }
+}
+
+// ---- (2) scatter --------------------------------------------------------------
+template <bool SPH>
+__global__ __launch_bounds__(kBlock) void scatter_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
+                                                          View5 grid, View5 vox, View5 cnt, float empty_val)
+{
+    const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * kBlock) {
+        int n, c, h, w;
+        decode_pixel(D, idx, n, c, h, w);
+        float d_raw, gx, gy, gz, u_h, u_w, f;
+        if (!pixel_point<SPH>(D, depth, camdist, fl, grid, n, c, h, w, d_raw, gx, gy, gz, u_h, u_w, f)) continue;
+        const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
+        if (!in_grid(D, ix, iy, iz)) continue;                       // :252
+        const float dist = norm3(gx - centre_f(ix, D.X), gy - centre_f(iy, D.Y), gz - centre_f(iz, D.Z));
+        float *pc = cnt.p + n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4;
+        float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
+        const float old = unsafeAtomicAdd(pc, 1.0f);                 // :274, hardware global_atomic_add_f32
+        // negated accumulation; the first arriver also cancels the prefill (see file header)
+        unsafeAtomicAdd(pv, (old == 0.0f) ? -(dist + empty_val) : -dist);   // :273
+    }
+}
+
+// ---- (3) normalise, per pixel ---------------------------------------------------
+template <bool SPH>
+__global__ __launch_bounds__(kBlock) void normalise_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
+                                                            View5 grid, View5 vox, View5 cnt)
+{
+    const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * kBlock) {
+        int n, c, h, w;
+        decode_pixel(D, idx, n, c, h, w);
+        float d_raw, gx, gy, gz, u_h, u_w, f;
+        if (!pixel_point<SPH>(D, depth, camdist, fl, grid, n, c, h, w, d_raw, gx, gy, gz, u_h, u_w, f)) continue;
+        const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
+        if (!in_grid(D, ix, iy, iz)) continue;
+        float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
+        const float s = *pv;
+        if (s < 0.0f) {                                               // still a raw (negated) sum
+            const float k = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
+            *pv = (0.0f - s) / k;                                     // :304 (mean distance)
+        }
+    }
+}
+
+// ---- K3: surface mask (:324-357), one lane per voxel, z fastest -----------------
+__device__ __forceinline__ int floor_i_d(double a) { return (a < 0) ? (int)a - 1 : (int)a; }
+__device__ __forceinline__ int round_i_d(double a)
+{   // ROUND_I (:42-43): FLOOR_F is (float)FLOOR_I; ties go down
+    const double ff = (double)(float)floor_i_d(a);
+    return (a - ff > ff + 1.0 - a) ? floor_i_d(a) + 1 : floor_i_d(a);
+}
+
+__global__ __launch_bounds__(kBlock) void surface_mask_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
+                                                               View5 cnt, View5 mask)
+{
+    const int64_t total = (int64_t)D.N * D.NC * D.X * D.Y * D.Z;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        int64_t r = i;
+        const int iz = (int)(r % D.Z); r /= D.Z;
+        const int iy = (int)(r % D.Y); r /= D.Y;
+        const int ix = (int)(r % D.X); r /= D.X;
+        const int c = (int)(r % D.NC);
+        const int n = (int)(r / D.NC);
+        float m = 1.0f;                                                // :853 fill
+        const float ptnum = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
+        if (!((double)ptnum > 1e-5)) {                                 // :333
+            const float f = fl.p[n * fl.s0 + c * fl.s1];
+            const float cam_dist = camdist.p[n * camdist.s0 + c * camdist.s1];
+            const float cx = centre_d(ix, D.X), cy = centre_d(iy, D.Y), cz = centre_d(iz, D.Z);
+            const float im_h = -cz * f / (cx + cam_dist);              // :339
+            const float im_w = -cy * f / (cx + cam_dist);              // :340
+            const int ih = round_i_d(0.5 * ((double)(float)D.H - 1.0) + (double)im_h);
+            const int iw = round_i_d(0.5 * ((double)(float)D.W - 1.0) + (double)im_w);
+            if (ih >= 0 && ih < D.H && iw >= 0 && iw < D.W) {
+                const float d = depth.p[n * depth.s0 + c * depth.s1 + ih * depth.s2 + iw * depth.s3];
+                if (!(d < 0.0f)) {
+                    const float ray = norm3(cx + cam_dist, cy, cz);    // :353
+                    if (d < ray) m = 0.0f;
+                }
+            }
+        }
+        mask.p[n * mask.s0 + c * mask.s1 + ix * mask.s2 + iy * mask.s3 + iz * mask.s4] = m;
+    }
+}
+
+// ---- K4: camera backward (:387-470) ----------------------------------------------
+// grid = (blocks per image, N*NC).  grad_depth is written for every pixel (0 where
+// the reference leaves its zero fill).  The two per-image scalars are reduced in
+// fp64 inside the wave (DPP/bpermute shuffles) and the block (LDS), then ONE fp32
+// atomic per block -- the reference does 2 same-address atomics per pixel.
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 depth, View2 fl, View2 camdist,
+                                                               View5 cnt, View5 gin, View4 gdepth,
+                                                               View2 gcam, View2 gfl)
+{
+    __shared__ double red[2][kBlock / 64];
+    const int img = blockIdx.y;
+    const int n = img / D.NC, c = img % D.NC;
+    const int npix = D.H * D.W;
+    double acc_fl = 0.0, acc_cd = 0.0;
+    const View5 nogrid = {nullptr, 0, 0, 0, 0, 0};
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < npix; p += gridDim.x * kBlock) {
+        const int h = p / D.W, w = p % D.W;
+        float gd_out = 0.0f;
+        float d_i, gx, gy, gz, u_h, u_w, f;
+        if (pixel_point<false>(D, depth, camdist, fl, nogrid, n, c, h, w, d_i, gx, gy, gz, u_h, u_w, f)) {
+            const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
+            if (in_grid(D, ix, iy, iz)) {
+                const float cx = centre_d(ix, D.X), cy = centre_d(iy, D.Y), cz = centre_d(iz, D.Z);
+                float L = norm3(u_h, u_w, f);                           // :432
+                if ((double)L < 1e-5) L = (float)1e-5;
+                const float rx = -f / L, ry = u_w / L, rz = u_h / L;    // :436-438
+                float Dn = norm3(gx - cx, gy - cy, gz - cz);            // :440
+                if ((double)Dn < 1e-5) Dn = (float)1e-5;
+                const float qx = (gx - cx) / Dn, qy = (gy - cy) / Dn, qz = (gz - cz) / Dn;
+                const float cos_cc = (rx * qx) + (ry * qy) + (rz * qz); // :448
+                float ptnum = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
+                if (ptnum < 1.0f) ptnum = 1.0f;
+                const float gd = gin.p[n * gin.s0 + c * gin.s1 + ix * gin.s2 + iy * gin.s3 + iz * gin.s4];
+                gd_out = -gd * cos_cc / ptnum;                          // :455
+                const float L3 = L * L * L;
+                const float gfx = ((gx - cx) / Dn) * (u_w * u_w + u_h * u_h) / L3;   // :459
+                const float gfy = ((gy - cy) / Dn) * (u_w * f) / L3;                 // :460
+                const float gfz = ((gz - cz) / Dn) * (u_h * f) / L3;                 // :461
+                acc_fl += (double)((gfx + gfy + gfz) * gd * d_i / ptnum);            // :462
+                acc_cd += (double)(-qx * gd / ptnum);                                // :469
+            }
+        }
+        gdepth.p[n * gdepth.s0 + c * gdepth.s1 + h * gdepth.s2 + w * gdepth.s3] = gd_out;
+    }
+    acc_fl = wave_sum(acc_fl);
+    acc_cd = wave_sum(acc_cd);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = acc_fl; red[1][wv] = acc_cd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int i = 0; i < kBlock / 64; i++) { a += red[0][i]; b += red[1][i]; }
+        unsafeAtomicAdd(gfl.p + n * gfl.s0 + c * gfl.s1, (float)a);
+        unsafeAtomicAdd(gcam.p + n * gcam.s0 + c * gcam.s1, (float)b);
+    }
+}
+
+__global__ void zero2_kernel(View2 a, View2 b, int N, int NC)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * NC) {
+        const int n = i / NC, c = i % NC;
+        a.p[n * a.s0 + c * a.s1] = 0.0f;
+        b.p[n * b.s0 + c * b.s1] = 0.0f;
+    }
+}
+
+// ---- K6: spherical backward (:560-626) ---------------------------------------------
+__global__ __launch_bounds__(kBlock) void sph_backward_kernel(Dims D, View4 depth, View5 grid, View5 cnt,
+                                                               View5 gin, View4 gdepth)
+{
+    const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
+    const View2 none = {nullptr, 0, 0};
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * kBlock) {
+        int n, c, h, w;
+        decode_pixel(D, idx, n, c, h, w);
+        float out = 0.0f;
+        float d, gx, gy, gz, u_h, u_w, f;
+        if (pixel_point<true>(D, depth, none, none, grid, n, c, h, w, d, gx, gy, gz, u_h, u_w, f)) {
+            const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
+            if (in_grid(D, ix, iy, iz)) {
+                const float cx = centre_d(ix, D.X), cy = centre_d(iy, D.Y), cz = centre_d(iz, D.Z);
+                float L = norm3(gx, gy, gz);                            // :600
+                if ((double)L < 1e-5) L = (float)1e-5;
+                const float rx = gx / L, ry = gy / L, rz = gz / L;
+                const float cos_cc = (rx * cx) + (ry * cy) + (rz * cz); // :608
+                float dist = norm3(gx - cx, gy - cy, gz - cz);          // :609
+                float ptnum = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
+                if (ptnum < 1.0f) ptnum = 1.0f;
+                if ((double)dist < 1e-5) dist = (float)1e-5;
+                const float gd = gin.p[n * gin.s0 + c * gin.s1 + ix * gin.s2 + iy * gin.s3 + iz * gin.s4];
+                out = gd * (d - cos_cc) / (ptnum * dist);               // :621
+            }
+        }
+        gdepth.p[n * gdepth.s0 + c * gdepth.s1 + h * gdepth.s2 + w * gdepth.s3] = out;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------
+inline int grid_for(int64_t work_items, int cap_blocks = kCUs * 8)
+{
+    int64_t b = (work_items + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    return (int)(b > cap_blocks ? cap_blocks : b);
+}
+
+// shape checks of cambp_shapecheck (:105-144 / :146-184)
+int check_image(const char *op, const genre_tensor *depth, Dims &D)
+{
+    GENRE_REQUIRE(is_f32(depth, 4), "%s: depth must be a 4-D fp32 tensor [N,NC,H,W]", op);
+    D.N = (int)depth->size[0]; D.NC = (int)depth->size[1]; D.H = (int)depth->size[2]; D.W = (int)depth->size[3];
+    GENRE_REQUIRE((int64_t)D.N * D.NC * D.H * D.W < (int64_t)1 << 31, "%s: depth too large", op);
+    return 1;
+}
+int check_scalar(const char *op, const char *name, const genre_tensor *t, const Dims &D)
+{
+    GENRE_REQUIRE(is_f32(t, 2) && t->size[0] == D.N && t->size[1] == D.NC,
+                  "%s: %s must be a 2-D fp32 tensor [N=%d,NC=%d]", op, name, D.N, D.NC);
+    return 1;
+}
+int check_volume(const char *op, const char *name, const genre_tensor *t, Dims &D, bool set)
+{
+    GENRE_REQUIRE(is_f32(t, 5) && t->size[0] == D.N && t->size[1] == D.NC,
+                  "%s: %s must be a 5-D fp32 tensor [N=%d,NC=%d,X,Y,Z]", op, name, D.N, D.NC);
+    if (set) { D.X = (int)t->size[2]; D.Y = (int)t->size[3]; D.Z = (int)t->size[4]; }
+    GENRE_REQUIRE(t->size[2] == D.X && t->size[3] == D.Y && t->size[4] == D.Z,
+                  "%s: %s spatial size must be [%d,%d,%d]", op, name, D.X, D.Y, D.Z);
+    return 1;
+}
+int check_map(const char *op, const char *name, const genre_tensor *t, const Dims &D)
+{
+    GENRE_REQUIRE(is_f32(t, 4) && t->size[0] == D.N && t->size[1] == D.NC && t->size[2] == D.H &&
+                      t->size[3] == D.W,
+                  "%s: %s must be a 4-D fp32 tensor [%d,%d,%d,%d]", op, name, D.N, D.NC, D.H, D.W);
+    return 1;
+}
+
+int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_tensor *b, float vb,
+                 hipStream_t st)
+{
+    const int64_t total = (int64_t)D.N * D.NC * D.X * D.Y * D.Z;
+    if (total == 0) return 1;
+    if (is_contiguous(a) && is_contiguous(b) && (total % 4) == 0 && aligned16(a->data) && aligned16(b->data)) {
+        fill2_vec4_kernel<<<grid_for(total / 4), kBlock, 0, st>>>((float4 *)a->data, va, (float4 *)b->data, vb,
+                                                                  total / 4);
+    } else {
+        fill2_strided_kernel<<<grid_for(total), kBlock, 0, st>>>(D, view5(a), va, view5(b), vb);
+    }
+    GENRE_LAUNCH_CHECK("fill");
+    return 1;
+}
+
+template <bool SPH>
+int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *camdist, const genre_tensor *fl,
+                 const genre_tensor *grid, const genre_tensor *voxel, const genre_tensor *cnt, void *stream)
+{
+    Dims D{};
+    if (!check_image(op, depth, D)) return 0;
+    View2 vcd{nullptr, 0, 0}, vfl{nullptr, 0, 0};
+    View5 vgrid{nullptr, 0, 0, 0, 0, 0};
+    if (SPH) {
+        GENRE_REQUIRE(is_f32(grid, 5) && grid->size[0] == D.N && grid->size[1] == D.NC &&
+                          grid->size[2] == D.H && grid->size[3] == D.W && grid->size[4] == 3,
+                      "%s: grid must be a 5-D fp32 tensor [%d,%d,%d,%d,3]", op, D.N, D.NC, D.H, D.W);
+        vgrid = view5(grid);
+    } else {
+        if (!check_scalar(op, "camdist", camdist, D) || !check_scalar(op, "fl", fl, D)) return 0;
+        vcd = view2(camdist); vfl = view2(fl);
+    }
+    if (!check_volume(op, "voxel", voxel, D, true) || !check_volume(op, "cnt", cnt, D, false)) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int mx = D.X > D.Y ? (D.X > D.Z ? D.X : D.Z) : (D.Y > D.Z ? D.Y : D.Z);
+    // camera path: prefill 1/res (cam_back_projection.py:23-24) and bias 1/max(res) (:304,:829) are the
+    // same number for the cubic grids the reference builds; spherical path: prefill 0, bias 0 (:695).
+    const float empty_val = SPH ? 0.0f : (float)(1.0 / (double)mx);
+    if (!launch_fill2(D, voxel, empty_val, cnt, 0.0f, st)) return 0;
+    const int64_t npix = (int64_t)D.N * D.NC * D.H * D.W;
+    if (npix == 0 || (int64_t)D.X * D.Y * D.Z == 0) return 1;
+    const int g = grid_for(npix);
+    scatter_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), empty_val);
+    GENRE_LAUNCH_CHECK("projection forward");
+    normalise_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt));
+    GENRE_LAUNCH_CHECK("safe divide");
+    return 1;
+}
+
+}  // namespace
+}  // namespace genre
+
+using namespace genre;
+
+extern "C" int genre_back_projection_forward(const genre_tensor *depth, const genre_tensor *camdist,
+                                             const genre_tensor *fl, const genre_tensor *voxel,
+                                             const genre_tensor *cnt, void *stream)
+{
+    return forward_impl<false>("back_projection_forward", depth, camdist, fl, nullptr, voxel, cnt, stream);
+}
+
+extern "C" int genre_spherical_back_proj_forward(const genre_tensor *depth, const genre_tensor *grid_in,
+                                                 const genre_tensor *voxel, const genre_tensor *cnt,
+                                                 void *stream)
+{
+    return forward_impl<true>("spherical_back_proj_forward", depth, nullptr, nullptr, grid_in, voxel, cnt, stream);
+}
+
+extern "C" int genre_back_projection_backward(const genre_tensor *depth, const genre_tensor *fl,
+                                              const genre_tensor *camdist, const genre_tensor *cnt,
+                                              const genre_tensor *grad_in, const genre_tensor *grad_depth,
+                                              const genre_tensor *grad_camdist, const genre_tensor *grad_fl,
+                                              void *stream)
+{
+    const char *op = "back_projection_backward";
+    Dims D{};
+    if (!check_image(op, depth, D) || !check_scalar(op, "fl", fl, D) || !check_scalar(op, "camdist", camdist, D) ||
+        !check_volume(op, "cnt", cnt, D, true) || !check_volume(op, "grad_in", grad_in, D, false) ||
+        !check_map(op, "grad_depth", grad_depth, D) || !check_scalar(op, "grad_camdist", grad_camdist, D) ||
+        !check_scalar(op, "grad_fl", grad_fl, D))
+        return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int imgs = D.N * D.NC;
+    if (imgs == 0) return 1;
+    zero2_kernel<<<ceil_div(imgs, 256), 256, 0, st>>>(view2(grad_camdist), view2(grad_fl), D.N, D.NC);
+    GENRE_LAUNCH_CHECK("zero grads");
+    const int npix = D.H * D.W;
+    if (npix == 0) return 1;
+    GENRE_REQUIRE(imgs <= 65535, "%s: N*NC must be <= 65535", op);
+    int bx = ceil_div(npix, kBlock);
+    if (bx > 256) bx = 256;
+    cam_backward_kernel<<<dim3(bx, imgs), kBlock, 0, st>>>(D, view4(depth), view2(fl), view2(camdist), view5(cnt),
+                                                          view5(grad_in), view4(grad_depth), view2(grad_camdist),
+                                                          view2(grad_fl));
+    GENRE_LAUNCH_CHECK("projection backward");
+    return 1;
+}
+
+extern "C" int genre_get_surface_mask(const genre_tensor *depth, const genre_tensor *camdist,
+                                      const genre_tensor *fl, const genre_tensor *cnt,
+                                      const genre_tensor *mask, void *stream)
+{
+    const char *op = "get_surface_mask";
+    Dims D{};
+    if (!check_image(op, depth, D) || !check_scalar(op, "camdist", camdist, D) || !check_scalar(op, "fl", fl, D) ||
+        !check_volume(op, "mask", mask, D, true) || !check_volume(op, "cnt", cnt, D, false))
+        return 0;
+    const int64_t total = (int64_t)D.N * D.NC * D.X * D.Y * D.Z;
+    if (total == 0) return 1;
+    surface_mask_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(D, view4(depth), view2(camdist),
+                                                                              view2(fl), view5(cnt), view5(mask));
+    GENRE_LAUNCH_CHECK("surface mask");
+    return 1;
+}
+
+extern "C" int genre_spherical_back_proj_backward(const genre_tensor *depth, const genre_tensor *grid_in,
+                                                  const genre_tensor *cnt, const genre_tensor *grad_in,
+                                                  const genre_tensor *grad_depth, void *stream)
+{
+    const char *op = "spherical_back_proj_backward";
+    Dims D{};
+    if (!check_image(op, depth, D)) return 0;
+    GENRE_REQUIRE(is_f32(grid_in, 5) && grid_in->size[0] == D.N && grid_in->size[1] == D.NC &&
+                      grid_in->size[2] == D.H && grid_in->size[3] == D.W && grid_in->size[4] == 3,
+                  "%s: grid must be a 5-D fp32 tensor [%d,%d,%d,%d,3]", op, D.N, D.NC, D.H, D.W);
+    if (!check_volume(op, "cnt", cnt, D, true) || !check_volume(op, "grad_in", grad_in, D, false) ||
+        !check_map(op, "grad_depth", grad_depth, D))
+        return 0;
+    const int64_t npix = (int64_t)D.N * D.NC * D.H * D.W;
+    if (npix == 0) return 1;
+    sph_backward_kernel<<<grid_for(npix), kBlock, 0, (hipStream_t)stream>>>(D, view4(depth), view5(grid_in),
+                                                                            view5(cnt), view5(grad_in),
+                                                                            view4(grad_depth));
+    GENRE_LAUNCH_CHECK("spherical projection backward");
+    return 1;
+}

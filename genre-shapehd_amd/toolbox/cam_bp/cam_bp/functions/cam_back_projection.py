@@ -1,0 +1,46 @@
+"""CameraBackProjection -- drop-in for the reference's autograd Function
+(toolbox/cam_bp/cam_bp/functions/cam_back_projection.py:9-46): same signature,
+same returned gradients ``(grad_depth, grad_fl, grad_camdist, None)``.
+
+Differences that do not change results: outputs are ``torch.empty`` (the native
+op writes every element, so the reference's two ``zero_()`` passes and the
+``+ 1/res`` pass, :22-24, disappear), and ``cnt`` is kept both on ``ctx`` (as the
+reference does, :28) and in ``saved_tensors``.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .._ext import cam_bp_lib
+
+
+class CameraBackProjection(Function):
+
+    @staticmethod
+    def forward(ctx, depth_t, fl, cam_dist, res=128):
+        assert depth_t.dim() == 4
+        n, nc = depth_t.shape[0], depth_t.shape[1]
+        assert fl.dim() == 2 and tuple(fl.shape) == (n, nc)
+        assert cam_dist.dim() == 2 and tuple(cam_dist.shape) == (n, nc)
+        assert depth_t.is_cuda and fl.is_cuda and cam_dist.is_cuda
+        tdf = torch.empty((n, nc, res, res, res), dtype=depth_t.dtype, device=depth_t.device)
+        cnt = torch.empty_like(tdf)
+        cam_bp_lib.back_projection_forward(depth_t, cam_dist, fl, tdf, cnt)
+        ctx.save_for_backward(depth_t, fl, cam_dist, cnt)
+        ctx.cnt_forward = cnt
+        ctx.depth_shape = depth_t.shape
+        return tdf
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        assert grad_output.is_cuda
+        depth_t, fl, cam_dist, cnt = ctx.saved_tensors
+        n, nc = ctx.depth_shape[0], ctx.depth_shape[1]
+        grad_depth = torch.empty(ctx.depth_shape, dtype=grad_output.dtype, device=grad_output.device)
+        grad_fl = torch.empty((n, nc), dtype=grad_output.dtype, device=grad_output.device)
+        grad_camdist = torch.empty_like(grad_fl)
+        # note the fl / cam_dist order flip between forward and backward (back_projection.h:1-2)
+        cam_bp_lib.back_projection_backward(depth_t, fl, cam_dist, cnt, grad_output,
+                                            grad_depth, grad_camdist, grad_fl)
+        return grad_depth, grad_fl, grad_camdist, None

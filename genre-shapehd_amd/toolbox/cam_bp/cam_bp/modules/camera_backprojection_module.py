@@ -1,0 +1,39 @@
+"""Camera_back_projection_layer -- drop-in for
+toolbox/cam_bp/cam_bp/modules/camera_backprojection_module.py:6-28 (the only live class of
+that file; its `camera_backprojection` and Spherical_backproj.py classes reference undefined
+names in the reference and are not reproduced)."""
+import torch
+from torch import nn
+
+from ..functions import CameraBackProjection
+
+
+class Camera_back_projection_layer(nn.Module):
+    def __init__(self, res=128):
+        super().__init__()
+        assert res == 128
+        self.res = 128
+        self._consts = {}
+
+    def _const(self, value, n, device):
+        # the reference allocates + fills a fresh [n,1] tensor every call (:16-21); cache it so the
+        # layer issues no extra kernels and can be captured in a HIP graph
+        key = (float(value), n, str(device))
+        t = self._consts.get(key)
+        if t is None:
+            t = torch.full((n, 1), float(value), dtype=torch.float32, device=device)
+            self._consts[key] = t
+        return t
+
+    def forward(self, depth_t, fl=418.3, cam_dist=2.2, shift=True):
+        n = depth_t.size(0)
+        if type(fl) == float:
+            fl = self._const(fl, n, depth_t.device)
+        if type(cam_dist) == float:
+            cam_dist = self._const(cam_dist, n, depth_t.device)
+        df = CameraBackProjection.apply(depth_t, fl, cam_dist, self.res)
+        return self.shift_tdf(df) if shift else df
+
+    @staticmethod
+    def shift_tdf(input_tdf, res=128):
+        return 1 - res * input_tdf

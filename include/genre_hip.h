@@ -1,0 +1,149 @@
+/*
+ * genre_hip.h -- C ABI of libgenre_hip.so: MI355X (gfx950) kernels for the
+ * geometric hot path of GenRe / ShapeHD.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one cffi-exported C
+ * function of the reference (xiumingzhang/GenRe-ShapeHD); argument ORDER is the
+ * reference's, `THCudaTensor*` becomes `const genre_tensor*` (a plain
+ * pointer + sizes + element strides descriptor -- no torch types), and a
+ * `hipStream_t` (passed as void*) is appended.  Conventions kept from the
+ * reference:
+ *   - the caller allocates every output (cam_back_projection.py:22-25,39-45);
+ *     the library never allocates device memory and keeps no global state;
+ *   - return 1 on success, 0 on failure (back_projection.c:13-15 turns 0 into
+ *     THError("aborting")); on 0, genre_last_error() returns a thread-local
+ *     message -- shape/dtype violations that THArgCheck / THCUNN_check_dim_size
+ *     (back_projection_kernel.cu:85-97,105-184) would have raised, or the HIP
+ *     launch error string;
+ *   - all work is enqueued asynchronously on `stream` (the reference used THC's
+ *     current stream, back_projection_kernel.cu:647; its nndistance launcher
+ *     ignored the stream, nnd_cuda.cu:130-131 -- here every op honours it);
+ *     no host synchronisation inside any call; re-entrant and thread-safe.
+ *   - cam_bp / calc_prob tensors may have arbitrary element strides (the
+ *     reference kernels are stride-generic; an expand()ed `grid` with batch
+ *     stride 0 is legal); nndistance tensors must be contiguous (nnd.py:16).
+ * Outputs are fully defined by the call: every element of every output tensor
+ * is written (the fills the reference did in Python / THCudaTensor_zero are
+ * part of the op), so callers may pass uninitialised memory.
+ *
+ * All data is fp32 (GENRE_F32) except nndistance indices (GENRE_I32).
+ */
+#ifndef GENRE_HIP_H
+#define GENRE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENRE_ABI_VERSION 1
+#define GENRE_MAX_DIMS 5
+
+enum { GENRE_F32 = 0, GENRE_I32 = 1 };
+
+/* Tensor view: device pointer, sizes and ELEMENT strides (not bytes). */
+typedef struct genre_tensor {
+    void   *data;
+    int32_t ndim;
+    int32_t dtype;                   /* GENRE_F32 | GENRE_I32 */
+    int64_t size[GENRE_MAX_DIMS];
+    int64_t stride[GENRE_MAX_DIMS];
+} genre_tensor;
+
+/* ABI version of the loaded library (== GENRE_ABI_VERSION it was built with). */
+int genre_abi_version(void);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char *genre_last_error(void);
+
+/* ---- cam_bp : toolbox/cam_bp/cam_bp/src/back_projection.h:1-5 ------------- */
+
+/* Replaces back_projection_forward (back_projection.c:9-17 ->
+ * back_projection_forward_wrap, back_projection_kernel.cu:760-838; kernels
+ * :200-276 and :282-306) INCLUDING the Python prefill of
+ * cam_back_projection.py:22-24.
+ *   depth [N,NC,H,W]  camdist [N,NC]  fl [N,NC]  ->  voxel, cnt [N,NC,X,Y,Z]
+ * voxel = mean distance of the back-projected points of a voxel to its centre,
+ * 1/max(X,Y,Z) where no point fell; cnt = number of points (integer-valued). */
+int genre_back_projection_forward(const genre_tensor *depth, const genre_tensor *camdist,
+                                  const genre_tensor *fl, const genre_tensor *voxel,
+                                  const genre_tensor *cnt, void *stream);
+
+/* Replaces back_projection_backward (back_projection.c:20-28 -> :897-963,
+ * kernel :366-471).  NOTE fl/camdist swap places relative to forward, as in the
+ * reference.  grad_depth [N,NC,H,W], grad_camdist / grad_fl [N,NC] are fully
+ * written (zero where the reference leaves its zero fill).  camdist is read
+ * with its own strides (the reference's :401 uses the cnt strides -- an
+ * out-of-bounds read for n>0 that is not reproduced). */
+int genre_back_projection_backward(const genre_tensor *depth, const genre_tensor *fl,
+                                   const genre_tensor *camdist, const genre_tensor *cnt,
+                                   const genre_tensor *grad_in, const genre_tensor *grad_depth,
+                                   const genre_tensor *grad_camdist, const genre_tensor *grad_fl,
+                                   void *stream);
+
+/* Replaces get_surface_mask (back_projection.c:30-38 -> :840-891, kernel
+ * :310-358).  mask [N,NC,X,Y,Z] := 1, except 0 for empty voxels (cnt <= 1e-5)
+ * that lie behind the observed surface. */
+int genre_get_surface_mask(const genre_tensor *depth, const genre_tensor *camdist,
+                           const genre_tensor *fl, const genre_tensor *cnt,
+                           const genre_tensor *mask, void *stream);
+
+/* Replaces spherical_back_proj_forward (back_projection.c:40-48 -> :629-703,
+ * kernels :475-542 and :282-306 with bias 0) INCLUDING the zero fills of
+ * sperical_to_tdf.py:23-25.
+ *   depth [N,NC,H,W]  grid_in [N,NC,H,W,3] (any strides)  ->  voxel, cnt */
+int genre_spherical_back_proj_forward(const genre_tensor *depth, const genre_tensor *grid_in,
+                                      const genre_tensor *voxel, const genre_tensor *cnt,
+                                      void *stream);
+
+/* Replaces spherical_back_proj_backward (back_projection.c:49-57 -> :704-757,
+ * kernel :545-627).  grad_depth [N,NC,H,W] fully written. */
+int genre_spherical_back_proj_backward(const genre_tensor *depth, const genre_tensor *grid_in,
+                                       const genre_tensor *cnt, const genre_tensor *grad_in,
+                                       const genre_tensor *grad_depth, void *stream);
+
+/* ---- calc_prob : toolbox/calc_prob/calc_prob/src/calc_prob.h:1-2 ---------- */
+
+/* Replaces calc_prob_forward (calc_prob.c:9-17 -> calc_prob_kernel.cu:191-226,
+ * kernel :113-143).  prob_in, prob_out [N,NC,X,Y,Z]; rays run along Z:
+ *   out[z] = in[z] * prod_{k<z} (1 - in[k])                                   */
+int genre_calc_prob_forward(const genre_tensor *prob_in, const genre_tensor *prob_out,
+                            void *stream);
+
+/* Replaces calc_prob_backward (calc_prob.c:18-26 -> :227-266, kernel
+ * :146-189).  stop_prob_weighted = stop_prob * grad (formed by the caller,
+ * calc_prob.py:27):  grad_out[z] = w[z]/p[z] - (sum_{j>z} w[j]) / (1 - p[z])  */
+int genre_calc_prob_backward(const genre_tensor *prob_in, const genre_tensor *stop_prob_weighted,
+                             const genre_tensor *grad_out, void *stream);
+
+/* Extension (no reference counterpart): same as genre_calc_prob_backward but
+ * forms w = stop_prob * grad_in inside the kernel (fp32 product, as
+ * calc_prob.py:27 does), saving one 3-tensor elementwise pass. */
+int genre_calc_prob_backward_fused(const genre_tensor *prob_in, const genre_tensor *stop_prob,
+                                   const genre_tensor *grad_in, const genre_tensor *grad_out,
+                                   void *stream);
+
+/* ---- nndistance : toolbox/nndistance/src/my_lib_cuda.h:1-4 ---------------- */
+
+/* Replaces nnd_forward_cuda (my_lib_cuda.c:9-27 -> NmDistanceKernelLauncher,
+ * nnd_cuda.cu:129-141; kernel :6-128) and, for values, the CPU nnd_forward
+ * (my_lib.c:30-49).  xyz1 [B,n,3], xyz2 [B,m,3] contiguous fp32 ->
+ * dist1 [B,n], dist2 [B,m] squared L2 to the nearest neighbour in the other
+ * cloud; idx1, idx2 int32 its index (lowest index among equal distances). */
+int genre_nnd_forward(const genre_tensor *xyz1, const genre_tensor *xyz2,
+                      const genre_tensor *dist1, const genre_tensor *dist2,
+                      const genre_tensor *idx1, const genre_tensor *idx2, void *stream);
+
+/* Replaces nnd_backward_cuda (my_lib_cuda.c:30-54 -> NmDistanceGradKernelLauncher,
+ * nnd_cuda.cu:163-177; kernel :143-162).  gradxyz1 [B,n,3], gradxyz2 [B,m,3]
+ * fully written (the reference memsets them, :164-165). */
+int genre_nnd_backward(const genre_tensor *xyz1, const genre_tensor *xyz2,
+                       const genre_tensor *gradxyz1, const genre_tensor *gradxyz2,
+                       const genre_tensor *graddist1, const genre_tensor *graddist2,
+                       const genre_tensor *idx1, const genre_tensor *idx2, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENRE_HIP_H */

@@ -1,0 +1,189 @@
+"""GPU parity: cam_bp family -- HIP kernels through the C ABI /
+autograd Functions vs the CPU oracle on the same seeded inputs.
+
+Bars: cnt (integer-valued fp32) bit-exact; tdf / gradients within 1e-5 absolute (fp32), the
+tolerance north_star states; masks bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def depth_cases():
+    return {
+        "sphere": inputs.sphere_depth(),
+        "sphere_noise": inputs.sphere_depth(noise_seed=2),
+        "random30": inputs.random_depth(seed=5),
+        "random_negbg": inputs.random_depth(seed=6, negative_bg=True),
+        "empty": np.zeros((1, 1, 256, 256), np.float32),
+        "small_odd": inputs.sphere_depth(64, 64, noise_seed=3),
+    }
+
+
+@pytest.mark.parametrize("name", list(depth_cases()))
+def test_camera_forward(name, genre, oracle, dev):
+    d = depth_cases()[name]
+    fl, cd = inputs.cam_params(1)
+    tdf_o, cnt_o = oracle.back_projection_forward(d, cd, fl)
+    tdf = genre.CameraBackProjection.apply(t(d, dev), t(fl, dev), t(cd, dev), 128)
+    lib = genre.CameraBackProjection  # cnt via the plain function
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp.functions.get_surface_mask import get_vox_surface_cnt
+    cnt = get_vox_surface_cnt(t(d, dev), t(fl, dev), t(cd, dev), 128)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o), "cnt must be exact"
+    diff = np.abs(tdf.cpu().numpy() - tdf_o).max()
+    assert diff <= TOL, diff
+    # voxels hit by exactly one point have no summation-order freedom: bit-exact
+    one = cnt_o == 1
+    assert np.array_equal(tdf.cpu().numpy()[one], tdf_o[one])
+    assert np.array_equal(tdf.cpu().numpy()[cnt_o == 0], tdf_o[cnt_o == 0])
+
+
+def test_camera_forward_is_idempotent_on_dirty_outputs(genre, oracle, dev):
+    """outputs are fully defined by the call (no dependence on what the buffers held)"""
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    d = inputs.sphere_depth(noise_seed=2)
+    fl, cd = inputs.cam_params(1)
+    tdf_o, cnt_o = oracle.back_projection_forward(d, cd, fl)
+    tdf = torch.full((1, 1, 128, 128, 128), -7.0, device=dev)
+    cnt = torch.full((1, 1, 128, 128, 128), 3.0, device=dev)
+    for _ in range(2):
+        cam_bp_lib.back_projection_forward(t(d, dev), t(cd, dev), t(fl, dev), tdf, cnt)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert np.abs(tdf.cpu().numpy() - tdf_o).max() <= TOL
+
+
+def test_camera_forward_batch_and_channels(genre, oracle, dev):
+    d = inputs.batch_depth(3).reshape(3, 1, 256, 256)
+    d = np.concatenate([d, d[::-1]], 1)                      # NC = 2
+    fl = np.array([[418.3, 400.0], [430.0, 418.3], [418.3, 410.0]], np.float32)
+    cd = np.array([[2.2, 2.1], [2.3, 2.2], [2.2, 2.25]], np.float32)
+    tdf_o, cnt_o = oracle.back_projection_forward(d, cd, fl)
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp.functions.get_surface_mask import get_vox_surface_cnt
+    tdf = genre.CameraBackProjection.apply(t(d, dev), t(fl, dev), t(cd, dev), 128)
+    cnt = get_vox_surface_cnt(t(d, dev), t(fl, dev), t(cd, dev), 128)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert np.abs(tdf.cpu().numpy() - tdf_o).max() <= TOL
+
+
+def test_camera_forward_strided_inputs(genre, oracle, dev):
+    """the reference kernels are stride-generic (back_projection_kernel.cu:650-672)"""
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    d = inputs.sphere_depth(noise_seed=2)
+    fl, cd = inputs.cam_params(1)
+    tdf_o, cnt_o = oracle.back_projection_forward(d, cd, fl)
+    big = torch.zeros((1, 1, 256, 512), device=dev)
+    big[..., ::2] = t(d, dev)
+    dv = big[..., ::2]                                          # w stride 2
+    assert not dv.is_contiguous()
+    tdf = torch.empty((1, 1, 128, 128, 256), device=dev)[..., ::2]   # strided outputs too
+    cnt = torch.empty((1, 1, 128, 128, 256), device=dev)[..., ::2]
+    cam_bp_lib.back_projection_forward(dv, t(cd, dev), t(fl, dev), tdf, cnt)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert np.abs(tdf.cpu().numpy() - tdf_o).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["sphere", "sphere_noise", "random30"])
+def test_camera_backward(name, genre, oracle, dev):
+    d = depth_cases()[name]
+    fl, cd = inputs.cam_params(1)
+    _, cnt_o = oracle.back_projection_forward(d, cd, fl)
+    g = np.random.default_rng(4).standard_normal(cnt_o.shape).astype(np.float32)
+    gd_o, gc_o, gf_o, gc_d, gf_d = oracle.back_projection_backward(d, fl, cd, cnt_o, g, with_double=True)
+    dt = t(d, dev).requires_grad_(True)
+    flt = t(fl, dev).requires_grad_(True)
+    cdt = t(cd, dev).requires_grad_(True)
+    tdf = genre.CameraBackProjection.apply(dt, flt, cdt, 128)
+    tdf.backward(t(g, dev))
+    assert np.abs(dt.grad.cpu().numpy() - gd_o).max() <= TOL
+    # per-pixel terms are bit-identical; only the summation differs.  The reference adds ~19k fp32
+    # terms serially (its own rounding noise ~1e-5 relative); we reduce in fp64.  Check against the
+    # fp64-accumulated oracle tightly and against the fp32 serial oracle at its own noise level.
+    assert abs(flt.grad.item() - gf_d.item()) <= 1e-6 * max(1.0, abs(gf_d.item()))
+    assert abs(cdt.grad.item() - gc_d.item()) <= 1e-6 * max(1.0, abs(gc_d.item()))
+    assert abs(flt.grad.item() - gf_o.item()) <= 1e-4 * max(1.0, abs(gf_o.item()))
+    assert abs(cdt.grad.item() - gc_o.item()) <= 1e-4 * max(1.0, abs(gc_o.item()))
+
+
+def test_camera_backward_batch(genre, oracle, dev):
+    """bwd at N>1 is defined per sample (the reference reads camdist out of bounds for n>0, F8)"""
+    d = inputs.batch_depth(3).reshape(3, 1, 256, 256)
+    fl = np.array([[418.3], [430.0], [400.0]], np.float32)
+    cd = np.array([[2.2], [2.3], [2.1]], np.float32)
+    _, cnt_o = oracle.back_projection_forward(d, cd, fl)
+    g = np.random.default_rng(4).standard_normal(cnt_o.shape).astype(np.float32)
+    dt = t(d, dev).requires_grad_(True)
+    flt = t(fl, dev).requires_grad_(True)
+    cdt = t(cd, dev).requires_grad_(True)
+    genre.CameraBackProjection.apply(dt, flt, cdt, 128).backward(t(g, dev))
+    for i in range(3):
+        gd_o, gc_o, gf_o, gc_d, gf_d = oracle.back_projection_backward(
+            d[i:i + 1], fl[i:i + 1], cd[i:i + 1], cnt_o[i:i + 1], g[i:i + 1], with_double=True)
+        assert np.abs(dt.grad[i:i + 1].cpu().numpy() - gd_o).max() <= TOL
+        assert abs(flt.grad[i].item() - gf_d.item()) <= 1e-6 * max(1.0, abs(gf_d.item()))
+        assert abs(cdt.grad[i].item() - gc_d.item()) <= 1e-6 * max(1.0, abs(gc_d.item()))
+
+
+@pytest.mark.parametrize("name", ["sphere", "sphere_noise", "random_negbg"])
+def test_surface_mask(name, genre, oracle, dev):
+    d = depth_cases()[name]
+    fl, cd = inputs.cam_params(1, fl=784.4645406, cam_dist=2.0)     # get_surface_mask.py:25 defaults
+    _, cnt_o = oracle.back_projection_forward(d, cd, fl)
+    mask_o = oracle.get_surface_mask(d, cd, fl, cnt_o)
+    surf, mask = genre.get_surface_mask(t(d, dev))
+    assert np.array_equal(surf.cpu().numpy(), np.clip(cnt_o, 0, 1))
+    assert np.array_equal(mask.cpu().numpy(), mask_o)
+
+
+def test_layer_shift(genre, oracle, dev):
+    d = inputs.sphere_depth(noise_seed=2)
+    fl, cd = inputs.cam_params(1)
+    tdf_o, _ = oracle.back_projection_forward(d, cd, fl)
+    layer = genre.Camera_back_projection_layer().to(dev)
+    out = layer(t(d, dev))                                       # fl=418.3, cam_dist=2.2, shift
+    assert np.abs(out.cpu().numpy() - (1 - 128 * tdf_o)).max() <= 128 * TOL
+    out2 = layer(t(d, dev), shift=False)
+    assert np.abs(out2.cpu().numpy() - tdf_o).max() <= TOL
+
+
+# ---- spherical back-projection -------------------------------------------------------------
+@pytest.mark.parametrize("batch", [1, 3])
+def test_spherical_forward_backward(batch, genre, oracle, dev):
+    s = np.concatenate([inputs.sph_depth_map(seed=7 + i) for i in range(batch)])
+    g = inputs.gen_sph_grid_np()
+    gb = np.broadcast_to(g, (batch, 1, 128, 128, 3))
+    tdf_o, cnt_o = oracle.spherical_back_proj_forward(s, gb)
+    gi = np.random.default_rng(4).standard_normal(tdf_o.shape).astype(np.float32)
+    gd_o = oracle.spherical_back_proj_backward(s, gb, cnt_o, gi)
+    st = t(s, dev).requires_grad_(True)
+    grid = genre.gen_sph_grid(128).to(dev).expand(batch, -1, -1, -1, -1)      # batch stride 0
+    assert np.array_equal(grid[0].cpu().numpy(), g[0]), "gen_sph_grid must match the reference table"
+    tdf, cnt = genre.SphericalBackProjection.apply(st, grid, 128)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert np.abs(tdf.detach().cpu().numpy() - tdf_o).max() <= TOL
+    one = cnt_o == 1
+    assert np.array_equal(tdf.detach().cpu().numpy()[one], tdf_o[one])
+    tdf.backward(t(gi, dev))
+    diff = np.abs(st.grad.cpu().numpy() - gd_o)
+    scale = np.maximum(1.0, np.abs(gd_o))
+    assert (diff / scale).max() <= TOL, (diff / scale).max()
+
+
+def test_shape_errors_raise(genre, dev):
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    d = torch.zeros((1, 1, 8, 8), device=dev)
+    p = torch.zeros((1, 1), device=dev)
+    v = torch.zeros((1, 1, 4, 4, 4), device=dev)
+    with pytest.raises(RuntimeError, match="cnt"):
+        cam_bp_lib.back_projection_forward(d, p, p, v, torch.zeros((1, 1, 4, 4, 5), device=dev))
+    with pytest.raises(RuntimeError, match="camdist"):
+        cam_bp_lib.back_projection_forward(d, torch.zeros((2, 1), device=dev), p, v, v.clone())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        cam_bp_lib.back_projection_forward(d.cpu(), p, p, v, v.clone())
