@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path throughput on MI355X (contract: see the task statement / DESIGN.md).
+
+A "step" is ONE pass of BASELINE.json configs[1] over one batch of synthetic depth maps that is
+already resident in HBM:
+
+    depth [B,1,256,256] -> cam_bp fwd -> 128^3 TDF -> shift, x50, clamp -> render_spherical
+    (trilinear sampling of 128x128 rays x 256 samples, calc_prob stop-probability scan, depth
+    expectation) -> sph_pad -> [B,1,160,160]; then the backward of the same chain down to
+    grad_depth (calc_prob bwd, sampling bwd, cam_bp bwd).
+
+`value` = depth maps ("shapes") per second through that forward+backward chain, summed over
+all ranks (weak scaling: every rank owns its own batch; the path needs no collective).
+Besides the contract keys the JSON line carries
+  roofline     : the dominant hand-written kernel of the step against the 8 TB/s HBM roof
+                 (ALGORITHMIC bytes / measured kernel time, HIP events on the launch stream)
+  m2           : BASELINE's second metric, cam_bp fwd + calc_prob fwd bytes / their time
+  batch1       : the same at batch 1 (launch-bound regime; replayed from a HIP graph)
+  cpu_baseline : the same step on the host (reference kernel bodies host-compiled, or the C
+                 port), bounded sample, rank 0 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_CAM_FWD = 256 * 256 * 4 + 2 * 128 ** 3 * 4          # depth + tdf + cnt          = 17 039 360
+BYTES_CP_FWD = 2 * 128 * 128 * 256 * 4                    # prob in + stop out         = 33 554 432
+BYTES_CP_BWD_FUSED = 4 * 128 * 128 * 256 * 4              # p, s, grad in + grad out   = 67 108 864
+BYTES_RENDER_FUSED = 128 ** 3 * 4 + 128 * 128 * 4         # vox in + map out           =  8 454 144
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="depth maps per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="force the reference op sequence in render_spherical")
+    return ap.parse_args()
+
+
+class HotPath(torch.nn.Module):
+    """configs[1] with the product ops (depth_pred_with_sph_inpaint.py:120-126)."""
+
+    def __init__(self, G, fused):
+        super().__init__()
+        self.G = G
+        self.cam = G.Camera_back_projection_layer()
+        self.render = G.render_spherical(fused=fused)
+
+    def forward(self, depth):
+        proj = self.cam(depth)                                        # fl=418.3, cam_dist=2.2, 1-128*tdf
+        sph = self.render(torch.clamp(proj * 50, 1e-5, 1 - 1e-5))
+        return self.G.sph_pad(sph, 16)
+
+
+def event_time_us(fn, iters, warm):
+    """average duration of fn() in microseconds, HIP events on the current (launch) stream"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters
+
+
+def kernel_table(G, dev, B):
+    """time the hand-written kernels of the step in isolation (back-to-back launches)"""
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    from genre_shapehd_amd.toolbox.calc_prob.calc_prob._ext import calc_prob_lib
+    import inputs
+    d = torch.from_numpy(inputs.batch_depth(B)).to(dev)
+    fl = torch.full((B, 1), 418.3, device=dev)
+    cd = torch.full((B, 1), 2.2, device=dev)
+    tdf = torch.empty((B, 1, 128, 128, 128), device=dev)
+    cnt = torch.empty_like(tdf)
+    p = torch.rand((B, 1, 128, 128, 256), device=dev).clamp_(1e-5, 1 - 1e-5)
+    s = torch.empty_like(p)
+    g = torch.randn_like(p)
+    o = torch.empty_like(p)
+    iters = max(20, 400 // B)
+    rows = {}
+    t = event_time_us(lambda: cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt), iters, 5)
+    rows["cam_bp_fwd"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="fill2_vec4+scatter+normalise")
+    t = event_time_us(lambda: calc_prob_lib.calc_prob_forward(p, s), iters, 5)
+    rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel")
+    t = event_time_us(lambda: calc_prob_lib.calc_prob_backward_fused(p, s, g, o), iters, 5)
+    rows["calc_prob_bwd_fused"] = dict(us=t, bytes=B * BYTES_CP_BWD_FUSED, kernels="stop_bwd_vec4_kernel<fused>")
+    for r in rows.values():
+        r["GBs"] = r["bytes"] / r["us"] / 1e3
+    return rows
+
+
+def batch1_graph(G, dev):
+    """cam_bp fwd + calc_prob fwd at batch 1, replayed from a HIP graph (no host launch cost)"""
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    from genre_shapehd_amd.toolbox.calc_prob.calc_prob._ext import calc_prob_lib
+    import inputs
+    d = torch.from_numpy(inputs.sphere_depth(noise_seed=2)).to(dev)
+    fl = torch.full((1, 1), 418.3, device=dev)
+    cd = torch.full((1, 1), 2.2, device=dev)
+    tdf = torch.empty((1, 1, 128, 128, 128), device=dev)
+    cnt = torch.empty_like(tdf)
+    p = torch.rand((1, 1, 128, 128, 256), device=dev).clamp_(1e-5, 1 - 1e-5)
+    s = torch.empty_like(p)
+    reps = 20
+
+    def body():
+        for _ in range(reps):
+            cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt)
+            calc_prob_lib.calc_prob_forward(p, s)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        body()
+    us = event_time_us(graph.replay, 20, 3) / reps
+    nbytes = BYTES_CAM_FWD + BYTES_CP_FWD
+    return dict(us_per_image=us, GBs=nbytes / us / 1e3, frac=nbytes / us / 1e3 / HBM_PEAK_GBS,
+                launches_per_image=4, note="HIP-graph replay of 20x(cam_bp fwd + calc_prob fwd), batch 1")
+
+
+def cpu_baseline(budget_s):
+    """the same step on the host cores: reference kernel bodies (oracle/_ref) if they travelled
+    with the snapshot, else the C port; torch CPU ops (1 thread) for grid_sample/matmul."""
+    import inputs
+    from oracle.oracle import Oracle, Reference, reference_available
+    from oracle.torch_oracle import HotPathCPU
+    torch.set_num_threads(1)
+    backend = Reference() if reference_available() else Oracle()
+    hp = HotPathCPU(backend)
+    g = torch.from_numpy(np.random.default_rng(0).standard_normal((1, 1, 160, 160)).astype(np.float32))
+    depths = inputs.batch_depth(4)
+    hp.forward_backward(torch.from_numpy(depths[:1]), g)               # warm-up (grid tables, page-in)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        hp.forward_backward(torch.from_numpy(depths[n % 4:n % 4 + 1]), g)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return dict(value=n / el, unit="shapes/s", cores=1, kind=backend.kind,
+                sample="%d depth maps fwd+bwd through the same chain in %.1f s, 1 thread" % (n, el))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+
+    import inputs
+    import genre_shapehd_amd as G
+    from genre_shapehd_amd.toolbox import _fused_render
+    fused = (not args.unfused) and _fused_render.available()
+    model = HotPath(G, fused).to(dev)
+    B = args.batch
+    depth = torch.from_numpy(inputs.batch_depth(B, seed=100 + 1000 * rank)).to(dev).requires_grad_(True)
+    grad_out = torch.randn((B, 1, 160, 160), device=dev)
+
+    def step():
+        depth.grad = None
+        out = model(depth)
+        out.backward(grad_out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * B * args.steps / elapsed
+
+    if rank == 0:
+        rows = kernel_table(G, dev, B)
+        # dominant hand-written kernel of the step = the one moving the most algorithmic bytes
+        in_step = [k for k in rows if not (fused and k.startswith("calc_prob"))]
+        dom_name = max(in_step, key=lambda k: rows[k]["us"])
+        dom = rows[dom_name]
+        m2_us = rows["cam_bp_fwd"]["us"] + rows["calc_prob_fwd"]["us"]
+        m2_bytes = rows["cam_bp_fwd"]["bytes"] + rows["calc_prob_fwd"]["bytes"]
+        out = {
+            "metric": "hot-path shapes/sec (256x256 depth -> 128^3 vox -> 160x160 sph, fwd+bwd) ; "
+                      "cam_bp+calc_prob HBM GB/s vs roofline in m2",
+            "value": value, "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: cam_bp + calc_prob fwd/bwd, 256x256 depth -> 128^3 voxel -> "
+                                   "128x128x256 rays -> 160x160 spherical", "batch_per_gpu": B,
+                       "render_spherical": "fused" if fused else "reference op sequence (grid_sample + CalcStopProb)",
+                       "parallelism": "batch-sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": dom_name + " (" + dom["kernels"] + ")",
+                         "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["us"]},
+            "m2": {"what": "cam_bp fwd + calc_prob fwd, algorithmic bytes / time, batch %d" % B,
+                   "achieved": m2_bytes / m2_us / 1e3, "unit": "GB/s", "frac": m2_bytes / m2_us / 1e3 / HBM_PEAK_GBS,
+                   "us_per_image": m2_us / B},
+            "kernels": {k: {"us": round(v["us"], 2), "GBs": round(v["GBs"], 1)} for k, v in rows.items()},
+            "batch1": batch1_graph(G, dev),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@
 //
 // Index arithmetic (voxel index, centre, distance) is the reference's fp32
 // sequence, compiled with contraction OFF so that the voxel a point lands in
-// is bit-identical to the reference/oracle; `cnt` is therefore exact, and the
+// is bit-identical to the reference; `cnt` is therefore exact, and the
 // per-point distances are bit-exact (only the order of the float atomics,
 // which the reference does not define either, can differ).
 #include "common.hpp"

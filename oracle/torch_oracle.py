@@ -1,0 +1,151 @@
+"""CPU-torch restatement of the PyTorch-level pieces of the hot path -- TEST INFRASTRUCTURE ONLY.
+
+The reference's render_spherical / sph_pad / Camera_back_projection_layer.shift_tdf are plain
+PyTorch-0.4.1 ops around the native kernels (toolbox/spherical_proj.py:21-72,
+camera_backprojection_module.py:12-28).  Here they are restated on CPU torch with the native
+ops replaced by the C oracle (oracle.Oracle) or the host-compiled reference (oracle.Reference),
+wrapped in autograd Functions so a whole forward+backward chain can be checked / timed on
+the host.  ``grid_sample`` is called with ``align_corners=True`` -- the 0.4.1 semantics
+(environment.yml:14; today's default differs).
+
+Used by tests/ (parity of render_spherical and of the full chain) and by bench.py's
+cpu_baseline leg.  Never imported by the product.
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+
+def _np(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
+def make_functions(backend):
+    """autograd Functions over `backend` (an oracle.Oracle or oracle.Reference instance)"""
+
+    class CameraBackProjectionCPU(Function):
+        # cam_back_projection.py:12-46
+        @staticmethod
+        def forward(ctx, depth_t, fl, cam_dist, res=128):
+            tdf, cnt = backend.back_projection_forward(_np(depth_t), _np(cam_dist), _np(fl), res)
+            ctx.save_for_backward(depth_t, fl, cam_dist)
+            ctx.cnt = cnt
+            return torch.from_numpy(tdf)
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            depth_t, fl, cam_dist = ctx.saved_tensors
+            N = depth_t.shape[0]
+            gds, gcs, gfs = [], [], []
+            for i in range(N):        # per sample: the reference's K4 is only valid at N == 1 (F8)
+                r = backend.back_projection_backward(_np(depth_t[i:i + 1]), _np(fl[i:i + 1]),
+                                                     _np(cam_dist[i:i + 1]), ctx.cnt[i:i + 1],
+                                                     _np(grad_output[i:i + 1]))
+                gds.append(r[0]); gcs.append(r[1]); gfs.append(r[2])
+            return (torch.from_numpy(np.concatenate(gds)), torch.from_numpy(np.concatenate(gfs)),
+                    torch.from_numpy(np.concatenate(gcs)), None)
+
+    class CalcStopProbCPU(Function):
+        # calc_prob.py:10-29
+        @staticmethod
+        def forward(ctx, prob_in):
+            s = torch.from_numpy(backend.calc_prob_forward(_np(prob_in)))
+            ctx.save_for_backward(prob_in, s)
+            return s
+
+        @staticmethod
+        def backward(ctx, grad_in):
+            prob_in, s = ctx.saved_tensors
+            w = s * grad_in                                           # :27
+            return torch.from_numpy(backend.calc_prob_backward(_np(prob_in), _np(w)))
+
+    class SphericalBackProjectionCPU(Function):
+        # sperical_to_tdf.py:13-47
+        @staticmethod
+        def forward(ctx, spherical, grid, res=128):
+            g = grid.detach().cpu().numpy()                            # keeps expand()ed strides
+            tdf, cnt = backend.spherical_back_proj_forward(_np(spherical), g, res)
+            ctx.save_for_backward(spherical.detach(), grid)
+            ctx.cnt = cnt
+            cnt_t = torch.from_numpy(cnt)
+            ctx.mark_non_differentiable(cnt_t)
+            return torch.from_numpy(tdf), cnt_t
+
+        @staticmethod
+        def backward(ctx, grad_output, grad_phony):
+            spherical, grid = ctx.saved_tensors
+            gd = backend.spherical_back_proj_backward(_np(spherical), grid.detach().cpu().numpy(), ctx.cnt,
+                                                      _np(grad_output))
+            return torch.from_numpy(gd), None, None
+
+    return CameraBackProjectionCPU, CalcStopProbCPU, SphericalBackProjectionCPU
+
+
+def unit_dirs(res):
+    phi = np.linspace(0, 180, res * 2 + 1)[1::2] * np.pi / 180
+    theta = np.linspace(0, 360, res + 1)[:-1] * np.pi / 180
+    g = np.zeros((res, res, 3))
+    g[:, :, 2] = np.cos(phi)[:, None]
+    g[:, :, 0] = np.sin(phi)[:, None] * np.cos(theta)[None, :]
+    g[:, :, 1] = np.sin(phi)[:, None] * np.sin(theta)[None, :]
+    return g
+
+
+def render_grid(sph_res=128, z_res=256):
+    """spherical_proj.py:39-60: sample k of ray (i,j) at 2*dir*(1-alpha_k), alpha = linspace(0,1,z_res)"""
+    alpha = np.linspace(0, 1, z_res).reshape(1, 1, z_res, 1)
+    grid = (unit_dirs(sph_res) * 2)[:, :, np.newaxis, :] * (1 - alpha)
+    return torch.from_numpy(grid).float(), torch.linspace(0, 1, z_res)
+
+
+class RenderSphericalCPU(torch.nn.Module):
+    """spherical_proj.py:31-72 on CPU torch + the oracle's calc_prob"""
+
+    def __init__(self, backend, sph_res=128, z_res=256):
+        super().__init__()
+        self.grid, self.depth_weight = render_grid(sph_res, z_res)
+        self.calc = make_functions(backend)[1].apply
+
+    def forward(self, vox):
+        grid = self.grid.expand(vox.shape[0], -1, -1, -1, -1)
+        vox = vox.permute(0, 1, 4, 3, 2)
+        prob = torch.nn.functional.grid_sample(vox, grid, mode="bilinear", padding_mode="zeros",
+                                               align_corners=True)
+        prob = torch.clamp(prob, 1e-5, 1 - 1e-5)
+        stop = self.calc(prob)
+        exp_depth = torch.matmul(stop, self.depth_weight)
+        return exp_depth + torch.prod(1.0 - prob, dim=4)
+
+
+def sph_pad(sph, pm=16):
+    """spherical_proj.py:21-28"""
+    out = torch.nn.functional.pad(sph, (pm, pm, pm, pm), mode="replicate")
+    _, _, h, w = out.shape
+    out[:, :, :, 0:pm] = out[:, :, :, w - 2 * pm:w - pm]
+    out[:, :, :, h - pm:] = out[:, :, :, pm:2 * pm]
+    return out
+
+
+class HotPathCPU:
+    """configs[1] on the host: depth -> cam_bp -> shift/x50/clamp -> render_spherical -> pad,
+    forward and backward (depth_pred_with_sph_inpaint.py:120-126)."""
+
+    def __init__(self, backend, fl=418.3, cam_dist=2.2):
+        self.cam = make_functions(backend)[0].apply
+        self.render = RenderSphericalCPU(backend)
+        self.fl, self.cam_dist = fl, cam_dist
+
+    def forward(self, depth):
+        n = depth.shape[0]
+        fl = torch.full((n, 1), self.fl)
+        cd = torch.full((n, 1), self.cam_dist)
+        tdf = self.cam(depth, fl, cd, 128)
+        proj = 1 - 128 * tdf                                           # shift_tdf
+        sph = self.render(torch.clamp(proj * 50, 1e-5, 1 - 1e-5))
+        return sph_pad(sph, 16)
+
+    def forward_backward(self, depth, grad_out):
+        depth = depth.clone().requires_grad_(True)
+        out = self.forward(depth)
+        out.backward(grad_out)
+        return out.detach(), depth.grad

@@ -1,0 +1,58 @@
+"""GPU parity: render_spherical / the configs[1] chain against the
+CPU-torch restatement (oracle/torch_oracle.py: torch CPU ops with align_corners=True + the C
+oracle's calc_prob).  Tolerance 1e-5 absolute on maps in (0,1]."""
+import numpy as np
+import pytest
+import torch
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def vox_cases(oracle):
+    d = inputs.sphere_depth(noise_seed=2)
+    fl, cd = inputs.cam_params(1)
+    tdf, _ = oracle.back_projection_forward(d, cd, fl)
+    proj = 1 - 128 * tdf
+    rng = np.random.default_rng(12)
+    return {
+        "genre_binary": np.clip(proj * 50, 1e-5, 1 - 1e-5).astype(np.float32),     # depth_pred_with_sph_inpaint.py:124
+        "soft": np.clip(proj * 0.7, 1e-5, 1 - 1e-5).astype(np.float32),
+        "random": rng.uniform(0, 0.05, proj.shape).astype(np.float32),
+    }
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", ["genre_binary", "soft", "random"])
+def test_render_spherical_forward_backward(name, fused, genre, oracle, dev):
+    from genre_shapehd_amd.toolbox import _fused_render
+    if fused and not _fused_render.available():
+        pytest.skip("fused render kernel not in this build")
+    from oracle.torch_oracle import RenderSphericalCPU
+    v = vox_cases(oracle)[name]
+    vc = torch.from_numpy(v).requires_grad_(True)
+    ref = RenderSphericalCPU(oracle)(vc)
+    g = torch.from_numpy(np.random.default_rng(3).standard_normal(ref.shape).astype(np.float32))
+    ref.backward(g)
+    vt = torch.from_numpy(v).to(dev).requires_grad_(True)
+    out = genre.render_spherical(fused=fused).to(dev)(vt)
+    assert out.shape == (1, 1, 128, 128)
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= TOL
+    out.backward(g.to(dev))
+    diff = (vt.grad.cpu() - vc.grad).abs() / (1 + vc.grad.abs())
+    assert diff.max().item() <= 2e-5, diff.max().item()
+
+
+def test_chain_config2(genre, oracle, dev):
+    """configs[1]: depth -> cam_bp -> x50 clamp -> render_spherical -> sph_pad(16) -> 160x160"""
+    from oracle.torch_oracle import HotPathCPU
+    d = inputs.batch_depth(2)
+    ref = HotPathCPU(oracle).forward(torch.from_numpy(d))
+    layer = genre.Camera_back_projection_layer().to(dev)
+    render = genre.render_spherical().to(dev)
+    proj = layer(torch.from_numpy(d).to(dev))
+    out = genre.sph_pad(render(torch.clamp(proj * 50, 1e-5, 1 - 1e-5)), 16)
+    assert out.shape == (2, 1, 160, 160)
+    assert (out.cpu() - ref).abs().max().item() <= TOL
