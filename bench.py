@@ -102,6 +102,21 @@ def kernel_table(G, dev, B):
     rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel")
     t = event_time_us(lambda: calc_prob_lib.calc_prob_backward_fused(p, s, g, o), iters, 5)
     rows["calc_prob_bwd_fused"] = dict(us=t, bytes=B * BYTES_CP_BWD_FUSED, kernels="stop_bwd_vec4_kernel<fused>")
+    from genre_shapehd_amd.toolbox import _fused_render
+    if _fused_render.available():
+        render_lib = _fused_render._loader().render_lib
+        mod = G.render_spherical(fused=True).to(dev)
+        vox = torch.clamp((1 - 128 * tdf) * 50, 1e-5, 1 - 1e-5)          # the volume the step really renders
+        dirs = mod._dirs64.view(torch.float32)
+        out = torch.empty((B, 1, 128, 128), device=dev)
+        gout = torch.randn_like(out)
+        gvox = torch.empty_like(vox)
+        t = event_time_us(lambda: render_lib.render_spherical_forward(vox, dirs, mod.depth_weight, out), iters, 5)
+        rows["render_fwd_fused"] = dict(us=t, bytes=B * BYTES_RENDER_FUSED, kernels="render_fwd_kernel")
+        t = event_time_us(lambda: render_lib.render_spherical_backward(vox, dirs, mod.depth_weight, gout, gvox),
+                          iters, 5)
+        rows["render_bwd_fused"] = dict(us=t, bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
+                                        kernels="zero_vec4+render_bwd_kernel")
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3
     return rows

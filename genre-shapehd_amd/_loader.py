@@ -43,7 +43,7 @@ def _load():
                         ("genre_spherical_back_proj_backward", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
-                        ("genre_render_spherical_forward", 3), ("genre_render_spherical_backward", 4)):
+                        ("genre_render_spherical_forward", 4), ("genre_render_spherical_backward", 5)):
         fn = getattr(lib, name, None)
         if fn is None:
             continue
@@ -142,6 +142,18 @@ class _CalcProbLib:
         return _call("genre_calc_prob_backward_fused", prob_in, stop_prob, grad_in, grad_out)
 
 
+class _RenderLib:
+    """fused render_spherical (extension; fuses toolbox/spherical_proj.py:62-72)"""
+
+    @staticmethod
+    def render_spherical_forward(vox, dirs64_as_f32, depth_weight, out):
+        return _call("genre_render_spherical_forward", vox, dirs64_as_f32, depth_weight, out)
+
+    @staticmethod
+    def render_spherical_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox):
+        return _call("genre_render_spherical_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox)
+
+
 class _MyLib:
     """stands in for nndistance/_ext/my_lib (my_lib.h:3-5, my_lib_cuda.h:1-4).
     The reference's CPU entry points exist here only to fail loudly."""
@@ -165,3 +177,4 @@ class _MyLib:
 cam_bp_lib = _CamBpLib()
 calc_prob_lib = _CalcProbLib()
 my_lib = _MyLib()
+render_lib = _RenderLib()

@@ -1,0 +1,336 @@
+// sph_render.hip -- fused voxel -> spherical depth map renderer for gfx950.
+//
+// Replaces, as ONE kernel each way, the op sequence of render_spherical.forward
+// (toolbox/spherical_proj.py:62-72): expand + permute + grid_sample (5-D trilinear,
+// zeros padding, PyTorch-0.4.1 == align_corners=True) + clamp + CalcStopProb
+// (calc_prob_kernel.cu:113-143) + matmul(depth_weight) + prod(1-p) + add.  The reference
+// moves ~150 MB per image (48 MiB grid buffer, four 16 MiB intermediates, taps); this kernel
+// reads the 128^3 volume (8 MiB, L2/MALL resident after first touch) and writes the
+// [R,R] map (64 KiB): algorithmic traffic 8.45 MB per image.
+//
+// One wave renders one ray.  Lane l owns samples 4l..4l+3 (0.5 voxel apart, so a lane's 32
+// taps and its neighbours' overlap in L1); the exclusive product scan of (1-p), the depth
+// expectation and (backward) the reverse sum scan run in fp64 registers + 6 cross-lane
+// steps, exactly like calc_prob.hip.  Sample positions are generated analytically from the
+// per-ray unit direction in fp64 -- grid[i,j,k] = float((2*dir_ij) * (1 - alpha_k)), the
+// reference's own float64 expression (spherical_proj.py:50-56) -- so they are bit-identical
+// to the reference's 48 MiB `grid` buffer without reading it.
+//
+// Trilinear taps follow ATen's grid_sampler_3d (the arithmetic PyTorch runs for the
+// reference): ix = ((x+1)/2)*(size-1), corner weights as products of (corner - coord)
+// differences, out-of-volume corners contribute 0.
+//
+// Backward recomputes the forward in registers (nothing but `vox` is saved), then
+//     dL/dp_k = g * ( T_k w_k - (sum_{j>k} s_j w_j + prod_all(1-p)) / (1 - p_k) )
+// is masked by the clamp (pass where lo <= v <= hi, torch.clamp's rule) and scattered to the
+// 8 taps with hardware fp32 atomics; samples whose gradient is exactly 0 (clamped away --
+// almost all of them on GenRe's near-binary volumes) issue no atomics.
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace genre {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+struct RenderDims { int N, NC, X, Y, Z, R, ZR; double step; float lo, hi; };
+
+struct Taps {
+    int64_t off[8];
+    float w[8];
+    unsigned ok;          // bit t set: corner t inside the volume
+};
+
+// ATen grid_sampler_3d forward arithmetic (align_corners=True, zeros padding).
+// x -> X axis (stride sx), y -> Y, z -> Z: vox.permute(0,1,4,3,2) in spherical_proj.py:64
+__device__ __forceinline__ void make_taps(const RenderDims &D, int64_t sx, int64_t sy, int64_t sz,
+                                          float gx, float gy, float gz, Taps &t)
+{
+    const float ix = ((gx + 1.f) / 2) * (D.X - 1);
+    const float iy = ((gy + 1.f) / 2) * (D.Y - 1);
+    const float iz = ((gz + 1.f) / 2) * (D.Z - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;                 // weight of the +1 corner
+    const float wx0 = (fx + 1) - ix, wy0 = (fy + 1) - iy, wz0 = (fz + 1) - iz;
+    const bool bx0 = x0 >= 0 && x0 < D.X, bx1 = x0 + 1 >= 0 && x0 + 1 < D.X;
+    const bool by0 = y0 >= 0 && y0 < D.Y, by1 = y0 + 1 >= 0 && y0 + 1 < D.Y;
+    const bool bz0 = z0 >= 0 && z0 < D.Z, bz1 = z0 + 1 >= 0 && z0 + 1 < D.Z;
+    // ATen corner order: tnw, tne, tsw, tse, bnw, bne, bsw, bse  (t/b: z, n/s: y, w/e: x)
+    const int64_t ox0 = x0 * sx, ox1 = ox0 + sx, oy0 = y0 * sy, oy1 = oy0 + sy, oz0 = z0 * sz, oz1 = oz0 + sz;
+    t.off[0] = ox0 + oy0 + oz0; t.w[0] = wx0 * wy0 * wz0;
+    t.off[1] = ox1 + oy0 + oz0; t.w[1] = wx1 * wy0 * wz0;
+    t.off[2] = ox0 + oy1 + oz0; t.w[2] = wx0 * wy1 * wz0;
+    t.off[3] = ox1 + oy1 + oz0; t.w[3] = wx1 * wy1 * wz0;
+    t.off[4] = ox0 + oy0 + oz1; t.w[4] = wx0 * wy0 * wz1;
+    t.off[5] = ox1 + oy0 + oz1; t.w[5] = wx1 * wy0 * wz1;
+    t.off[6] = ox0 + oy1 + oz1; t.w[6] = wx0 * wy1 * wz1;
+    t.off[7] = ox1 + oy1 + oz1; t.w[7] = wx1 * wy1 * wz1;
+    t.ok = (unsigned)(bx0 && by0 && bz0) | (unsigned)(bx1 && by0 && bz0) << 1 |
+           (unsigned)(bx0 && by1 && bz0) << 2 | (unsigned)(bx1 && by1 && bz0) << 3 |
+           (unsigned)(bx0 && by0 && bz1) << 4 | (unsigned)(bx1 && by0 && bz1) << 5 |
+           (unsigned)(bx0 && by1 && bz1) << 6 | (unsigned)(bx1 && by1 && bz1) << 7;
+}
+
+__device__ __forceinline__ float gather(const float *__restrict__ base, const Taps &t)
+{
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        if (t.ok >> c & 1u) acc += base[t.off[c]] * t.w[c];
+    return acc;
+}
+
+// sample k of the ray with doubled direction (dx2,dy2,dz2) = 2*dir (fp64): spherical_proj.py:50-56
+__device__ __forceinline__ void sample_pos(const RenderDims &D, double dx2, double dy2, double dz2, int k,
+                                           float &gx, float &gy, float &gz)
+{
+    const double alpha = (k == D.ZR - 1) ? 1.0 : (double)k * D.step;       // numpy.linspace(0,1,ZR)[k]
+    const double a = 1.0 - alpha;
+    gx = (float)(dx2 * a); gy = (float)(dy2 * a); gz = (float)(dz2 * a);
+}
+
+__device__ __forceinline__ double wave_incl_prod_up(double v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_incl_sum_down(double v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_down(v, o, 64);
+        if (lane + o < 64) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void ray_decode(const RenderDims &D, int64_t r, int64_t &n, int &c, int &q)
+{
+    const int rr = D.R * D.R;
+    q = (int)(r % rr);
+    const int64_t nc = r / rr;
+    c = (int)(nc % D.NC);
+    n = nc / D.NC;
+}
+
+// ---- forward --------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void render_fwd_kernel(RenderDims D, View5 vox, const double *__restrict__ dirs,
+                                                             const float *__restrict__ dw, View4 out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
+    for (int64_t r = wave0; r < rays; r += nwaves) {
+        int64_t n; int c, q;
+        ray_decode(D, r, n, c, q);
+        const float *__restrict__ base = vox.p + n * vox.s0 + c * vox.s1;
+        const double dx2 = dirs[q * 3 + 0] * 2, dy2 = dirs[q * 3 + 1] * 2, dz2 = dirs[q * 3 + 2] * 2;
+        double carry = 1.0, acc = 0.0;
+        for (int k0 = 0; k0 < D.ZR; k0 += 256) {
+            float p[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int k = k0 + lane * 4 + t;
+                p[t] = 0.f;                                              // neutral beyond the ray's end
+                if (k < D.ZR) {
+                    float gx, gy, gz;
+                    sample_pos(D, dx2, dy2, dz2, k, gx, gy, gz);
+                    Taps tp;
+                    make_taps(D, vox.s2, vox.s3, vox.s4, gx, gy, gz, tp);
+                    const float v = gather(base, tp);
+                    p[t] = fminf(fmaxf(v, D.lo), D.hi);                  // clamp(.,1e-5,1-1e-5), :66
+                }
+            }
+            const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2],
+                         q3 = 1.0 - (double)p[3];
+            const double e1 = q0, e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
+            const double incl = wave_incl_prod_up(tot, lane);
+            double excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0;
+            excl *= carry;
+            const int kb = k0 + lane * 4;
+            // expected depth: sum_k s_k * depth_weight[k]   (:68)
+            if (kb + 0 < D.ZR) acc += ((double)p[0] * excl) * (double)dw[kb + 0];
+            if (kb + 1 < D.ZR) acc += ((double)p[1] * (excl * e1)) * (double)dw[kb + 1];
+            if (kb + 2 < D.ZR) acc += ((double)p[2] * (excl * e2)) * (double)dw[kb + 2];
+            if (kb + 3 < D.ZR) acc += ((double)p[3] * (excl * e3)) * (double)dw[kb + 3];
+            carry *= __shfl(incl, 63, 64);
+        }
+        const double total = wave_sum(acc) + carry;                      // + prod(1-p)  (:69-71)
+        if (lane == 0) {
+            const int i = q / D.R, j = q % D.R;
+            out.p[n * out.s0 + c * out.s1 + i * out.s2 + j * out.s3] = (float)total;
+        }
+    }
+}
+
+// ---- backward (single chunk: ZR <= 256) ---------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void render_bwd_kernel(RenderDims D, View5 vox, const double *__restrict__ dirs,
+                                                             const float *__restrict__ dw, View4 gout, View5 gvox)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
+    for (int64_t r = wave0; r < rays; r += nwaves) {
+        int64_t n; int c, q;
+        ray_decode(D, r, n, c, q);
+        const int i = q / D.R, j = q % D.R;
+        const float g = gout.p[n * gout.s0 + c * gout.s1 + i * gout.s2 + j * gout.s3];
+        if (g == 0.0f) continue;                                         // wave-uniform
+        const float *__restrict__ base = vox.p + n * vox.s0 + c * vox.s1;
+        float *gbase = gvox.p + n * gvox.s0 + c * gvox.s1;
+        const double dx2 = dirs[q * 3 + 0] * 2, dy2 = dirs[q * 3 + 1] * 2, dz2 = dirs[q * 3 + 2] * 2;
+        float p[4], w[4];
+        bool pass[4];
+        const int kb = lane * 4;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int k = kb + t;
+            p[t] = 0.f; w[t] = 0.f; pass[t] = false;
+            if (k < D.ZR) {
+                float gx, gy, gz;
+                sample_pos(D, dx2, dy2, dz2, k, gx, gy, gz);
+                Taps tp;
+                make_taps(D, vox.s2, vox.s3, vox.s4, gx, gy, gz, tp);
+                const float v = gather(base, tp);
+                pass[t] = (v >= D.lo) && (v <= D.hi) && tp.ok != 0u;     // torch.clamp backward mask
+                p[t] = fminf(fmaxf(v, D.lo), D.hi);
+                w[t] = dw[k];
+            }
+        }
+        const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2],
+                     q3 = 1.0 - (double)p[3];
+        const double e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
+        const double incl = wave_incl_prod_up(tot, lane);
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        const double prod_all = __shfl(incl, 63, 64);
+        const double T0 = excl, T1 = excl * q0, T2 = excl * e2, T3 = excl * e3;   // transmittance before k
+        const double sw0 = (double)p[0] * T0 * (double)w[0], sw1 = (double)p[1] * T1 * (double)w[1];
+        const double sw2 = (double)p[2] * T2 * (double)w[2], sw3 = (double)p[3] * T3 * (double)w[3];
+        const double lane_sw = ((sw3 + sw2) + sw1) + sw0;
+        const double incl_s = wave_incl_sum_down(lane_sw, lane);
+        double after = __shfl_down(incl_s, 1, 64);
+        if (lane == 63) after = 0.0;
+        after += prod_all;                                               // tail term prod(1-p) joins the suffix
+        const double A3 = after, A2 = after + sw3, A1 = after + (sw3 + sw2), A0 = after + ((sw3 + sw2) + sw1);
+        const double gd = (double)g;
+        float dp[4];
+        dp[0] = (float)(gd * (T0 * (double)w[0] - A0 / q0));
+        dp[1] = (float)(gd * (T1 * (double)w[1] - A1 / q1));
+        dp[2] = (float)(gd * (T2 * (double)w[2] - A2 / q2));
+        dp[3] = (float)(gd * (T3 * (double)w[3] - A3 / q3));
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (!pass[t] || dp[t] == 0.0f) continue;
+            float gx, gy, gz;
+            sample_pos(D, dx2, dy2, dz2, kb + t, gx, gy, gz);
+            Taps tp;
+            make_taps(D, gvox.s2, gvox.s3, gvox.s4, gx, gy, gz, tp);
+#pragma unroll
+            for (int cidx = 0; cidx < 8; cidx++)
+                if (tp.ok >> cidx & 1u) unsafeAtomicAdd(gbase + tp.off[cidx], tp.w[cidx] * dp[t]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void zero_vec4_kernel(float4 *__restrict__ a, int64_t n4)
+{
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) a[i] = z;
+}
+
+int check_render(const char *op, const genre_tensor *vox, const genre_tensor *dirs, const genre_tensor *dw,
+                 const genre_tensor *map, RenderDims &D)
+{
+    GENRE_REQUIRE(is_f32(vox, 5), "%s: vox must be a 5-D fp32 tensor [N,NC,X,Y,Z]", op);
+    GENRE_REQUIRE(is_f32(map, 4) && map->size[0] == vox->size[0] && map->size[1] == vox->size[1] &&
+                      map->size[2] == map->size[3],
+                  "%s: the spherical map must be a 4-D fp32 tensor [N,NC,R,R]", op);
+    D.N = (int)vox->size[0]; D.NC = (int)vox->size[1];
+    D.X = (int)vox->size[2]; D.Y = (int)vox->size[3]; D.Z = (int)vox->size[4];
+    D.R = (int)map->size[2];
+    // dirs: [R,R,6] fp32 words = [R,R,3] float64 unit directions (the caller passes the raw storage)
+    GENRE_REQUIRE(dirs && dirs->data && dirs->ndim == 3 && dirs->size[0] == D.R && dirs->size[1] == D.R &&
+                      dirs->size[2] == 6 && is_contiguous(dirs) && ((uintptr_t)dirs->data & 7u) == 0,
+                  "%s: dirs must be the contiguous float64 [R,R,3] direction table viewed as fp32 [R,R,6]", op);
+    GENRE_REQUIRE(is_f32(dw, 1) && is_contiguous(dw) && dw->size[0] >= 1, "%s: depth_weight must be a 1-D fp32 tensor", op);
+    D.ZR = (int)dw->size[0];
+    D.step = D.ZR > 1 ? 1.0 / (double)(D.ZR - 1) : 0.0;
+    D.lo = 1e-5f; D.hi = (float)(1 - 1e-5);                              // spherical_proj.py:66
+    return 1;
+}
+
+inline int grid_for_rays(int64_t rays)
+{
+    int64_t b = (rays + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t cap = (int64_t)kCUs * 8 * 8;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+}  // namespace genre
+
+using namespace genre;
+
+// Extension (no native counterpart in the reference: fuses spherical_proj.py:62-72).
+// vox [N,NC,X,Y,Z] (any strides) -> out [N,NC,R,R];  dirs = float64 [R,R,3] unit directions of
+// spherical_proj.py:43-49 passed as an fp32-typed [R,R,6] view; depth_weight [ZR] (:57).
+extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *dirs,
+                                              const genre_tensor *depth_weight, const genre_tensor *out,
+                                              void *stream)
+{
+    const char *op = "render_spherical_forward";
+    RenderDims D{};
+    if (!check_render(op, vox, dirs, depth_weight, out, D)) return 0;
+    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
+    if (rays == 0) return 1;
+    render_fwd_kernel<<<grid_for_rays(rays), kBlock, 0, (hipStream_t)stream>>>(
+        D, view5(vox), (const double *)dirs->data, (const float *)depth_weight->data, view4(out));
+    GENRE_LAUNCH_CHECK("render_spherical forward");
+    return 1;
+}
+
+// grad_vox [N,NC,X,Y,Z] is fully written (zeroed here, then accumulated).
+extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
+                                               const genre_tensor *depth_weight, const genre_tensor *grad_out,
+                                               const genre_tensor *grad_vox, void *stream)
+{
+    const char *op = "render_spherical_backward";
+    RenderDims D{};
+    if (!check_render(op, vox, dirs, depth_weight, grad_out, D)) return 0;
+    GENRE_REQUIRE(is_f32(grad_vox, 5) && same_shape(grad_vox, vox), "%s: grad_vox must have the shape of vox", op);
+    GENRE_REQUIRE(D.ZR <= 256, "%s: fused backward supports z_res <= 256", op);
+    GENRE_REQUIRE(is_contiguous(grad_vox) && aligned16(grad_vox->data) && numel(grad_vox) % 4 == 0,
+                  "%s: grad_vox must be contiguous, 16-byte aligned, numel %% 4 == 0", op);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nv = numel(grad_vox);
+    if (nv == 0) return 1;
+    int64_t zb = (nv / 4 + kBlock - 1) / kBlock;
+    if (zb > kCUs * 8) zb = kCUs * 8;
+    zero_vec4_kernel<<<(int)zb, kBlock, 0, st>>>((float4 *)grad_vox->data, nv / 4);
+    GENRE_LAUNCH_CHECK("render_spherical backward (zero)");
+    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
+    if (rays == 0) return 1;
+    render_bwd_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(D, view5(vox), (const double *)dirs->data,
+                                                             (const float *)depth_weight->data, view4(grad_out),
+                                                             view5(grad_vox));
+    GENRE_LAUNCH_CHECK("render_spherical backward");
+    return 1;
+}

@@ -62,17 +62,21 @@ class render_spherical(torch.nn.Module):
         grid = (_unit_dirs(res) * 2)[:, :, np.newaxis, :] * (1 - alpha)
         self.register_buffer('depth_weight', torch.linspace(0, 1, z_res))
         self.register_buffer('grid', torch.from_numpy(grid).float())
+        # float64 unit directions for the fused kernel, which regenerates `grid` bit-exactly from
+        # them; non-persistent so the state_dict keeps exactly the reference's two buffers
+        self.register_buffer('_dirs64', torch.from_numpy(_unit_dirs(res)).contiguous(), persistent=False)
 
     def _use_fused(self, vox):
         if self.fused is not None:
             return self.fused
         from . import _fused_render
-        return _fused_render.available() and vox.is_cuda and vox.dtype == torch.float32
+        return (_fused_render.available() and vox.is_cuda and vox.dtype == torch.float32
+                and self.z_res <= 256)
 
     def forward(self, vox):
         if self._use_fused(vox):
             from . import _fused_render
-            return _fused_render.RenderSphericalFused.apply(vox, self.sph_res, self.z_res)
+            return _fused_render.RenderSphericalFused.apply(vox, self._dirs64, self.depth_weight)
         grid = self.grid.expand(vox.shape[0], -1, -1, -1, -1)
         vox = vox.permute(0, 1, 4, 3, 2)
         prob_sph = torch.nn.functional.grid_sample(vox, grid, mode='bilinear', padding_mode='zeros',

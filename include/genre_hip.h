@@ -143,6 +143,29 @@ int genre_nnd_backward(const genre_tensor *xyz1, const genre_tensor *xyz2,
                        const genre_tensor *graddist1, const genre_tensor *graddist2,
                        const genre_tensor *idx1, const genre_tensor *idx2, void *stream);
 
+/* ---- render_spherical : toolbox/spherical_proj.py:31-72 (extension) ---------- */
+
+/* No native counterpart in the reference: fuses the PyTorch op sequence of
+ * render_spherical.forward (spherical_proj.py:62-72: expand, permute,
+ * grid_sample [0.4.1 semantics == align_corners=True, zeros padding], clamp to
+ * [1e-5, 1-1e-5], CalcStopProb, matmul(depth_weight), prod(1-p), add) into one
+ * kernel.  vox [N,NC,X,Y,Z] (any strides) -> out [N,NC,R,R].
+ *   dirs         : the float64 [R,R,3] unit-direction table of spherical_proj.py:43-49,
+ *                  passed as its raw storage viewed as fp32 [R,R,6] (contiguous);
+ *                  sample k of ray (i,j) sits at float((2*dirs[i,j]) * (1 - k/(ZR-1))),
+ *                  bit-identical to the reference's `grid` buffer (:50-56)
+ *   depth_weight : [ZR] fp32, the reference's buffer of the same name (:57) */
+int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *dirs,
+                                   const genre_tensor *depth_weight, const genre_tensor *out,
+                                   void *stream);
+
+/* Adjoint of the above w.r.t. vox (what autograd derives for the reference's
+ * op chain).  grad_out [N,NC,R,R] -> grad_vox [N,NC,X,Y,Z] contiguous, fully
+ * written.  Recomputes the forward; requires ZR <= 256. */
+int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
+                                    const genre_tensor *depth_weight, const genre_tensor *grad_out,
+                                    const genre_tensor *grad_vox, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
