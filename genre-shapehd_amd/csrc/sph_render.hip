@@ -26,6 +26,7 @@
 // 8 taps with hardware fp32 atomics; samples whose gradient is exactly 0 (clamped away --
 // almost all of them on GenRe's near-binary volumes) issue no atomics.
 #include "common.hpp"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -35,7 +36,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
 
-struct RenderDims { int N, NC, X, Y, Z, R, ZR; double step; float lo, hi; };
+struct RenderDims { int N, NC, X, Y, Z, R, ZR; double step; float lo, hi; int dbg; };
 
 struct Taps {
     int64_t off[8];
@@ -238,8 +239,11 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(RenderDims D, View5 
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             if (!pass[t] || dp[t] == 0.0f) continue;
+            if (D.dbg == 1) continue;                                   // EXPERIMENT: no atomics at all
             float gx, gy, gz;
             sample_pos(D, dx2, dy2, dz2, kb + t, gx, gy, gz);
+            if (D.dbg == 2 && (gx * gx + gy * gy + gz * gz) < 0.0635f) continue;   // EXPERIMENT: skip rho < 16 vox
+            if (D.dbg == 3 && (gx * gx + gy * gy + gz * gz) < 0.0159f) continue;   // EXPERIMENT: skip rho < 8 vox
             Taps tp;
             make_taps(D, gvox.s2, gvox.s3, gvox.s4, gx, gy, gz, tp);
 #pragma unroll
@@ -273,6 +277,7 @@ int check_render(const char *op, const genre_tensor *vox, const genre_tensor *di
     D.ZR = (int)dw->size[0];
     D.step = D.ZR > 1 ? 1.0 / (double)(D.ZR - 1) : 0.0;
     D.lo = 1e-5f; D.hi = (float)(1 - 1e-5);                              // spherical_proj.py:66
+    { const char *e = getenv("GENRE_DBG"); D.dbg = e ? atoi(e) : 0; }
     return 1;
 }
 
