@@ -187,15 +187,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import genre_shapehd_amd as G
+    from genre_shapehd_amd import dist_utils
+    dist = dist_utils.init_from_env("nccl", dev)           # RCCL; None when WORLD_SIZE == 1
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
 
     import inputs
-    import genre_shapehd_amd as G
     from genre_shapehd_amd.toolbox import _fused_render
     fused = (not args.unfused) and _fused_render.available()
     model = HotPath(G, fused).to(dev)
@@ -209,10 +206,7 @@ def main():
         out.backward(grad_out)
 
     def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        dist_utils.fence(dist, torch.cuda.synchronize)
 
     for _ in range(args.warmup):
         step()
@@ -222,10 +216,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = dist_utils.max_over_ranks(dist, elapsed, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
 
