@@ -43,7 +43,7 @@ def _load():
                         ("genre_spherical_back_proj_backward", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
-                        ("genre_render_spherical_forward", 4), ("genre_render_spherical_backward", 5)):
+                        ("genre_render_spherical_forward", 4), ("genre_render_spherical_backward", 8)):
         fn = getattr(lib, name, None)
         if fn is None:
             continue
@@ -85,12 +85,15 @@ def _call(name, *tensors):
     dev = tensors[0].device
     descs = []
     for k, t in enumerate(tensors):
+        if t is None:                       # optional argument -> NULL
+            descs.append(None)
+            continue
         if t.device != dev:
             raise RuntimeError("%s: tensors are on different GPUs (%s vs %s)" % (name, dev, t.device))
         descs.append(_desc(t, "%s arg %d" % (name, k)))
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        ok = getattr(_lib, name)(*[C.byref(d) for d in descs], C.c_void_p(stream))
+        ok = getattr(_lib, name)(*[None if d is None else C.byref(d) for d in descs], C.c_void_p(stream))
     if ok != 1:
         raise RuntimeError("%s failed: %s" % (name, _lib.genre_last_error().decode()))
     return 1
@@ -150,8 +153,12 @@ class _RenderLib:
         return _call("genre_render_spherical_forward", vox, dirs64_as_f32, depth_weight, out)
 
     @staticmethod
-    def render_spherical_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox):
-        return _call("genre_render_spherical_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox)
+    def render_spherical_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
+                                  dp_scratch=None, brick_table=None, sample_list=None):
+        """with the three optional tensors: two-pass brick-owned backward (no global atomics);
+        without: global-atomic scatter fallback"""
+        return _call("genre_render_spherical_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
+                     dp_scratch, brick_table, sample_list)
 
 
 class _MyLib:

@@ -1,32 +1,40 @@
 // sph_render.hip -- fused voxel -> spherical depth map renderer for gfx950.
 //
-// Replaces, as ONE kernel each way, the op sequence of render_spherical.forward
-// (toolbox/spherical_proj.py:62-72): expand + permute + grid_sample (5-D trilinear,
-// zeros padding, PyTorch-0.4.1 == align_corners=True) + clamp + CalcStopProb
-// (calc_prob_kernel.cu:113-143) + matmul(depth_weight) + prod(1-p) + add.  The reference
-// moves ~150 MB per image (48 MiB grid buffer, four 16 MiB intermediates, taps); this kernel
-// reads the 128^3 volume (8 MiB, L2/MALL resident after first touch) and writes the
-// [R,R] map (64 KiB): algorithmic traffic 8.45 MB per image.
+// Replaces the op sequence of render_spherical.forward (toolbox/spherical_proj.py:62-72):
+// expand + permute + grid_sample (5-D trilinear, zeros padding, PyTorch-0.4.1 ==
+// align_corners=True) + clamp + CalcStopProb (calc_prob_kernel.cu:113-143) +
+// matmul(depth_weight) + prod(1-p) + add, and its autograd backward.  The reference moves
+// ~150 MB per image forward (48 MiB grid buffer, four 16 MiB intermediates, taps); the
+// forward here reads the 128^3 volume (8 MiB, L2/MALL resident) and writes the [R,R] map:
+// algorithmic traffic 8.45 MB per image.
 //
-// One wave renders one ray.  Lane l owns samples 4l..4l+3 (0.5 voxel apart, so a lane's 32
-// taps and its neighbours' overlap in L1); the exclusive product scan of (1-p), the depth
-// expectation and (backward) the reverse sum scan run in fp64 registers + 6 cross-lane
-// steps, exactly like calc_prob.hip.  Sample positions are generated analytically from the
-// per-ray unit direction in fp64 -- grid[i,j,k] = float((2*dir_ij) * (1 - alpha_k)), the
-// reference's own float64 expression (spherical_proj.py:50-56) -- so they are bit-identical
-// to the reference's 48 MiB `grid` buffer without reading it.
+// FORWARD  one wave renders one ray.  Lane l owns samples 4l..4l+3 (0.5 voxel apart, so a
+//   lane's taps and its neighbours' overlap in L1); the exclusive product scan of (1-p) and the
+//   depth expectation run in fp64 registers + 6 cross-lane steps, exactly like calc_prob.hip.
+//   Sample positions are regenerated in fp64 from the per-ray unit direction --
+//   grid[i,j,k] = float((2*dir_ij) * (1 - alpha_k)), the reference's own float64 expression
+//   (spherical_proj.py:50-56) -- bit-identical to its 48 MiB `grid` buffer without reading it.
+//   Trilinear taps follow ATen's grid_sampler_3d arithmetic (what PyTorch runs for the
+//   reference); samples with no corner inside the volume (about half of them) skip all loads.
 //
-// Trilinear taps follow ATen's grid_sampler_3d (the arithmetic PyTorch runs for the
-// reference): ix = ((x+1)/2)*(size-1), corner weights as products of (corner - coord)
-// differences, out-of-volume corners contribute 0.
-//
-// Backward recomputes the forward in registers (nothing but `vox` is saved), then
-//     dL/dp_k = g * ( T_k w_k - (sum_{j>k} s_j w_j + prod_all(1-p)) / (1 - p_k) )
-// is masked by the clamp (pass where lo <= v <= hi, torch.clamp's rule) and scattered to the
-// 8 taps with hardware fp32 atomics; samples whose gradient is exactly 0 (clamped away --
-// almost all of them on GenRe's near-binary volumes) issue no atomics.
+// BACKWARD two passes, no global atomics:
+//   A  (wave per ray) recomputes the ray, forms
+//        dL/dp_k = g * ( T_k w_k - (sum_{j>k} s_j w_j + prod_all(1-p)) / (1 - p_k) ),
+//      masks it with torch.clamp's rule (pass where lo <= v <= hi) and writes it to a
+//      [rays, ZR] scratch with one coalesced float4 per lane.
+//   B  (workgroup per 16^3 voxel BRICK) accumulates the trilinear adjoint of every sample that
+//      touches the brick into a 32 KiB LDS tile and writes each voxel of grad_vox exactly once
+//      with plain stores.  The tile is 64-bit FIXED POINT (ds_add_u64): measured on gfx950
+//      ds_add_f32 sustains 0.33 lane-ops/clk/CU, ds_add_u64 6-10 (tools/lds_atomic_bench.hip).
+//      The scale is 2^(44-e) with 2^e >= max|dL/dp| (found by pass A), leaving 18 bits of headroom
+//      for the up-to-2^17 contributions a central voxel receives: 44 bits below the largest term --
+//      finer than fp32 accumulation, and order-independent (deterministic).  Which samples touch which brick depends only
+//      on the geometry, so it comes from a precomputed list (built once on the host, see
+//      toolbox/_fused_render.py); bricks are scheduled heaviest first.
+//   The first version scattered dL/dp with 8 global fp32 atomics per sample: 1.3 ms/image,
+//   95 % of it atomic throughput (all 16 384 rays converge on the central voxels).  It is kept
+//   as the fallback when no brick tables are passed.
 #include "common.hpp"
-#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -35,62 +43,66 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kBrick = 16;                       // brick edge (voxels)
 
-struct RenderDims { int N, NC, X, Y, Z, R, ZR; double step; float lo, hi; int dbg; };
-
-struct Taps {
-    int64_t off[8];
-    float w[8];
-    unsigned ok;          // bit t set: corner t inside the volume
+struct RenderDims {
+    int N, NC, X, Y, Z, R, ZR;
+    int sx, sy, sz;                              // element strides of one image's volume (fit in int)
+    double step;                                 // 1/(ZR-1)
+    float lo, hi;                                // clamp bounds of spherical_proj.py:66
 };
 
-// ATen grid_sampler_3d forward arithmetic (align_corners=True, zeros padding).
-// x -> X axis (stride sx), y -> Y, z -> Z: vox.permute(0,1,4,3,2) in spherical_proj.py:64
-__device__ __forceinline__ void make_taps(const RenderDims &D, int64_t sx, int64_t sy, int64_t sz,
-                                          float gx, float gy, float gz, Taps &t)
-{
-    const float ix = ((gx + 1.f) / 2) * (D.X - 1);
-    const float iy = ((gy + 1.f) / 2) * (D.Y - 1);
-    const float iz = ((gz + 1.f) / 2) * (D.Z - 1);
-    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;                 // weight of the +1 corner
-    const float wx0 = (fx + 1) - ix, wy0 = (fy + 1) - iy, wz0 = (fz + 1) - iz;
-    const bool bx0 = x0 >= 0 && x0 < D.X, bx1 = x0 + 1 >= 0 && x0 + 1 < D.X;
-    const bool by0 = y0 >= 0 && y0 < D.Y, by1 = y0 + 1 >= 0 && y0 + 1 < D.Y;
-    const bool bz0 = z0 >= 0 && z0 < D.Z, bz1 = z0 + 1 >= 0 && z0 + 1 < D.Z;
-    // ATen corner order: tnw, tne, tsw, tse, bnw, bne, bsw, bse  (t/b: z, n/s: y, w/e: x)
-    const int64_t ox0 = x0 * sx, ox1 = ox0 + sx, oy0 = y0 * sy, oy1 = oy0 + sy, oz0 = z0 * sz, oz1 = oz0 + sz;
-    t.off[0] = ox0 + oy0 + oz0; t.w[0] = wx0 * wy0 * wz0;
-    t.off[1] = ox1 + oy0 + oz0; t.w[1] = wx1 * wy0 * wz0;
-    t.off[2] = ox0 + oy1 + oz0; t.w[2] = wx0 * wy1 * wz0;
-    t.off[3] = ox1 + oy1 + oz0; t.w[3] = wx1 * wy1 * wz0;
-    t.off[4] = ox0 + oy0 + oz1; t.w[4] = wx0 * wy0 * wz1;
-    t.off[5] = ox1 + oy0 + oz1; t.w[5] = wx1 * wy0 * wz1;
-    t.off[6] = ox0 + oy1 + oz1; t.w[6] = wx0 * wy1 * wz1;
-    t.off[7] = ox1 + oy1 + oz1; t.w[7] = wx1 * wy1 * wz1;
-    t.ok = (unsigned)(bx0 && by0 && bz0) | (unsigned)(bx1 && by0 && bz0) << 1 |
-           (unsigned)(bx0 && by1 && bz0) << 2 | (unsigned)(bx1 && by1 && bz0) << 3 |
-           (unsigned)(bx0 && by0 && bz1) << 4 | (unsigned)(bx1 && by0 && bz1) << 5 |
-           (unsigned)(bx0 && by1 && bz1) << 6 | (unsigned)(bx1 && by1 && bz1) << 7;
-}
-
-__device__ __forceinline__ float gather(const float *__restrict__ base, const Taps &t)
-{
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; c++)
-        if (t.ok >> c & 1u) acc += base[t.off[c]] * t.w[c];
-    return acc;
-}
-
-// sample k of the ray with doubled direction (dx2,dy2,dz2) = 2*dir (fp64): spherical_proj.py:50-56
+// sample k of the ray with doubled direction 2*dir (fp64): spherical_proj.py:50-56
 __device__ __forceinline__ void sample_pos(const RenderDims &D, double dx2, double dy2, double dz2, int k,
                                            float &gx, float &gy, float &gz)
 {
     const double alpha = (k == D.ZR - 1) ? 1.0 : (double)k * D.step;       // numpy.linspace(0,1,ZR)[k]
     const double a = 1.0 - alpha;
     gx = (float)(dx2 * a); gy = (float)(dy2 * a); gz = (float)(dz2 * a);
+}
+
+// ATen grid_sampler_3d coordinates (align_corners=True): base corner + weights of the two corners
+// per axis.  x -> X axis, y -> Y, z -> Z (vox.permute(0,1,4,3,2) in spherical_proj.py:64).
+struct Cell { int x0, y0, z0; float wx0, wx1, wy0, wy1, wz0, wz1; };
+
+__device__ __forceinline__ bool locate(const RenderDims &D, float gx, float gy, float gz, Cell &c)
+{
+    const float ix = ((gx + 1.f) / 2) * (D.X - 1);
+    const float iy = ((gy + 1.f) / 2) * (D.Y - 1);
+    const float iz = ((gz + 1.f) / 2) * (D.Z - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    c.x0 = (int)fx; c.y0 = (int)fy; c.z0 = (int)fz;
+    c.wx1 = ix - fx; c.wy1 = iy - fy; c.wz1 = iz - fz;                       // weight of the +1 corner
+    c.wx0 = (fx + 1) - ix; c.wy0 = (fy + 1) - iy; c.wz0 = (fz + 1) - iz;
+    // at least one of the 8 corners inside the volume?
+    return c.x0 >= -1 && c.x0 < D.X && c.y0 >= -1 && c.y0 < D.Y && c.z0 >= -1 && c.z0 < D.Z;
+}
+
+// ATen corner order: tnw, tne, tsw, tse, bnw, bne, bsw, bse (t/b: z, n/s: y, w/e: x); weight
+// products evaluated left to right as ATen does.
+__device__ __forceinline__ float corner_w(const Cell &c, int i)
+{
+    const float wx = (i & 1) ? c.wx1 : c.wx0, wy = (i & 2) ? c.wy1 : c.wy0, wz = (i & 4) ? c.wz1 : c.wz0;
+    return wx * wy * wz;
+}
+
+__device__ __forceinline__ float gather(const RenderDims &D, const float *__restrict__ base, const Cell &c)
+{
+    const int o = c.x0 * D.sx + c.y0 * D.sy + c.z0 * D.sz;
+    float acc = 0.f;
+    if (c.x0 >= 0 && c.x0 + 1 < D.X && c.y0 >= 0 && c.y0 + 1 < D.Y && c.z0 >= 0 && c.z0 + 1 < D.Z) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            acc += base[o + ((i & 1) ? D.sx : 0) + ((i & 2) ? D.sy : 0) + ((i & 4) ? D.sz : 0)] * corner_w(c, i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int x = c.x0 + (i & 1), y = c.y0 + ((i >> 1) & 1), z = c.z0 + ((i >> 2) & 1);
+            if (x >= 0 && x < D.X && y >= 0 && y < D.Y && z >= 0 && z < D.Z)
+                acc += base[x * D.sx + y * D.sy + z * D.sz] * corner_w(c, i);
+        }
+    }
+    return acc;
 }
 
 __device__ __forceinline__ double wave_incl_prod_up(double v, int lane)
@@ -127,11 +139,51 @@ __device__ __forceinline__ void ray_decode(const RenderDims &D, int64_t r, int64
     n = nc / D.NC;
 }
 
-// ---- forward --------------------------------------------------------------------------------
+// Sampling with a coalescing-friendly mapping: in round c (0..3) lane l samples k = k0 + 64c + l, so
+// the 64 lanes of one load instruction walk 32 voxels along the ray instead of 128 (half the
+// distinct cache lines per gather).  The raw sample values go through a per-wave 1 KiB LDS row and
+// come back blocked (lane l <- samples 4l..4l+3, one ds_read_b128) for the lane-local + wave scan.
+// LDS traffic of one wave is processed in issue order, so wave-scope fences (compiler ordering only)
+// are sufficient -- no workgroup barrier.
+template <bool WITH_MASK>
+__device__ __forceinline__ void lane_samples(const RenderDims &D, const float *__restrict__ base, double dx2,
+                                             double dy2, double dz2, int k0, int lane, float *__restrict__ row,
+                                             float (&p)[4], bool (&pass)[4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int k = k0 + c * 64 + lane;
+        float v = 0.f;                                               // v = 0 -> p = lo; beyond ZR masked below
+        if (k < D.ZR) {
+            float gx, gy, gz;
+            sample_pos(D, dx2, dy2, dz2, k, gx, gy, gz);
+            Cell cl;
+            if (locate(D, gx, gy, gz, cl)) v = gather(D, base, cl);
+        }
+        row[c * 64 + lane] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float4 v4 = *reinterpret_cast<const float4 *>(row + lane * 4);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                                 // row is reused by the next ray
+    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const bool live = k0 + lane * 4 + t < D.ZR;
+        if (WITH_MASK) pass[t] = live && (vv[t] >= D.lo) && (vv[t] <= D.hi);   // torch.clamp backward mask
+        p[t] = live ? fminf(fmaxf(vv[t], D.lo), D.hi) : 0.f;        // clamp(.,1e-5,1-1e-5), :66; 0 = neutral
+    }
+}
+
+// ---- forward ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void render_fwd_kernel(RenderDims D, View5 vox, const double *__restrict__ dirs,
                                                              const float *__restrict__ dw, View4 out)
 {
+    __shared__ __attribute__((aligned(16))) float rows[kWavesPerBlock][256];
     const int lane = threadIdx.x & 63;
+    float *row = rows[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
     const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
@@ -142,20 +194,10 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(RenderDims D, View5 
         const double dx2 = dirs[q * 3 + 0] * 2, dy2 = dirs[q * 3 + 1] * 2, dz2 = dirs[q * 3 + 2] * 2;
         double carry = 1.0, acc = 0.0;
         for (int k0 = 0; k0 < D.ZR; k0 += 256) {
+            const int kb = k0 + lane * 4;
             float p[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int k = k0 + lane * 4 + t;
-                p[t] = 0.f;                                              // neutral beyond the ray's end
-                if (k < D.ZR) {
-                    float gx, gy, gz;
-                    sample_pos(D, dx2, dy2, dz2, k, gx, gy, gz);
-                    Taps tp;
-                    make_taps(D, vox.s2, vox.s3, vox.s4, gx, gy, gz, tp);
-                    const float v = gather(base, tp);
-                    p[t] = fminf(fmaxf(v, D.lo), D.hi);                  // clamp(.,1e-5,1-1e-5), :66
-                }
-            }
+            bool unused[4];
+            lane_samples<false>(D, base, dx2, dy2, dz2, k0, lane, row, p, unused);
             const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2],
                          q3 = 1.0 - (double)p[3];
             const double e1 = q0, e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
@@ -163,7 +205,6 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(RenderDims D, View5 
             double excl = __shfl_up(incl, 1, 64);
             if (lane == 0) excl = 1.0;
             excl *= carry;
-            const int kb = k0 + lane * 4;
             // expected depth: sum_k s_k * depth_weight[k]   (:68)
             if (kb + 0 < D.ZR) acc += ((double)p[0] * excl) * (double)dw[kb + 0];
             if (kb + 1 < D.ZR) acc += ((double)p[1] * (excl * e1)) * (double)dw[kb + 1];
@@ -179,10 +220,187 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(RenderDims D, View5 
     }
 }
 
-// ---- backward (single chunk: ZR <= 256) ---------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void render_bwd_kernel(RenderDims D, View5 vox, const double *__restrict__ dirs,
-                                                             const float *__restrict__ dw, View4 gout, View5 gvox)
+// dL/dp of the lane's 4 samples (ZR <= 256: the whole ray is one chunk), already clamp-masked
+__device__ __forceinline__ void lane_dp(const RenderDims &D, const float *__restrict__ base, double dx2, double dy2,
+                                        double dz2, const float *__restrict__ dw, float g, int lane,
+                                        float *__restrict__ row, float (&dp)[4])
 {
+    const int kb = lane * 4;
+    float p[4], w[4];
+    bool pass[4];
+    lane_samples<true>(D, base, dx2, dy2, dz2, 0, lane, row, p, pass);
+#pragma unroll
+    for (int t = 0; t < 4; t++) w[t] = (kb + t < D.ZR) ? dw[kb + t] : 0.f;
+    const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2], q3 = 1.0 - (double)p[3];
+    const double e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
+    const double incl = wave_incl_prod_up(tot, lane);
+    double excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0;
+    const double prod_all = __shfl(incl, 63, 64);
+    const double T0 = excl, T1 = excl * q0, T2 = excl * e2, T3 = excl * e3;       // transmittance before k
+    const double sw0 = (double)p[0] * T0 * (double)w[0], sw1 = (double)p[1] * T1 * (double)w[1];
+    const double sw2 = (double)p[2] * T2 * (double)w[2], sw3 = (double)p[3] * T3 * (double)w[3];
+    const double lane_sw = ((sw3 + sw2) + sw1) + sw0;
+    const double incl_s = wave_incl_sum_down(lane_sw, lane);
+    double after = __shfl_down(incl_s, 1, 64);
+    if (lane == 63) after = 0.0;
+    after += prod_all;                                                   // prod(1-p) joins the suffix
+    const double A3 = after, A2 = after + sw3, A1 = after + (sw3 + sw2), A0 = after + ((sw3 + sw2) + sw1);
+    const double gd = (double)g;
+    dp[0] = pass[0] ? (float)(gd * (T0 * (double)w[0] - A0 / q0)) : 0.f;
+    dp[1] = pass[1] ? (float)(gd * (T1 * (double)w[1] - A1 / q1)) : 0.f;
+    dp[2] = pass[2] ? (float)(gd * (T2 * (double)w[2] - A2 / q2)) : 0.f;
+    dp[3] = pass[3] ? (float)(gd * (T3 * (double)w[3] - A3 / q3)) : 0.f;
+}
+
+// ---- backward pass A: dL/dp -> scratch [rays, ZR] -----------------------------------------------
+__global__ __launch_bounds__(kBlock) void render_bwd_dp_kernel(RenderDims D, View5 vox, const double *__restrict__ dirs,
+                                                                const float *__restrict__ dw, View4 gout,
+                                                                float *__restrict__ dpbuf,
+                                                                unsigned *__restrict__ dpmax_bits)
+{
+    __shared__ __attribute__((aligned(16))) float rows[kWavesPerBlock][256];
+    float *row = rows[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
+    float wmax = 0.f;
+    for (int64_t r = wave0; r < rays; r += nwaves) {
+        int64_t n; int c, q;
+        ray_decode(D, r, n, c, q);
+        const int i = q / D.R, j = q % D.R;
+        const float g = gout.p[n * gout.s0 + c * gout.s1 + i * gout.s2 + j * gout.s3];
+        float dp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g != 0.0f) {                                                 // wave-uniform
+            const float *__restrict__ base = vox.p + n * vox.s0 + c * vox.s1;
+            lane_dp(D, base, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, dw, g, lane, row, dp);
+        }
+        // running max |dL/dp| of this wave (bit pattern of a non-negative float orders like the value)
+        wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
+        float *dst = dpbuf + r * D.ZR + lane * 4;
+        if ((D.ZR & 3) == 0) {
+            if (lane * 4 < D.ZR) *reinterpret_cast<float4 *>(dst) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (lane * 4 + t < D.ZR) dst[t] = dp[t];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    // one same-address global atomic costs ~10 ns: publish only when this wave would raise the maximum
+    // (the racy pre-read is safe -- the value only grows)
+    if (lane == 0 && wmax > 0.f && isfinite(wmax)) {
+        const unsigned bits = __float_as_uint(wmax);
+        if (bits > __hip_atomic_load(dpmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dpmax_bits, bits);
+    }
+}
+
+// ---- backward pass B: brick-owned accumulation ----------------------------------------------------
+// brick_table [rows,4] = (brick id, begin, end, mode) into chunk_list, heaviest first; mode 0: the
+// row covers the whole brick (plain stores); mode 1: the brick's list is split over several rows
+// (each flushes its tile with atomics onto the brick pre-zeroed by zero_shared_bricks_kernel).
+// chunk_list entries = (ray q << 12) | (first sample k << 4) | (len - 1): up to 16 CONSECUTIVE samples
+// of one ray, handled by 16 adjacent lanes -- the list word and the ray direction are broadcast
+// loads and the dL/dp read is one 64-byte segment.
+__global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, const double *__restrict__ dirs,
+                                                                   const float *__restrict__ dpbuf,
+                                                                   const int *__restrict__ brick_table,
+                                                                   const int *__restrict__ chunk_list,
+                                                                   const unsigned *__restrict__ dpmax_bits, View5 gvox)
+{
+    __shared__ unsigned long long tile[kBrick * kBrick * kBrick];
+    // fixed-point scale 2^(44-e), 2^e >= max|dL/dp| (see file header); max == 0 -> everything is 0
+    int e = 0;
+    (void)frexpf(__uint_as_float(*dpmax_bits), &e);
+    const double scale = ldexp(1.0, 44 - e), inv_scale = ldexp(1.0, e - 44);
+    const int img = blockIdx.y;
+    const int brick = brick_table[blockIdx.x * 4 + 0];
+    const int begin = brick_table[blockIdx.x * 4 + 1], end = brick_table[blockIdx.x * 4 + 2];
+    const int shared = brick_table[blockIdx.x * 4 + 3];
+    const int nby = (D.Y + kBrick - 1) / kBrick, nbz = (D.Z + kBrick - 1) / kBrick;
+    const int bx = brick / (nby * nbz), by = (brick / nbz) % nby, bz = brick % nbz;
+    const int ox = bx * kBrick, oy = by * kBrick, oz = bz * kBrick;
+    for (int t = threadIdx.x; t < kBrick * kBrick * kBrick; t += kBlock) tile[t] = 0ull;
+    __syncthreads();
+    const float *__restrict__ dpi = dpbuf + (int64_t)img * D.R * D.R * D.ZR;
+    // A wave takes 64 consecutive list words with ONE coalesced load, then walks them four at a time
+    // (16 lanes per chunk), batching the dependent dL/dp and direction loads of four steps so that the
+    // loop exposes ~5 memory latencies per 64 chunks instead of 32.
+    const int lane = threadIdx.x & 63, sub = lane & 15, g4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int c0 = begin + wave * 64; c0 < end; c0 += kWavesPerBlock * 64) {
+        const int nvalid = (end - c0 < 64) ? end - c0 : 64;
+        const unsigned myword = (lane < nvalid) ? (unsigned)chunk_list[c0 + lane] : 0u;
+        for (int s0 = 0; s0 * 4 < nvalid; s0 += 4) {
+            float dp[4];
+            int qq[4], kk[4];
+            double dx2[4], dy2[4], dz2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ci = (s0 + u) * 4 + g4;
+                const unsigned ent = (unsigned)__shfl((int)myword, ci & 63, 64);
+                qq[u] = (int)(ent >> 12);
+                kk[u] = (int)((ent >> 4) & 255u) + sub;
+                const bool act = ci < nvalid && sub <= (int)(ent & 15u);
+                dp[u] = act ? dpi[(int64_t)qq[u] * D.ZR + kk[u]] : 0.f;
+                dx2[u] = dirs[qq[u] * 3 + 0] * 2; dy2[u] = dirs[qq[u] * 3 + 1] * 2; dz2[u] = dirs[qq[u] * 3 + 2] * 2;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (dp[u] == 0.0f) continue;
+                float gx, gy, gz;
+                sample_pos(D, dx2[u], dy2[u], dz2[u], kk[u], gx, gy, gz);
+                Cell c;
+                locate(D, gx, gy, gz, c);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int lx = c.x0 + (i & 1) - ox, ly = c.y0 + ((i >> 1) & 1) - oy, lz = c.z0 + ((i >> 2) & 1) - oz;
+                    if ((unsigned)lx < (unsigned)kBrick && (unsigned)ly < (unsigned)kBrick &&
+                        (unsigned)lz < (unsigned)kBrick)
+                        atomicAdd(&tile[(lx * kBrick + ly) * kBrick + lz],
+                                  (unsigned long long)__double2ll_rn((double)(corner_w(c, i) * dp[u]) * scale));   // ds_add_u64
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = img / D.NC, cc = img % D.NC;
+    float *gbase = gvox.p + n * gvox.s0 + cc * gvox.s1;
+    for (int t = threadIdx.x; t < kBrick * kBrick * kBrick; t += kBlock) {
+        const int lz = t % kBrick, ly = (t / kBrick) % kBrick, lx = t / (kBrick * kBrick);
+        const int x = ox + lx, y = oy + ly, z = oz + lz;
+        if (x < D.X && y < D.Y && z < D.Z) {
+            float *dst = gbase + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
+            const float val = (float)((double)(long long)tile[t] * inv_scale);
+            if (!shared) *dst = val;
+            else if (tile[t] != 0ull) unsafeAtomicAdd(dst, val);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void zero_shared_bricks_kernel(RenderDims D, const int *__restrict__ brick_table,
+                                                                     View5 gvox)
+{
+    if (brick_table[blockIdx.x * 4 + 3] == 0) return;
+    const int brick = brick_table[blockIdx.x * 4 + 0];
+    const int nby = (D.Y + kBrick - 1) / kBrick, nbz = (D.Z + kBrick - 1) / kBrick;
+    const int ox = (brick / (nby * nbz)) * kBrick, oy = ((brick / nbz) % nby) * kBrick, oz = (brick % nbz) * kBrick;
+    const int img = blockIdx.y;
+    float *gbase = gvox.p + (img / D.NC) * gvox.s0 + (img % D.NC) * gvox.s1;
+    for (int t = threadIdx.x; t < kBrick * kBrick * kBrick; t += kBlock) {
+        const int x = ox + t / (kBrick * kBrick), y = oy + (t / kBrick) % kBrick, z = oz + t % kBrick;
+        if (x < D.X && y < D.Y && z < D.Z) gbase[x * gvox.s2 + y * gvox.s3 + z * gvox.s4] = 0.f;
+    }
+}
+
+// ---- backward fallback: global-atomic scatter (no tables) ------------------------------------------
+__global__ __launch_bounds__(kBlock) void render_bwd_atomic_kernel(RenderDims D, View5 vox, const double *__restrict__ dirs,
+                                                                    const float *__restrict__ dw, View4 gout, View5 gvox)
+{
+    __shared__ __attribute__((aligned(16))) float rows[kWavesPerBlock][256];
+    float *row = rows[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -196,59 +414,21 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(RenderDims D, View5 
         const float *__restrict__ base = vox.p + n * vox.s0 + c * vox.s1;
         float *gbase = gvox.p + n * gvox.s0 + c * gvox.s1;
         const double dx2 = dirs[q * 3 + 0] * 2, dy2 = dirs[q * 3 + 1] * 2, dz2 = dirs[q * 3 + 2] * 2;
-        float p[4], w[4];
-        bool pass[4];
-        const int kb = lane * 4;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int k = kb + t;
-            p[t] = 0.f; w[t] = 0.f; pass[t] = false;
-            if (k < D.ZR) {
-                float gx, gy, gz;
-                sample_pos(D, dx2, dy2, dz2, k, gx, gy, gz);
-                Taps tp;
-                make_taps(D, vox.s2, vox.s3, vox.s4, gx, gy, gz, tp);
-                const float v = gather(base, tp);
-                pass[t] = (v >= D.lo) && (v <= D.hi) && tp.ok != 0u;     // torch.clamp backward mask
-                p[t] = fminf(fmaxf(v, D.lo), D.hi);
-                w[t] = dw[k];
-            }
-        }
-        const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2],
-                     q3 = 1.0 - (double)p[3];
-        const double e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
-        const double incl = wave_incl_prod_up(tot, lane);
-        double excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0;
-        const double prod_all = __shfl(incl, 63, 64);
-        const double T0 = excl, T1 = excl * q0, T2 = excl * e2, T3 = excl * e3;   // transmittance before k
-        const double sw0 = (double)p[0] * T0 * (double)w[0], sw1 = (double)p[1] * T1 * (double)w[1];
-        const double sw2 = (double)p[2] * T2 * (double)w[2], sw3 = (double)p[3] * T3 * (double)w[3];
-        const double lane_sw = ((sw3 + sw2) + sw1) + sw0;
-        const double incl_s = wave_incl_sum_down(lane_sw, lane);
-        double after = __shfl_down(incl_s, 1, 64);
-        if (lane == 63) after = 0.0;
-        after += prod_all;                                               // tail term prod(1-p) joins the suffix
-        const double A3 = after, A2 = after + sw3, A1 = after + (sw3 + sw2), A0 = after + ((sw3 + sw2) + sw1);
-        const double gd = (double)g;
         float dp[4];
-        dp[0] = (float)(gd * (T0 * (double)w[0] - A0 / q0));
-        dp[1] = (float)(gd * (T1 * (double)w[1] - A1 / q1));
-        dp[2] = (float)(gd * (T2 * (double)w[2] - A2 / q2));
-        dp[3] = (float)(gd * (T3 * (double)w[3] - A3 / q3));
+        lane_dp(D, base, dx2, dy2, dz2, dw, g, lane, row, dp);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            if (!pass[t] || dp[t] == 0.0f) continue;
-            if (D.dbg == 1) continue;                                   // EXPERIMENT: no atomics at all
+            if (dp[t] == 0.0f) continue;
             float gx, gy, gz;
-            sample_pos(D, dx2, dy2, dz2, kb + t, gx, gy, gz);
-            if (D.dbg == 2 && (gx * gx + gy * gy + gz * gz) < 0.0635f) continue;   // EXPERIMENT: skip rho < 16 vox
-            if (D.dbg == 3 && (gx * gx + gy * gy + gz * gz) < 0.0159f) continue;   // EXPERIMENT: skip rho < 8 vox
-            Taps tp;
-            make_taps(D, gvox.s2, gvox.s3, gvox.s4, gx, gy, gz, tp);
+            sample_pos(D, dx2, dy2, dz2, lane * 4 + t, gx, gy, gz);
+            Cell cl;
+            locate(D, gx, gy, gz, cl);
 #pragma unroll
-            for (int cidx = 0; cidx < 8; cidx++)
-                if (tp.ok >> cidx & 1u) unsafeAtomicAdd(gbase + tp.off[cidx], tp.w[cidx] * dp[t]);
+            for (int ci = 0; ci < 8; ci++) {
+                const int x = cl.x0 + (ci & 1), y = cl.y0 + ((ci >> 1) & 1), z = cl.z0 + ((ci >> 2) & 1);
+                if (x >= 0 && x < D.X && y >= 0 && y < D.Y && z >= 0 && z < D.Z)
+                    unsafeAtomicAdd(gbase + x * gvox.s2 + y * gvox.s3 + z * gvox.s4, corner_w(cl, ci) * dp[t]);
+            }
         }
     }
 }
@@ -269,6 +449,13 @@ int check_render(const char *op, const genre_tensor *vox, const genre_tensor *di
     D.N = (int)vox->size[0]; D.NC = (int)vox->size[1];
     D.X = (int)vox->size[2]; D.Y = (int)vox->size[3]; D.Z = (int)vox->size[4];
     D.R = (int)map->size[2];
+    int64_t span = 1;
+    for (int i = 2; i < 5; i++) {
+        GENRE_REQUIRE(vox->stride[i] >= 0, "%s: negative vox strides are not supported", op);
+        span += (vox->size[i] - 1) * vox->stride[i];
+    }
+    GENRE_REQUIRE(span < ((int64_t)1 << 31), "%s: one image's volume must span < 2^31 elements", op);
+    D.sx = (int)vox->stride[2]; D.sy = (int)vox->stride[3]; D.sz = (int)vox->stride[4];
     // dirs: [R,R,6] fp32 words = [R,R,3] float64 unit directions (the caller passes the raw storage)
     GENRE_REQUIRE(dirs && dirs->data && dirs->ndim == 3 && dirs->size[0] == D.R && dirs->size[1] == D.R &&
                       dirs->size[2] == 6 && is_contiguous(dirs) && ((uintptr_t)dirs->data & 7u) == 0,
@@ -277,7 +464,6 @@ int check_render(const char *op, const genre_tensor *vox, const genre_tensor *di
     D.ZR = (int)dw->size[0];
     D.step = D.ZR > 1 ? 1.0 / (double)(D.ZR - 1) : 0.0;
     D.lo = 1e-5f; D.hi = (float)(1 - 1e-5);                              // spherical_proj.py:66
-    { const char *e = getenv("GENRE_DBG"); D.dbg = e ? atoi(e) : 0; }
     return 1;
 }
 
@@ -294,9 +480,6 @@ inline int grid_for_rays(int64_t rays)
 
 using namespace genre;
 
-// Extension (no native counterpart in the reference: fuses spherical_proj.py:62-72).
-// vox [N,NC,X,Y,Z] (any strides) -> out [N,NC,R,R];  dirs = float64 [R,R,3] unit directions of
-// spherical_proj.py:43-49 passed as an fp32-typed [R,R,6] view; depth_weight [ZR] (:57).
 extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *dirs,
                                               const genre_tensor *depth_weight, const genre_tensor *out,
                                               void *stream)
@@ -312,30 +495,63 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
     return 1;
 }
 
-// grad_vox [N,NC,X,Y,Z] is fully written (zeroed here, then accumulated).
 extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
                                                const genre_tensor *depth_weight, const genre_tensor *grad_out,
-                                               const genre_tensor *grad_vox, void *stream)
+                                               const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
+                                               const genre_tensor *brick_table, const genre_tensor *sample_list,
+                                               void *stream)
 {
     const char *op = "render_spherical_backward";
     RenderDims D{};
     if (!check_render(op, vox, dirs, depth_weight, grad_out, D)) return 0;
     GENRE_REQUIRE(is_f32(grad_vox, 5) && same_shape(grad_vox, vox), "%s: grad_vox must have the shape of vox", op);
     GENRE_REQUIRE(D.ZR <= 256, "%s: fused backward supports z_res <= 256", op);
-    GENRE_REQUIRE(is_contiguous(grad_vox) && aligned16(grad_vox->data) && numel(grad_vox) % 4 == 0,
-                  "%s: grad_vox must be contiguous, 16-byte aligned, numel %% 4 == 0", op);
     hipStream_t st = (hipStream_t)stream;
     const int64_t nv = numel(grad_vox);
+    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
     if (nv == 0) return 1;
+    const bool bricks = brick_table && sample_list && dp_scratch && brick_table->ndim == 2 && brick_table->size[0] > 0;
+    if (bricks) {
+        const int nb = ((D.X + kBrick - 1) / kBrick) * ((D.Y + kBrick - 1) / kBrick) * ((D.Z + kBrick - 1) / kBrick);
+        GENRE_REQUIRE(is_i32(brick_table, 2) && brick_table->size[0] >= nb && brick_table->size[1] == 4 &&
+                          is_contiguous(brick_table) && brick_table->size[0] < (1 << 30),
+                      "%s: brick_table must be a contiguous int32 [rows >= %d, 4] tensor", op, nb);
+        const int rows = (int)brick_table->size[0];
+        GENRE_REQUIRE(is_i32(sample_list, 1) && is_contiguous(sample_list), "%s: sample_list must be int32 [S]", op);
+        GENRE_REQUIRE(is_f32(dp_scratch, 1) && is_contiguous(dp_scratch) && dp_scratch->size[0] >= rays * D.ZR + 4 &&
+                          aligned16(dp_scratch->data),
+                      "%s: dp_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR + 4 elements", op);
+        GENRE_REQUIRE((int64_t)D.R * D.R < (1 << 20), "%s: R*R must be < 2^20", op);
+        GENRE_REQUIRE(D.N * D.NC <= 65535, "%s: N*NC must be <= 65535", op);
+        unsigned *dpmax = (unsigned *)dp_scratch->data + rays * D.ZR;       // max|dL/dp| lives behind the samples
+        if (hipMemsetAsync(dpmax, 0, 16, st) != hipSuccess) return fail("%s: hipMemsetAsync failed", op);
+        if (rays > 0) {
+            render_bwd_dp_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(
+                D, view5(vox), (const double *)dirs->data, (const float *)depth_weight->data, view4(grad_out),
+                (float *)dp_scratch->data, dpmax);
+            GENRE_LAUNCH_CHECK("render_spherical backward (dL/dp)");
+        }
+        if (rows > nb) {        // some bricks are split over several rows: those accumulate with atomics
+            zero_shared_bricks_kernel<<<dim3(rows, D.N * D.NC), kBlock, 0, st>>>(D, (const int *)brick_table->data,
+                                                                                view5(grad_vox));
+            GENRE_LAUNCH_CHECK("render_spherical backward (zero shared bricks)");
+        }
+        render_bwd_brick_kernel<<<dim3(rows, D.N * D.NC), kBlock, 0, st>>>(
+            D, (const double *)dirs->data, (const float *)dp_scratch->data, (const int *)brick_table->data,
+            (const int *)sample_list->data, dpmax, view5(grad_vox));
+        GENRE_LAUNCH_CHECK("render_spherical backward (bricks)");
+        return 1;
+    }
+    GENRE_REQUIRE(is_contiguous(grad_vox) && aligned16(grad_vox->data) && nv % 4 == 0,
+                  "%s: (atomic fallback) grad_vox must be contiguous, 16-byte aligned, numel %% 4 == 0", op);
     int64_t zb = (nv / 4 + kBlock - 1) / kBlock;
     if (zb > kCUs * 8) zb = kCUs * 8;
     zero_vec4_kernel<<<(int)zb, kBlock, 0, st>>>((float4 *)grad_vox->data, nv / 4);
     GENRE_LAUNCH_CHECK("render_spherical backward (zero)");
-    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
     if (rays == 0) return 1;
-    render_bwd_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(D, view5(vox), (const double *)dirs->data,
-                                                             (const float *)depth_weight->data, view4(grad_out),
-                                                             view5(grad_vox));
+    render_bwd_atomic_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(D, view5(vox), (const double *)dirs->data,
+                                                                    (const float *)depth_weight->data,
+                                                                    view4(grad_out), view5(grad_vox));
     GENRE_LAUNCH_CHECK("render_spherical backward");
     return 1;
 }

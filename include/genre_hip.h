@@ -160,11 +160,25 @@ int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *
                                    void *stream);
 
 /* Adjoint of the above w.r.t. vox (what autograd derives for the reference's
- * op chain).  grad_out [N,NC,R,R] -> grad_vox [N,NC,X,Y,Z] contiguous, fully
- * written.  Recomputes the forward; requires ZR <= 256. */
+ * op chain).  grad_out [N,NC,R,R] -> grad_vox [N,NC,X,Y,Z], fully written.
+ * Recomputes the forward; requires ZR <= 256.  Two modes:
+ *  - dp_scratch, brick_table, sample_list given: two passes without global
+ *    atomics.  dp_scratch: fp32 [>= N*NC*R*R*ZR + 4], 16-byte aligned (receives
+ *    dL/dp per sample and, behind them, max|dL/dp| for the fixed-point scale).  brick_table: int32 [rows,4] = (brick id, begin, end, mode),
+ *    brick id = (bx*nby+by)*nbz+bz over ceil(X/16)*ceil(Y/16)*ceil(Z/16) bricks, every
+ *    brick in >= 1 row, rows in the order they should be scheduled; mode 0: the row
+ *    is the brick's only one, mode 1: the brick's samples are split over several rows; sample_list: int32 [S], entry
+ *    (ray index i*R+j) << 12 | k0 << 4 | (len-1) = the run of samples k0..k0+len-1
+ *    (len <= 16) of that ray; rows begin..end of a brick cover every sample with at
+ *    least one trilinear corner inside that brick (geometry only; reference
+ *    builder: genre-shapehd_amd/toolbox/_fused_render.py:build_brick_tables).
+ *  - the three pointers NULL: global-atomic scatter fallback (grad_vox must be
+ *    contiguous, 16-byte aligned, numel % 4 == 0). */
 int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
                                     const genre_tensor *depth_weight, const genre_tensor *grad_out,
-                                    const genre_tensor *grad_vox, void *stream);
+                                    const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
+                                    const genre_tensor *brick_table, const genre_tensor *sample_list,
+                                    void *stream);
 
 #ifdef __cplusplus
 }
