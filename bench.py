@@ -111,14 +111,18 @@ def kernel_table(G, dev, B):
         out = torch.empty((B, 1, 128, 128), device=dev)
         gout = torch.randn_like(out)
         gvox = torch.empty_like(vox)
-        table, chunks = _fused_render._tables_for(vox, mod._dirs64, mod.z_res)
-        scratch = torch.empty((B * 128 * 128 * mod.z_res + 4,), device=dev)
-        t = event_time_us(lambda: render_lib.render_spherical_forward(vox, dirs, mod.depth_weight, out), iters, 5)
-        rows["render_fwd_fused"] = dict(us=t, bytes=B * BYTES_RENDER_FUSED, kernels="render_fwd_kernel")
-        t = event_time_us(lambda: render_lib.render_spherical_backward(vox, dirs, mod.depth_weight, gout, gvox,
-                                                                       scratch, table, chunks), iters, 5)
+        T = _fused_render.tables_for(vox.shape, dev, mod._dirs64, mod.z_res)
+        vbuf = torch.empty((B * 128 * 128 * mod.z_res,), device=dev)
+        scratch = torch.empty((vbuf.numel() + 4,), device=dev)
+        t = event_time_us(lambda: render_lib.render_spherical_forward(
+            vox, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"]), iters, 5)
+        rows["render_fwd_fused"] = dict(us=t, bytes=B * BYTES_RENDER_FUSED,
+                                        kernels="render_sample_brick_kernel+render_scan_fwd_kernel")
+        t = event_time_us(lambda: render_lib.render_spherical_backward(
+            vox, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"], vbuf, T["kin"]),
+            iters, 5)
         rows["render_bwd_fused"] = dict(us=t, bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                                        kernels="render_bwd_dp_kernel+render_bwd_brick_kernel")
+                                        kernels="render_scan_bwd_kernel+render_bwd_brick_kernel")
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3
     return rows

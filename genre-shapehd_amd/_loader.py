@@ -43,7 +43,7 @@ def _load():
                         ("genre_spherical_back_proj_backward", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
-                        ("genre_render_spherical_forward", 4), ("genre_render_spherical_backward", 8)):
+                        ("genre_render_spherical_forward", 8), ("genre_render_spherical_backward", 10)):
         fn = getattr(lib, name, None)
         if fn is None:
             continue
@@ -149,16 +149,20 @@ class _RenderLib:
     """fused render_spherical (extension; fuses toolbox/spherical_proj.py:62-72)"""
 
     @staticmethod
-    def render_spherical_forward(vox, dirs64_as_f32, depth_weight, out):
-        return _call("genre_render_spherical_forward", vox, dirs64_as_f32, depth_weight, out)
+    def render_spherical_forward(vox, dirs64_as_f32, depth_weight, out,
+                                 v_scratch=None, fwd_table=None, fwd_chunks=None, kin=None):
+        """with the four optional tensors: LDS-staged brick sampling + scan (v_scratch receives the raw
+        sample values); without: one wave-per-ray gather kernel"""
+        return _call("genre_render_spherical_forward", vox, dirs64_as_f32, depth_weight, out,
+                     v_scratch, fwd_table, fwd_chunks, kin)
 
     @staticmethod
     def render_spherical_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                                  dp_scratch=None, brick_table=None, sample_list=None):
-        """with the three optional tensors: two-pass brick-owned backward (no global atomics);
-        without: global-atomic scatter fallback"""
+                                  dp_scratch=None, brick_table=None, chunk_list=None, v_scratch=None, kin=None):
+        """dp_scratch/brick_table/chunk_list given: brick-owned backward (no global atomics), re-using the
+        forward's v_scratch when it is passed too; without: global-atomic scatter fallback"""
         return _call("genre_render_spherical_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                     dp_scratch, brick_table, sample_list)
+                     dp_scratch, brick_table, chunk_list, v_scratch, kin)
 
 
 class _MyLib:

@@ -178,6 +178,9 @@ __device__ __forceinline__ void lane_samples(const RenderDims &D, const float *_
 }
 
 // ---- forward ----------------------------------------------------------------------------------
+__device__ __forceinline__ double expect4(const RenderDims &D, const float (&p)[4], const float *__restrict__ dw,
+                                          int kb, int lane, double &carry);
+
 __global__ __launch_bounds__(kBlock) void render_fwd_kernel(RenderDims D, View5 vox, const double *__restrict__ dirs,
                                                              const float *__restrict__ dw, View4 out)
 {
@@ -194,23 +197,10 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(RenderDims D, View5 
         const double dx2 = dirs[q * 3 + 0] * 2, dy2 = dirs[q * 3 + 1] * 2, dz2 = dirs[q * 3 + 2] * 2;
         double carry = 1.0, acc = 0.0;
         for (int k0 = 0; k0 < D.ZR; k0 += 256) {
-            const int kb = k0 + lane * 4;
             float p[4];
             bool unused[4];
             lane_samples<false>(D, base, dx2, dy2, dz2, k0, lane, row, p, unused);
-            const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2],
-                         q3 = 1.0 - (double)p[3];
-            const double e1 = q0, e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
-            const double incl = wave_incl_prod_up(tot, lane);
-            double excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0;
-            excl *= carry;
-            // expected depth: sum_k s_k * depth_weight[k]   (:68)
-            if (kb + 0 < D.ZR) acc += ((double)p[0] * excl) * (double)dw[kb + 0];
-            if (kb + 1 < D.ZR) acc += ((double)p[1] * (excl * e1)) * (double)dw[kb + 1];
-            if (kb + 2 < D.ZR) acc += ((double)p[2] * (excl * e2)) * (double)dw[kb + 2];
-            if (kb + 3 < D.ZR) acc += ((double)p[3] * (excl * e3)) * (double)dw[kb + 3];
-            carry *= __shfl(incl, 63, 64);
+            acc += expect4(D, p, dw, k0 + lane * 4, lane, carry);
         }
         const double total = wave_sum(acc) + carry;                      // + prod(1-p)  (:69-71)
         if (lane == 0) {
@@ -220,15 +210,42 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(RenderDims D, View5 
     }
 }
 
-// dL/dp of the lane's 4 samples (ZR <= 256: the whole ray is one chunk), already clamp-masked
-__device__ __forceinline__ void lane_dp(const RenderDims &D, const float *__restrict__ base, double dx2, double dy2,
-                                        double dz2, const float *__restrict__ dw, float g, int lane,
-                                        float *__restrict__ row, float (&dp)[4])
+// clamp + mask of 4 raw sample values (kb = first sample index of this lane)
+__device__ __forceinline__ void clamp4(const RenderDims &D, const float (&v)[4], int kb, float (&p)[4], bool (&pass)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const bool live = kb + t < D.ZR;
+        pass[t] = live && (v[t] >= D.lo) && (v[t] <= D.hi);           // torch.clamp backward mask
+        p[t] = live ? fminf(fmaxf(v[t], D.lo), D.hi) : 0.f;           // clamp(.,1e-5,1-1e-5), :66; 0 = neutral
+    }
+}
+
+// forward scan of one ray chunk: returns this lane's share of sum_k s_k w_k, updates carry = prod(1-p)
+__device__ __forceinline__ double expect4(const RenderDims &D, const float (&p)[4], const float *__restrict__ dw,
+                                          int kb, int lane, double &carry)
+{
+    const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2], q3 = 1.0 - (double)p[3];
+    const double e1 = q0, e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
+    const double incl = wave_incl_prod_up(tot, lane);
+    double excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0;
+    excl *= carry;
+    double acc = 0.0;                                                    // sum_k s_k * depth_weight[k]   (:68)
+    if (kb + 0 < D.ZR) acc += ((double)p[0] * excl) * (double)dw[kb + 0];
+    if (kb + 1 < D.ZR) acc += ((double)p[1] * (excl * e1)) * (double)dw[kb + 1];
+    if (kb + 2 < D.ZR) acc += ((double)p[2] * (excl * e2)) * (double)dw[kb + 2];
+    if (kb + 3 < D.ZR) acc += ((double)p[3] * (excl * e3)) * (double)dw[kb + 3];
+    carry *= __shfl(incl, 63, 64);
+    return acc;
+}
+
+// dL/dp of the lane's 4 samples (ZR <= 256: the whole ray is one chunk), clamp-masked
+__device__ __forceinline__ void dp4(const RenderDims &D, const float (&p)[4], const bool (&pass)[4],
+                                    const float *__restrict__ dw, float g, int lane, float (&dp)[4])
 {
     const int kb = lane * 4;
-    float p[4], w[4];
-    bool pass[4];
-    lane_samples<true>(D, base, dx2, dy2, dz2, 0, lane, row, p, pass);
+    float w[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) w[t] = (kb + t < D.ZR) ? dw[kb + t] : 0.f;
     const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2], q3 = 1.0 - (double)p[3];
@@ -251,6 +268,40 @@ __device__ __forceinline__ void lane_dp(const RenderDims &D, const float *__rest
     dp[1] = pass[1] ? (float)(gd * (T1 * (double)w[1] - A1 / q1)) : 0.f;
     dp[2] = pass[2] ? (float)(gd * (T2 * (double)w[2] - A2 / q2)) : 0.f;
     dp[3] = pass[3] ? (float)(gd * (T3 * (double)w[3] - A3 / q3)) : 0.f;
+}
+
+__device__ __forceinline__ void lane_dp(const RenderDims &D, const float *__restrict__ base, double dx2, double dy2,
+                                        double dz2, const float *__restrict__ dw, float g, int lane,
+                                        float *__restrict__ row, float (&dp)[4])
+{
+    float p[4];
+    bool pass[4];
+    lane_samples<true>(D, base, dx2, dy2, dz2, 0, lane, row, p, pass);
+    dp4(D, p, pass, dw, g, lane, dp);
+}
+
+// publish a wave's max |dL/dp| (bit pattern of a non-negative float orders like the value).  One
+// same-address global atomic costs ~10 ns, so publish only when it would raise the maximum (the
+// racy pre-read is safe -- the value only grows).
+__device__ __forceinline__ void publish_max(float wmax, int lane, unsigned *dpmax_bits)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    if (lane == 0 && wmax > 0.f && isfinite(wmax)) {
+        const unsigned bits = __float_as_uint(wmax);
+        if (bits > __hip_atomic_load(dpmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dpmax_bits, bits);
+    }
+}
+
+__device__ __forceinline__ void store_dp(const RenderDims &D, float *dst, int lane, const float (&dp)[4])
+{
+    if ((D.ZR & 3) == 0) {
+        if (lane * 4 < D.ZR) *reinterpret_cast<float4 *>(dst) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (lane * 4 + t < D.ZR) dst[t] = dp[t];
+    }
 }
 
 // ---- backward pass A: dL/dp -> scratch [rays, ZR] -----------------------------------------------
@@ -276,25 +327,135 @@ __global__ __launch_bounds__(kBlock) void render_bwd_dp_kernel(RenderDims D, Vie
             const float *__restrict__ base = vox.p + n * vox.s0 + c * vox.s1;
             lane_dp(D, base, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, dw, g, lane, row, dp);
         }
-        // running max |dL/dp| of this wave (bit pattern of a non-negative float orders like the value)
         wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
-        float *dst = dpbuf + r * D.ZR + lane * 4;
-        if ((D.ZR & 3) == 0) {
-            if (lane * 4 < D.ZR) *reinterpret_cast<float4 *>(dst) = make_float4(dp[0], dp[1], dp[2], dp[3]);
-        } else {
+        store_dp(D, dpbuf + r * D.ZR + lane * 4, lane, dp);
+    }
+    publish_max(wmax, lane, dpmax_bits);
+}
+
+// ---- brick path, forward: LDS-staged voxel tiles ----------------------------------------------------
+// fwd_table [rows,4] = (brick id, begin, end, -) into fwd_chunks; every in-volume sample appears once,
+// under the brick that holds its base corner.  The workgroup stages the brick plus a one-voxel halo
+// (18^3 floats, zeros outside the volume) with coalesced row reads -- each voxel leaves HBM/L2 once per
+// row instead of once per tap -- then evaluates its samples with 8 LDS reads each and writes the raw
+// value v[ray, k] (16 consecutive floats per chunk).
+constexpr int kTile = kBrick + 2;
+__global__ __launch_bounds__(kBlock) void render_sample_brick_kernel(RenderDims D, View5 vox,
+                                                                      const double *__restrict__ dirs,
+                                                                      const int *__restrict__ fwd_table,
+                                                                      const int *__restrict__ fwd_chunks,
+                                                                      float *__restrict__ vbuf)
+{
+    __shared__ float tile[kTile * kTile * kTile];
+    const int img = blockIdx.y;
+    const int brick = fwd_table[blockIdx.x * 4 + 0];
+    const int begin = fwd_table[blockIdx.x * 4 + 1], end = fwd_table[blockIdx.x * 4 + 2];
+    const int nby = (D.Y + kBrick - 1) / kBrick, nbz = (D.Z + kBrick - 1) / kBrick;
+    const int ox = (brick / (nby * nbz)) * kBrick - 1, oy = ((brick / nbz) % nby) * kBrick - 1,
+              oz = (brick % nbz) * kBrick - 1;                            // tile origin (incl. halo)
+    const float *__restrict__ base = vox.p + (img / D.NC) * vox.s0 + (img % D.NC) * vox.s1;
+    for (int t = threadIdx.x; t < kTile * kTile * kTile; t += kBlock) {
+        const int lz = t % kTile, ly = (t / kTile) % kTile, lx = t / (kTile * kTile);
+        const int x = ox + lx, y = oy + ly, z = oz + lz;
+        float val = 0.f;
+        if (x >= 0 && x < D.X && y >= 0 && y < D.Y && z >= 0 && z < D.Z) val = base[x * D.sx + y * D.sy + z * D.sz];
+        tile[t] = val;
+    }
+    __syncthreads();
+    float *__restrict__ vi = vbuf + (int64_t)img * D.R * D.R * D.ZR;
+    const int lane = threadIdx.x & 63, sub = lane & 15, g4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int c0 = begin + wave * 64; c0 < end; c0 += kWavesPerBlock * 64) {
+        const int nvalid = (end - c0 < 64) ? end - c0 : 64;
+        const unsigned myword = (lane < nvalid) ? (unsigned)fwd_chunks[c0 + lane] : 0u;
+        for (int s = 0; s * 4 < nvalid; s++) {
+            const int ci = s * 4 + g4;
+            const unsigned ent = (unsigned)__shfl((int)myword, ci & 63, 64);
+            const int q = (int)(ent >> 12), k = (int)((ent >> 4) & 255u) + sub;
+            if (!(ci < nvalid && sub <= (int)(ent & 15u))) continue;
+            float gx, gy, gz;
+            sample_pos(D, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, k, gx, gy, gz);
+            Cell c;
+            locate(D, gx, gy, gz, c);
+            const float *tp = tile + ((c.x0 - ox) * kTile + (c.y0 - oy)) * kTile + (c.z0 - oz);
+            float acc = 0.f;                                              // ATen corner order, zeros outside
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-                if (lane * 4 + t < D.ZR) dst[t] = dp[t];
+            for (int i = 0; i < 8; i++)
+                acc += tp[((i & 1) ? kTile * kTile : 0) + ((i & 2) ? kTile : 0) + ((i & 4) ? 1 : 0)] * corner_w(c, i);
+            vi[(int64_t)q * D.ZR + k] = acc;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-    // one same-address global atomic costs ~10 ns: publish only when this wave would raise the maximum
-    // (the racy pre-read is safe -- the value only grows)
-    if (lane == 0 && wmax > 0.f && isfinite(wmax)) {
-        const unsigned bits = __float_as_uint(wmax);
-        if (bits > __hip_atomic_load(dpmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dpmax_bits, bits);
+}
+
+// forward scan over the raw values (samples before kin[ray] lie outside the volume: v = 0, not read)
+__global__ __launch_bounds__(kBlock) void render_scan_fwd_kernel(RenderDims D, const float *__restrict__ vbuf,
+                                                                  const int *__restrict__ kin,
+                                                                  const float *__restrict__ dw, View4 out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
+    const int rr = D.R * D.R;
+    for (int64_t r = wave0; r < rays; r += nwaves) {
+        const int q = (int)(r % rr);
+        const int k_in = kin[q];
+        const int kb = lane * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (kb + 3 >= k_in && kb < D.ZR) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(vbuf + r * D.ZR + kb);
+            v[0] = kb + 0 >= k_in ? v4.x : 0.f; v[1] = kb + 1 >= k_in ? v4.y : 0.f;
+            v[2] = kb + 2 >= k_in ? v4.z : 0.f; v[3] = kb + 3 >= k_in ? v4.w : 0.f;
+        }
+        float p[4];
+        bool pass[4];
+        clamp4(D, v, kb, p, pass);
+        double carry = 1.0;
+        const double acc = expect4(D, p, dw, kb, lane, carry);
+        const double total = wave_sum(acc) + carry;
+        if (lane == 0) {
+            const int64_t nc = r / rr;
+            out.p[(nc / D.NC) * out.s0 + (nc % D.NC) * out.s1 + (q / D.R) * out.s2 + (q % D.R) * out.s3] = (float)total;
+        }
     }
+}
+
+// backward scan: v -> dL/dp (same maths as render_bwd_dp_kernel without the sampling)
+__global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, const float *__restrict__ vbuf,
+                                                                  const int *__restrict__ kin,
+                                                                  const float *__restrict__ dw, View4 gout,
+                                                                  float *__restrict__ dpbuf,
+                                                                  unsigned *__restrict__ dpmax_bits)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
+    const int rr = D.R * D.R;
+    float wmax = 0.f;
+    for (int64_t r = wave0; r < rays; r += nwaves) {
+        const int q = (int)(r % rr);
+        const int64_t nc = r / rr;
+        const float g = gout.p[(nc / D.NC) * gout.s0 + (nc % D.NC) * gout.s1 + (q / D.R) * gout.s2 + (q % D.R) * gout.s3];
+        float dp[4] = {0.f, 0.f, 0.f, 0.f};
+        const int kb = lane * 4;
+        if (g != 0.0f) {
+            const int k_in = kin[q];
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (kb + 3 >= k_in && kb < D.ZR) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(vbuf + r * D.ZR + kb);
+                v[0] = kb + 0 >= k_in ? v4.x : 0.f; v[1] = kb + 1 >= k_in ? v4.y : 0.f;
+                v[2] = kb + 2 >= k_in ? v4.z : 0.f; v[3] = kb + 3 >= k_in ? v4.w : 0.f;
+            }
+            float p[4];
+            bool pass[4];
+            clamp4(D, v, kb, p, pass);
+            dp4(D, p, pass, dw, g, lane, dp);
+        }
+        wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
+        store_dp(D, dpbuf + r * D.ZR + kb, lane, dp);
+    }
+    publish_max(wmax, lane, dpmax_bits);
 }
 
 // ---- backward pass B: brick-owned accumulation ----------------------------------------------------
@@ -480,8 +641,25 @@ inline int grid_for_rays(int64_t rays)
 
 using namespace genre;
 
+// Tables shared by the brick kernels (formats: include/genre_hip.h).
+static int check_tables(const char *op, const RenderDims &D, const genre_tensor *table, const genre_tensor *chunks,
+                        int &rows)
+{
+    const int nb = ((D.X + kBrick - 1) / kBrick) * ((D.Y + kBrick - 1) / kBrick) * ((D.Z + kBrick - 1) / kBrick);
+    GENRE_REQUIRE(is_i32(table, 2) && table->size[0] >= nb && table->size[1] == 4 && is_contiguous(table) &&
+                      table->size[0] < (1 << 30),
+                  "%s: brick table must be a contiguous int32 [rows >= %d, 4] tensor", op, nb);
+    GENRE_REQUIRE(is_i32(chunks, 1) && is_contiguous(chunks), "%s: chunk list must be int32 [S]", op);
+    GENRE_REQUIRE((int64_t)D.R * D.R < (1 << 20) && D.ZR <= 256, "%s: brick path needs R*R < 2^20 and ZR <= 256", op);
+    GENRE_REQUIRE(D.N * D.NC <= 65535, "%s: N*NC must be <= 65535", op);
+    rows = (int)table->size[0];
+    return 1;
+}
+
 extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *dirs,
                                               const genre_tensor *depth_weight, const genre_tensor *out,
+                                              const genre_tensor *v_scratch, const genre_tensor *fwd_table,
+                                              const genre_tensor *fwd_chunks, const genre_tensor *kin,
                                               void *stream)
 {
     const char *op = "render_spherical_forward";
@@ -489,7 +667,26 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
     if (!check_render(op, vox, dirs, depth_weight, out, D)) return 0;
     const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
     if (rays == 0) return 1;
-    render_fwd_kernel<<<grid_for_rays(rays), kBlock, 0, (hipStream_t)stream>>>(
+    hipStream_t st = (hipStream_t)stream;
+    if (v_scratch && fwd_table && fwd_chunks && kin) {
+        int rows = 0;
+        if (!check_tables(op, D, fwd_table, fwd_chunks, rows)) return 0;
+        GENRE_REQUIRE((D.ZR & 3) == 0, "%s: brick path needs ZR %% 4 == 0", op);
+        GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && v_scratch->size[0] >= rays * D.ZR &&
+                          aligned16(v_scratch->data),
+                      "%s: v_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR elements", op);
+        GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R,
+                      "%s: kin must be int32 [R*R]", op);
+        render_sample_brick_kernel<<<dim3(rows, D.N * D.NC), kBlock, 0, st>>>(
+            D, view5(vox), (const double *)dirs->data, (const int *)fwd_table->data, (const int *)fwd_chunks->data,
+            (float *)v_scratch->data);
+        GENRE_LAUNCH_CHECK("render_spherical forward (bricks)");
+        render_scan_fwd_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(
+            D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data, view4(out));
+        GENRE_LAUNCH_CHECK("render_spherical forward (scan)");
+        return 1;
+    }
+    render_fwd_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(
         D, view5(vox), (const double *)dirs->data, (const float *)depth_weight->data, view4(out));
     GENRE_LAUNCH_CHECK("render_spherical forward");
     return 1;
@@ -498,7 +695,8 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
 extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
                                                const genre_tensor *depth_weight, const genre_tensor *grad_out,
                                                const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
-                                               const genre_tensor *brick_table, const genre_tensor *sample_list,
+                                               const genre_tensor *brick_table, const genre_tensor *chunk_list,
+                                               const genre_tensor *v_scratch, const genre_tensor *kin,
                                                void *stream)
 {
     const char *op = "render_spherical_backward";
@@ -510,22 +708,27 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
     const int64_t nv = numel(grad_vox);
     const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
     if (nv == 0) return 1;
-    const bool bricks = brick_table && sample_list && dp_scratch && brick_table->ndim == 2 && brick_table->size[0] > 0;
-    if (bricks) {
+    if (brick_table && chunk_list && dp_scratch) {
+        int rows = 0;
+        if (!check_tables(op, D, brick_table, chunk_list, rows)) return 0;
         const int nb = ((D.X + kBrick - 1) / kBrick) * ((D.Y + kBrick - 1) / kBrick) * ((D.Z + kBrick - 1) / kBrick);
-        GENRE_REQUIRE(is_i32(brick_table, 2) && brick_table->size[0] >= nb && brick_table->size[1] == 4 &&
-                          is_contiguous(brick_table) && brick_table->size[0] < (1 << 30),
-                      "%s: brick_table must be a contiguous int32 [rows >= %d, 4] tensor", op, nb);
-        const int rows = (int)brick_table->size[0];
-        GENRE_REQUIRE(is_i32(sample_list, 1) && is_contiguous(sample_list), "%s: sample_list must be int32 [S]", op);
         GENRE_REQUIRE(is_f32(dp_scratch, 1) && is_contiguous(dp_scratch) && dp_scratch->size[0] >= rays * D.ZR + 4 &&
                           aligned16(dp_scratch->data),
                       "%s: dp_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR + 4 elements", op);
-        GENRE_REQUIRE((int64_t)D.R * D.R < (1 << 20), "%s: R*R must be < 2^20", op);
-        GENRE_REQUIRE(D.N * D.NC <= 65535, "%s: N*NC must be <= 65535", op);
         unsigned *dpmax = (unsigned *)dp_scratch->data + rays * D.ZR;       // max|dL/dp| lives behind the samples
         if (hipMemsetAsync(dpmax, 0, 16, st) != hipSuccess) return fail("%s: hipMemsetAsync failed", op);
-        if (rays > 0) {
+        if (rays > 0 && v_scratch && kin) {          // the forward left the raw sample values: scan only
+            GENRE_REQUIRE((D.ZR & 3) == 0, "%s: brick path needs ZR %% 4 == 0", op);
+            GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && v_scratch->size[0] >= rays * D.ZR &&
+                              aligned16(v_scratch->data),
+                          "%s: v_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR elements", op);
+            GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R,
+                          "%s: kin must be int32 [R*R]", op);
+            render_scan_bwd_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(
+                D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data,
+                view4(grad_out), (float *)dp_scratch->data, dpmax);
+            GENRE_LAUNCH_CHECK("render_spherical backward (scan)");
+        } else if (rays > 0) {                       // recompute the samples from vox
             render_bwd_dp_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(
                 D, view5(vox), (const double *)dirs->data, (const float *)depth_weight->data, view4(grad_out),
                 (float *)dp_scratch->data, dpmax);
@@ -538,7 +741,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
         }
         render_bwd_brick_kernel<<<dim3(rows, D.N * D.NC), kBlock, 0, st>>>(
             D, (const double *)dirs->data, (const float *)dp_scratch->data, (const int *)brick_table->data,
-            (const int *)sample_list->data, dpmax, view5(grad_vox));
+            (const int *)chunk_list->data, dpmax, view5(grad_vox));
         GENRE_LAUNCH_CHECK("render_spherical backward (bricks)");
         return 1;
     }

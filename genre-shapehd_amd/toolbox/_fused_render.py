@@ -1,8 +1,15 @@
 """Fused render_spherical: HIP kernels instead of the reference's
 grid_sample -> clamp -> CalcStopProb -> matmul -> prod -> add chain
-(toolbox/spherical_proj.py:62-72).  Only `vox` is saved for backward; the backward recomputes
-the rays and accumulates the trilinear adjoint brick by brick in LDS (no global atomics), using
-a geometry-only sample list built once here."""
+(toolbox/spherical_proj.py:62-72).
+
+Forward : brick kernel (18^3 voxel tile staged in LDS with coalesced reads, trilinear taps read
+          from LDS) writes the raw sample values v[ray, k]; a wave-per-ray scan kernel turns them
+          into the spherical map.  v is what is saved for backward (16 MiB/image, half of what
+          the reference's autograd keeps: prob_sph + stop_prob).
+Backward: scan kernel v -> dL/dp[ray, k]; brick kernel accumulates the trilinear adjoint in
+          64-bit fixed-point LDS tiles and writes every voxel of grad_vox once (no global atomics).
+Which samples touch which brick depends only on the geometry; the lists are built once here
+with exactly the kernel's fp64/fp32 arithmetic and cached per geometry/device."""
 import numpy as np
 import torch
 from torch.autograd import Function
@@ -10,8 +17,9 @@ from torch.autograd.function import once_differentiable
 
 from .calc_prob.calc_prob._ext import _loader
 
-BRICK = 16          # must match kBrick in csrc/sph_render.hip
-SPLIT = 512         # bricks with more 16-sample chunks than this are split over several workgroups
+BRICK = 16              # must match kBrick in csrc/sph_render.hip
+SPLIT_BWD = 512         # backward rows above this many 16-sample chunks are split (atomic flush)
+SPLIT_FWD = 256         # forward rows are split freely (every sample is written exactly once)
 _TABLES = {}
 
 
@@ -19,15 +27,45 @@ def available():
     return _loader().has_symbol("genre_render_spherical_forward")
 
 
-def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT):
-    """Which samples touch which 16^3 voxel brick -- depends only on the geometry.
+def _chunk_rows(bricks, q, k, nb, split, shared_mode):
+    """sorted (brick, q, k) triples -> (table [rows,4], chunk words): runs of consecutive k of one ray
+    inside one brick cut into chunks of <= 16 samples; rows = (brick, begin, end, mode) heaviest first"""
+    n = len(bricks)
+    new_run = np.ones(n, bool)
+    new_run[1:] = (bricks[1:] != bricks[:-1]) | (q[1:] != q[:-1]) | (k[1:] != k[:-1] + 1)
+    run_start = np.maximum.accumulate(np.where(new_run, np.arange(n), 0))
+    starts = np.flatnonzero((np.arange(n) - run_start) % 16 == 0)
+    lens = np.diff(np.append(starts, n))
+    assert n == 0 or (lens.min() >= 1 and lens.max() <= 16)
+    words = ((q[starts] << 12) | (k[starts] << 4) | (lens - 1)).astype(np.uint32).view(np.int32)
+    cb = bricks[starts]
+    begin = np.searchsorted(cb, np.arange(nb), side="left")
+    end = np.searchsorted(cb, np.arange(nb), side="right")
+    rows = []
+    for b in range(nb):
+        cnt = int(end[b] - begin[b])
+        if cnt <= split:
+            rows.append((b, int(begin[b]), int(end[b]), 0))
+        else:
+            parts = -(-cnt // split)
+            size = -(-cnt // parts)
+            for s0 in range(int(begin[b]), int(end[b]), size):
+                rows.append((b, s0, min(s0 + size, int(end[b])), shared_mode))
+    rows.sort(key=lambda r: -(r[2] - r[1]))
+    return np.asarray(rows, np.int32).reshape(-1, 4), words
 
-    dirs64: float64 [R,R,3] unit directions (spherical_proj.py:43-49).  Returns numpy int32
-    (brick_table [rows,4] = (brick id, begin, end, mode), heaviest row first, mode 1 = the brick is
-    split over several rows; chunk_list [S] with entries (ray << 12) | (k0 << 4) | (len - 1) = up to
-    16 consecutive samples k0..k0+len-1 of one ray).  Sample positions and voxel coordinates are computed with exactly
-    the fp64/fp32 operation sequence of the kernel (csrc/sph_render.hip: sample_pos, locate),
-    so membership is exact."""
+
+def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT_BWD, split_fwd=SPLIT_FWD):
+    """Geometry-only tables of the brick kernels (see include/genre_hip.h for the formats).
+
+    dirs64: float64 [R,R,3] unit directions (spherical_proj.py:43-49).  Sample positions and voxel
+    coordinates are computed with exactly the fp64/fp32 operation sequence of the kernels
+    (csrc/sph_render.hip: sample_pos, locate), so membership is exact.  Returns a dict of numpy
+    int32 arrays:
+      bwd_table/bwd_chunks : every sample listed under each brick one of its 8 corners falls in
+      fwd_table/fwd_chunks : every in-volume sample listed once, under the brick of its base corner
+      kin                  : per ray, the first sample with a corner inside the volume (the inside
+                             samples of a ray are always a suffix: rays end at the centre)"""
     R = dirs64.shape[0]
     assert z_res <= 256 and R * R < (1 << 20)
     d2 = dirs64.reshape(-1, 3).astype(np.float64) * 2.0
@@ -36,8 +74,9 @@ def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT):
     alpha[-1] = 1.0
     a = 1.0 - alpha
     nbx, nby, nbz = -(-X // BRICK), -(-Y // BRICK), -(-Z // BRICK)
+    nb = nbx * nby * nbz
     one, two = np.float32(1), np.float32(2)
-    axes = []
+    axes, base = [], []
     anyin = None
     for ax, size in enumerate((X, Y, Z)):
         g = (d2[:, None, ax] * a[None, :]).astype(np.float32)                # [R*R, ZR]
@@ -48,53 +87,37 @@ def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT):
         b1 = (i0 + 1) >> 4
         v1 = (i0 + 1 <= size - 1) & ((b1 != b0) | ~v0)
         axes.append(((b0, v0), (b1, v1)))
-    keys = []
+        base.append(np.clip(i0, 0, size - 1) >> 4)
+    # inside samples form a suffix of every ray
+    kin = np.where(anyin.any(1), anyin.argmax(1), z_res).astype(np.int32)
+    assert (anyin == (np.arange(z_res)[None, :] >= kin[:, None])).all(), "inside set is not a suffix"
     sample_id = np.arange(R * R * z_res, dtype=np.int64).reshape(R * R, z_res)
+
+    def finish(keys, split_at, mode):
+        keys = np.sort(np.concatenate(keys)) if keys else np.zeros((0,), np.int64)
+        sid = keys & 0xFFFFFFFF
+        return _chunk_rows((keys >> 32).astype(np.int64), sid // z_res, sid % z_res, nb, split_at, mode)
+
+    bkeys = []
     for cx in axes[0]:
         for cy in axes[1]:
             for cz in axes[2]:
                 m = anyin & cx[1] & cy[1] & cz[1]
-                if not m.any():
-                    continue
-                brick = (cx[0][m].astype(np.int64) * nby + cy[0][m]) * nbz + cz[0][m]
-                keys.append((brick << 32) | sample_id[m])
-    keys = np.sort(np.concatenate(keys)) if keys else np.zeros((0,), np.int64)
-    bricks = (keys >> 32).astype(np.int64)
-    sid = keys & 0xFFFFFFFF
-    q, k = sid // z_res, sid % z_res
-    # runs of consecutive k of one ray inside one brick, cut into chunks of <= 16 samples
-    new_run = np.ones(len(keys), bool)
-    new_run[1:] = (bricks[1:] != bricks[:-1]) | (q[1:] != q[:-1]) | (k[1:] != k[:-1] + 1)
-    run_start = np.maximum.accumulate(np.where(new_run, np.arange(len(keys)), 0))
-    pos = np.arange(len(keys)) - run_start
-    starts = np.flatnonzero(pos % 16 == 0)
-    lens = np.diff(np.append(starts, len(keys)))
-    assert lens.min() >= 1 and lens.max() <= 16
-    sample_list = ((q[starts] << 12) | (k[starts] << 4) | (lens - 1)).astype(np.uint32).view(np.int32)
-    bricks = bricks[starts]
-    nb = nbx * nby * nbz
-    begin = np.searchsorted(bricks, np.arange(nb), side="left")
-    end = np.searchsorted(bricks, np.arange(nb), side="right")
-    rows = []
-    for b in range(nb):
-        n = int(end[b] - begin[b])
-        if n <= split:
-            rows.append((b, int(begin[b]), int(end[b]), 0))
-        else:
-            parts = -(-n // split)
-            size = -(-n // parts)
-            for s0 in range(int(begin[b]), int(end[b]), size):
-                rows.append((b, s0, min(s0 + size, int(end[b])), 1))
-    rows.sort(key=lambda r: -(r[2] - r[1]))
-    return np.asarray(rows, np.int32).reshape(-1, 4), sample_list
+                if m.any():
+                    brick = (cx[0][m].astype(np.int64) * nby + cy[0][m]) * nbz + cz[0][m]
+                    bkeys.append((brick << 32) | sample_id[m])
+    bwd_table, bwd_chunks = finish(bkeys, split, 1)
+    fbrick = (base[0][anyin].astype(np.int64) * nby + base[1][anyin]) * nbz + base[2][anyin]
+    fwd_table, fwd_chunks = finish([(fbrick << 32) | sample_id[anyin]], split_fwd, 0)
+    return dict(bwd_table=bwd_table, bwd_chunks=bwd_chunks, fwd_table=fwd_table, fwd_chunks=fwd_chunks, kin=kin)
 
 
-def _tables_for(vox, dirs64, z_res):
-    key = (tuple(vox.shape[2:]), dirs64.shape[0], z_res, str(vox.device))
+def tables_for(vox_shape, device, dirs64, z_res):
+    key = (tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device))
     t = _TABLES.get(key)
     if t is None:
-        table, samples = build_brick_tables(vox.shape[2], vox.shape[3], vox.shape[4], dirs64.cpu().numpy(), z_res)
-        t = (torch.from_numpy(table).to(vox.device), torch.from_numpy(samples).to(vox.device))
+        np_t = build_brick_tables(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), z_res)
+        t = {k: torch.from_numpy(v).to(device) for k, v in np_t.items()}
         _TABLES[key] = t
     return t
 
@@ -107,22 +130,25 @@ class RenderSphericalFused(Function):
         assert vox.dim() == 5 and vox.is_cuda and vox.dtype == torch.float32
         assert dirs64.dtype == torch.float64 and dirs64.dim() == 3 and dirs64.is_contiguous()
         lib = _loader().render_lib
-        res = dirs64.shape[0]
+        res, z_res = dirs64.shape[0], depth_weight.shape[0]
         out = torch.empty((vox.shape[0], vox.shape[1], res, res), dtype=vox.dtype, device=vox.device)
-        lib.render_spherical_forward(vox, dirs64.view(torch.float32), depth_weight, out)
-        ctx.save_for_backward(vox, dirs64, depth_weight)
+        t = tables_for(vox.shape, vox.device, dirs64, z_res)
+        rays = vox.shape[0] * vox.shape[1] * res * res
+        v = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
+        lib.render_spherical_forward(vox, dirs64.view(torch.float32), depth_weight, out,
+                                     v, t["fwd_table"], t["fwd_chunks"], t["kin"])
+        ctx.save_for_backward(vox, dirs64, depth_weight, v)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        vox, dirs64, depth_weight = ctx.saved_tensors
+        vox, dirs64, depth_weight, v = ctx.saved_tensors
         lib = _loader().render_lib
         z_res = depth_weight.shape[0]
+        t = tables_for(vox.shape, vox.device, dirs64, z_res)
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
-        table, samples = _tables_for(vox, dirs64, z_res)
-        rays = vox.shape[0] * vox.shape[1] * dirs64.shape[0] * dirs64.shape[1]
-        scratch = torch.empty((rays * z_res + 4,), dtype=torch.float32, device=vox.device)
+        scratch = torch.empty((v.numel() + 4,), dtype=torch.float32, device=vox.device)
         lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,
-                                      scratch, table, samples)
+                                      scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"])
         return grad_vox, None, None

@@ -148,36 +148,49 @@ int genre_nnd_backward(const genre_tensor *xyz1, const genre_tensor *xyz2,
 /* No native counterpart in the reference: fuses the PyTorch op sequence of
  * render_spherical.forward (spherical_proj.py:62-72: expand, permute,
  * grid_sample [0.4.1 semantics == align_corners=True, zeros padding], clamp to
- * [1e-5, 1-1e-5], CalcStopProb, matmul(depth_weight), prod(1-p), add) into one
- * kernel.  vox [N,NC,X,Y,Z] (any strides) -> out [N,NC,R,R].
+ * [1e-5, 1-1e-5], CalcStopProb, matmul(depth_weight), prod(1-p), add).
+ * vox [N,NC,X,Y,Z] (any non-negative strides) -> out [N,NC,R,R].
  *   dirs         : the float64 [R,R,3] unit-direction table of spherical_proj.py:43-49,
  *                  passed as its raw storage viewed as fp32 [R,R,6] (contiguous);
  *                  sample k of ray (i,j) sits at float((2*dirs[i,j]) * (1 - k/(ZR-1))),
  *                  bit-identical to the reference's `grid` buffer (:50-56)
- *   depth_weight : [ZR] fp32, the reference's buffer of the same name (:57) */
+ *   depth_weight : [ZR] fp32, the reference's buffer of the same name (:57)
+ * Optional geometry tables (all NULL = one wave-per-ray gather kernel):
+ *   v_scratch  : fp32 [>= N*NC*R*R*ZR], 16-byte aligned; receives the raw (un-clamped)
+ *                trilinear value of every in-volume sample, layout [ray][k]
+ *   fwd_table  : int32 [rows,4] = (brick id, begin, end, 0): rows of fwd_chunks handled by
+ *                one workgroup; brick id = (bx*nby+by)*nbz+bz over 16^3-voxel bricks
+ *   fwd_chunks : int32 [S], entry (ray i*R+j) << 12 | k0 << 4 | (len-1): samples
+ *                k0..k0+len-1 (len <= 16) of that ray; every sample with at least one
+ *                trilinear corner inside the volume appears exactly once, under the brick
+ *                of its (clamped) base corner
+ *   kin        : int32 [R*R], first such sample of each ray (they form a suffix)
+ * Reference builder of the tables: genre-shapehd_amd/toolbox/_fused_render.py. */
 int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *dirs,
                                    const genre_tensor *depth_weight, const genre_tensor *out,
+                                   const genre_tensor *v_scratch, const genre_tensor *fwd_table,
+                                   const genre_tensor *fwd_chunks, const genre_tensor *kin,
                                    void *stream);
 
 /* Adjoint of the above w.r.t. vox (what autograd derives for the reference's
  * op chain).  grad_out [N,NC,R,R] -> grad_vox [N,NC,X,Y,Z], fully written.
- * Recomputes the forward; requires ZR <= 256.  Two modes:
- *  - dp_scratch, brick_table, sample_list given: two passes without global
- *    atomics.  dp_scratch: fp32 [>= N*NC*R*R*ZR + 4], 16-byte aligned (receives
- *    dL/dp per sample and, behind them, max|dL/dp| for the fixed-point scale).  brick_table: int32 [rows,4] = (brick id, begin, end, mode),
- *    brick id = (bx*nby+by)*nbz+bz over ceil(X/16)*ceil(Y/16)*ceil(Z/16) bricks, every
- *    brick in >= 1 row, rows in the order they should be scheduled; mode 0: the row
- *    is the brick's only one, mode 1: the brick's samples are split over several rows; sample_list: int32 [S], entry
- *    (ray index i*R+j) << 12 | k0 << 4 | (len-1) = the run of samples k0..k0+len-1
- *    (len <= 16) of that ray; rows begin..end of a brick cover every sample with at
- *    least one trilinear corner inside that brick (geometry only; reference
- *    builder: genre-shapehd_amd/toolbox/_fused_render.py:build_brick_tables).
- *  - the three pointers NULL: global-atomic scatter fallback (grad_vox must be
+ * Requires ZR <= 256.  Modes:
+ *  - dp_scratch, brick_table, chunk_list given: brick-owned accumulation without
+ *    global atomics.  dp_scratch: fp32 [>= N*NC*R*R*ZR + 4], 16-byte aligned (receives
+ *    dL/dp per sample and, behind them, max|dL/dp| for the fixed-point scale).
+ *    brick_table: int32 [rows,4] = (brick id, begin, end, mode), every brick in >= 1 row;
+ *    mode 0: the row is the brick's only one, mode 1: the brick's samples are split over
+ *    several rows.  chunk_list: as fwd_chunks, but a brick's rows cover every sample with
+ *    at least one trilinear corner inside that brick (samples near faces appear in
+ *    several bricks).  If v_scratch (as written by the forward) and kin are given too,
+ *    the samples are not recomputed from vox.
+ *  - those pointers NULL: global-atomic scatter fallback (grad_vox must be
  *    contiguous, 16-byte aligned, numel % 4 == 0). */
 int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
                                     const genre_tensor *depth_weight, const genre_tensor *grad_out,
                                     const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
-                                    const genre_tensor *brick_table, const genre_tensor *sample_list,
+                                    const genre_tensor *brick_table, const genre_tensor *chunk_list,
+                                    const genre_tensor *v_scratch, const genre_tensor *kin,
                                     void *stream);
 
 #ifdef __cplusplus

@@ -19,19 +19,20 @@ def timeit(fn, iters=10, warm=2):
 res = {}
 mod = G.render_spherical(fused=True).to(dev)
 dirs = mod._dirs64.view(torch.float32)
-tabs = {}
-for split in (512, 2048, 8192, 1 << 30):
-    t, s = _fused_render.build_brick_tables(128, 128, 128, mod._dirs64.cpu().numpy(), 256, split)
-    tabs[split] = (torch.from_numpy(t).to(dev), torch.from_numpy(s).to(dev))
-    res[f"rows_split{split}"] = int(t.shape[0])
-for B in (1, 4, 8, 32):
+T = _fused_render.tables_for((1, 1, 128, 128, 128), dev, mod._dirs64, 256)
+for B in (1, 8, 32):
     d = torch.from_numpy(inputs.batch_depth(B)).to(dev)
     fl = torch.full((B, 1), 418.3, device=dev); cd = torch.full((B, 1), 2.2, device=dev)
     tdf = torch.empty((B, 1, 128, 128, 128), device=dev); cnt = torch.empty_like(tdf)
     cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt)
-    out = torch.empty((B, 1, 128, 128), device=dev); gout = torch.randn_like(out)
+    out = torch.empty((B, 1, 128, 128), device=dev); out2 = torch.empty_like(out); gout = torch.randn_like(out)
     vox = torch.clamp((1 - 128 * tdf) * 50, 1e-5, 1 - 1e-5)
-    scratch = torch.empty((B * 128 * 128 * 256 + 4,), device=dev); gvox = torch.empty_like(vox)
-    for split, (table, samples) in tabs.items():
-        res[f"B{B}_split{split}_bwd_us_per_img"] = round(timeit(lambda: lib.render_spherical_backward(vox, dirs, mod.depth_weight, gout, gvox, scratch, table, samples)) / B, 1)
+    vbuf = torch.empty((B * 128 * 128 * 256,), device=dev)
+    scratch = torch.empty((B * 128 * 128 * 256 + 4,), device=dev); gvox = torch.empty_like(vox); gvox2 = torch.empty_like(vox)
+    res[f"B{B}_fwd_gather_us_per_img"] = round(timeit(lambda: lib.render_spherical_forward(vox, dirs, mod.depth_weight, out2)) / B, 1)
+    res[f"B{B}_fwd_brick_us_per_img"] = round(timeit(lambda: lib.render_spherical_forward(vox, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"])) / B, 1)
+    res[f"B{B}_fwd_brick_vs_gather_maxabs"] = (out - out2).abs().max().item()
+    res[f"B{B}_bwd_recompute_us_per_img"] = round(timeit(lambda: lib.render_spherical_backward(vox, dirs, mod.depth_weight, gout, gvox2, scratch, T["bwd_table"], T["bwd_chunks"])) / B, 1)
+    res[f"B{B}_bwd_scan_us_per_img"] = round(timeit(lambda: lib.render_spherical_backward(vox, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"], vbuf, T["kin"])) / B, 1)
+    res[f"B{B}_bwd_scan_vs_recompute_maxrel"] = ((gvox - gvox2).abs() / (1 + gvox2.abs())).max().item()
 print(json.dumps(res, indent=1))
