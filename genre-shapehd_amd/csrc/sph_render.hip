@@ -387,35 +387,45 @@ __global__ __launch_bounds__(kBlock) void render_sample_brick_kernel(RenderDims 
     }
 }
 
-// forward scan over the raw values (samples before kin[ray] lie outside the volume: v = 0, not read)
+// raw sample values of this lane's 4 samples (0 before kin: outside the volume, never written)
+__device__ __forceinline__ void load_v4(const float *__restrict__ vray, int kb, int k_in, int ZR, float (&v)[4])
+{
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (kb + 3 >= k_in && kb < ZR) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(vray + kb);
+        v[0] = kb + 0 >= k_in ? v4.x : 0.f; v[1] = kb + 1 >= k_in ? v4.y : 0.f;
+        v[2] = kb + 2 >= k_in ? v4.z : 0.f; v[3] = kb + 3 >= k_in ? v4.w : 0.f;
+    }
+}
+
+// forward scan over the raw values.  grid = (blocks, N*NC); a wave keeps two rays in flight.
 __global__ __launch_bounds__(kBlock) void render_scan_fwd_kernel(RenderDims D, const float *__restrict__ vbuf,
                                                                   const int *__restrict__ kin,
                                                                   const float *__restrict__ dw, View4 out)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
-    const int rr = D.R * D.R;
-    for (int64_t r = wave0; r < rays; r += nwaves) {
-        const int q = (int)(r % rr);
-        const int k_in = kin[q];
-        const int kb = lane * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (kb + 3 >= k_in && kb < D.ZR) {
-            const float4 v4 = *reinterpret_cast<const float4 *>(vbuf + r * D.ZR + kb);
-            v[0] = kb + 0 >= k_in ? v4.x : 0.f; v[1] = kb + 1 >= k_in ? v4.y : 0.f;
-            v[2] = kb + 2 >= k_in ? v4.z : 0.f; v[3] = kb + 3 >= k_in ? v4.w : 0.f;
-        }
+    const int lane = threadIdx.x & 63, kb = lane * 4;
+    const int rr = D.R * D.R, img = blockIdx.y;
+    const int w0 = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = gridDim.x * kWavesPerBlock;
+    const float *__restrict__ vimg = vbuf + (int64_t)img * rr * D.ZR;
+    float *oimg = out.p + (img / D.NC) * out.s0 + (img % D.NC) * out.s1;
+    for (int q = w0; q < rr; q += 2 * nw) {
+        const int qb = q + nw;
+        const bool hasb = qb < rr;
+        float va[4], vb[4];
+        load_v4(vimg + (int64_t)q * D.ZR, kb, kin[q], D.ZR, va);
+        load_v4(vimg + (int64_t)(hasb ? qb : q) * D.ZR, kb, kin[hasb ? qb : q], D.ZR, vb);
         float p[4];
         bool pass[4];
-        clamp4(D, v, kb, p, pass);
         double carry = 1.0;
-        const double acc = expect4(D, p, dw, kb, lane, carry);
-        const double total = wave_sum(acc) + carry;
-        if (lane == 0) {
-            const int64_t nc = r / rr;
-            out.p[(nc / D.NC) * out.s0 + (nc % D.NC) * out.s1 + (q / D.R) * out.s2 + (q % D.R) * out.s3] = (float)total;
+        clamp4(D, va, kb, p, pass);
+        double total = wave_sum(expect4(D, p, dw, kb, lane, carry)) + carry;
+        if (lane == 0) oimg[(q / D.R) * out.s2 + (q % D.R) * out.s3] = (float)total;
+        if (hasb) {
+            carry = 1.0;
+            clamp4(D, vb, kb, p, pass);
+            total = wave_sum(expect4(D, p, dw, kb, lane, carry)) + carry;
+            if (lane == 0) oimg[(qb / D.R) * out.s2 + (qb % D.R) * out.s3] = (float)total;
         }
     }
 }
@@ -427,33 +437,35 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
                                                                   float *__restrict__ dpbuf,
                                                                   unsigned *__restrict__ dpmax_bits)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-    const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
-    const int rr = D.R * D.R;
+    const int lane = threadIdx.x & 63, kb = lane * 4;
+    const int rr = D.R * D.R, img = blockIdx.y;
+    const int w0 = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = gridDim.x * kWavesPerBlock;
+    const float *__restrict__ vimg = vbuf + (int64_t)img * rr * D.ZR;
+    float *__restrict__ dimg = dpbuf + (int64_t)img * rr * D.ZR;
+    const float *gimg = gout.p + (img / D.NC) * gout.s0 + (img % D.NC) * gout.s1;
     float wmax = 0.f;
-    for (int64_t r = wave0; r < rays; r += nwaves) {
-        const int q = (int)(r % rr);
-        const int64_t nc = r / rr;
-        const float g = gout.p[(nc / D.NC) * gout.s0 + (nc % D.NC) * gout.s1 + (q / D.R) * gout.s2 + (q % D.R) * gout.s3];
-        float dp[4] = {0.f, 0.f, 0.f, 0.f};
-        const int kb = lane * 4;
-        if (g != 0.0f) {
-            const int k_in = kin[q];
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (kb + 3 >= k_in && kb < D.ZR) {
-                const float4 v4 = *reinterpret_cast<const float4 *>(vbuf + r * D.ZR + kb);
-                v[0] = kb + 0 >= k_in ? v4.x : 0.f; v[1] = kb + 1 >= k_in ? v4.y : 0.f;
-                v[2] = kb + 2 >= k_in ? v4.z : 0.f; v[3] = kb + 3 >= k_in ? v4.w : 0.f;
-            }
-            float p[4];
-            bool pass[4];
-            clamp4(D, v, kb, p, pass);
-            dp4(D, p, pass, dw, g, lane, dp);
-        }
+    for (int q = w0; q < rr; q += 2 * nw) {
+        const int qb = q + nw;
+        const bool hasb = qb < rr;
+        const int q2 = hasb ? qb : q;
+        float va[4], vb[4];
+        load_v4(vimg + (int64_t)q * D.ZR, kb, kin[q], D.ZR, va);
+        load_v4(vimg + (int64_t)q2 * D.ZR, kb, kin[q2], D.ZR, vb);
+        const float ga = gimg[(q / D.R) * gout.s2 + (q % D.R) * gout.s3];
+        const float gb = gimg[(q2 / D.R) * gout.s2 + (q2 % D.R) * gout.s3];
+        float p[4], dp[4];
+        bool pass[4];
+        dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
+        if (ga != 0.0f) { clamp4(D, va, kb, p, pass); dp4(D, p, pass, dw, ga, lane, dp); }
         wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
-        store_dp(D, dpbuf + r * D.ZR + kb, lane, dp);
+        store_dp(D, dimg + (int64_t)q * D.ZR + kb, lane, dp);
+        if (hasb) {
+            dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
+            if (gb != 0.0f) { clamp4(D, vb, kb, p, pass); dp4(D, p, pass, dw, gb, lane, dp); }
+            wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
+            store_dp(D, dimg + (int64_t)qb * D.ZR + kb, lane, dp);
+        }
     }
     publish_max(wmax, lane, dpmax_bits);
 }
@@ -515,14 +527,30 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                 sample_pos(D, dx2[u], dy2[u], dz2[u], kk[u], gx, gy, gz);
                 Cell c;
                 locate(D, gx, gy, gz, c);
+                const double dps = (double)dp[u] * scale;                 // exact (power-of-two scale)
+                const int lx = c.x0 - ox, ly = c.y0 - oy, lz = c.z0 - oz;
+                unsigned long long *tp = tile + (lx * kBrick + ly) * kBrick + lz;
+                // weight (fp32 product, as ATen forms it) x dL/dp is exact in fp64; adding 1.5*2^52 rounds it
+                // to an integer held in the mantissa (|value| <= 2^44): 3 instructions instead of a cvt sequence
+#define GENRE_FIX(i) (unsigned long long)(__double_as_longlong((double)corner_w(c, i) * dps + 6755399441055744.0) - \
+                                          0x4338000000000000LL)
+                if ((unsigned)lx < (unsigned)(kBrick - 1) && (unsigned)ly < (unsigned)(kBrick - 1) &&
+                    (unsigned)lz < (unsigned)(kBrick - 1)) {             // all 8 corners inside this brick
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int lx = c.x0 + (i & 1) - ox, ly = c.y0 + ((i >> 1) & 1) - oy, lz = c.z0 + ((i >> 2) & 1) - oz;
-                    if ((unsigned)lx < (unsigned)kBrick && (unsigned)ly < (unsigned)kBrick &&
-                        (unsigned)lz < (unsigned)kBrick)
-                        atomicAdd(&tile[(lx * kBrick + ly) * kBrick + lz],
-                                  (unsigned long long)__double2ll_rn((double)(corner_w(c, i) * dp[u]) * scale));   // ds_add_u64
+                    for (int i = 0; i < 8; i++)
+                        atomicAdd(tp + ((i & 1) ? kBrick * kBrick : 0) + ((i & 2) ? kBrick : 0) + ((i & 4) ? 1 : 0),
+                                  GENRE_FIX(i));                          // ds_add_u64
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int cx = lx + (i & 1), cy = ly + ((i >> 1) & 1), cz = lz + ((i >> 2) & 1);
+                        if ((unsigned)cx < (unsigned)kBrick && (unsigned)cy < (unsigned)kBrick &&
+                            (unsigned)cz < (unsigned)kBrick)
+                            atomicAdd(tp + ((i & 1) ? kBrick * kBrick : 0) + ((i & 2) ? kBrick : 0) + ((i & 4) ? 1 : 0),
+                                      GENRE_FIX(i));
+                    }
                 }
+#undef GENRE_FIX
             }
         }
     }
@@ -636,6 +664,16 @@ inline int grid_for_rays(int64_t rays)
     return (int)(b < 1 ? 1 : b);
 }
 
+// scan kernels: grid.y = image; grid.x sized so that a wave sees about two rays (both in flight)
+inline dim3 scan_grid(const RenderDims &D)
+{
+    int bx = (D.R * D.R + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock);
+    const int imgs = D.N * D.NC;
+    const int cap = (kCUs * 8 * 4 + imgs - 1) / imgs;        // keep the launch around 8k workgroups
+    if (bx > cap) bx = cap;
+    return dim3(bx < 1 ? 1 : bx, imgs);
+}
+
 }  // namespace
 }  // namespace genre
 
@@ -681,7 +719,7 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
             D, view5(vox), (const double *)dirs->data, (const int *)fwd_table->data, (const int *)fwd_chunks->data,
             (float *)v_scratch->data);
         GENRE_LAUNCH_CHECK("render_spherical forward (bricks)");
-        render_scan_fwd_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(
+        render_scan_fwd_kernel<<<scan_grid(D), kBlock, 0, st>>>(
             D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data, view4(out));
         GENRE_LAUNCH_CHECK("render_spherical forward (scan)");
         return 1;
@@ -724,7 +762,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                           "%s: v_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR elements", op);
             GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R,
                           "%s: kin must be int32 [R*R]", op);
-            render_scan_bwd_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(
+            render_scan_bwd_kernel<<<scan_grid(D), kBlock, 0, st>>>(
                 D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data,
                 view4(grad_out), (float *)dp_scratch->data, dpmax);
             GENRE_LAUNCH_CHECK("render_spherical backward (scan)");

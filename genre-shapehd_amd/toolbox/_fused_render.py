@@ -19,7 +19,9 @@ from .calc_prob.calc_prob._ext import _loader
 
 BRICK = 16              # must match kBrick in csrc/sph_render.hip
 SPLIT_BWD = 512         # backward rows above this many 16-sample chunks are split (atomic flush)
-SPLIT_FWD = 256         # forward rows are split freely (every sample is written exactly once)
+SPLIT_FWD = 1024        # forward rows may be split freely (every sample is written exactly once) ...
+SPLIT_FWD_SMALL = 256   # ... more finely when fewer than SMALL_BATCH images have to fill 256 CUs
+SMALL_BATCH = 4
 _TABLES = {}
 
 
@@ -113,10 +115,12 @@ def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT_BWD, split_fwd=SPLIT_
 
 
 def tables_for(vox_shape, device, dirs64, z_res):
-    key = (tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device))
+    small = vox_shape[0] * vox_shape[1] < SMALL_BATCH
+    key = (tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device), small)
     t = _TABLES.get(key)
     if t is None:
-        np_t = build_brick_tables(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), z_res)
+        np_t = build_brick_tables(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), z_res,
+                                  split_fwd=SPLIT_FWD_SMALL if small else SPLIT_FWD)
         t = {k: torch.from_numpy(v).to(device) for k, v in np_t.items()}
         _TABLES[key] = t
     return t
