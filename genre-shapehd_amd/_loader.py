@@ -39,7 +39,8 @@ def _load():
         raise ImportError("libgenre_hip.so ABI %d != expected %d -- rebuild" % (lib.genre_abi_version(), ABI_VERSION))
     T, V = C.POINTER(GenreTensor), C.c_void_p
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
-                        ("genre_get_surface_mask", 5), ("genre_spherical_back_proj_forward", 4),
+                        ("genre_get_surface_mask", 5), ("genre_back_projection_forward_shifted", 5),
+                        ("genre_back_projection_backward_shifted", 8), ("genre_spherical_back_proj_forward", 4),
                         ("genre_spherical_back_proj_backward", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
@@ -113,6 +114,16 @@ class _CamBpLib:
     @staticmethod
     def back_projection_backward(depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl):
         return _call("genre_back_projection_backward", depth, fl, camdist, cnt, grad_in, grad_depth,
+                     grad_camdist, grad_fl)
+
+    @staticmethod
+    def back_projection_forward_shifted(depth, camdist, fl, voxel, cnt):
+        """extension: writes 1 - res*tdf (Camera_back_projection_layer.shift_tdf folded in)"""
+        return _call("genre_back_projection_forward_shifted", depth, camdist, fl, voxel, cnt)
+
+    @staticmethod
+    def back_projection_backward_shifted(depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl):
+        return _call("genre_back_projection_backward_shifted", depth, fl, camdist, cnt, grad_in, grad_depth,
                      grad_camdist, grad_fl)
 
     @staticmethod

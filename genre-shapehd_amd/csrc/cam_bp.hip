@@ -114,7 +114,8 @@ __global__ __launch_bounds__(kBlock) void fill2_strided_kernel(Dims D, View5 a, 
 // ---- (2) scatter --------------------------------------------------------------
 template <bool SPH>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
-                                                          View5 grid, View5 vox, View5 cnt, float empty_val)
+                                                          View5 grid, View5 vox, View5 cnt, float empty_val,
+                                                          float fill_val)
 {
     const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
@@ -129,15 +130,20 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(Dims D, View4 depth, Vi
         float *pc = cnt.p + n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4;
         float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
         const float old = unsafeAtomicAdd(pc, 1.0f);                 // :274, hardware global_atomic_add_f32
-        // negated accumulation; the first arriver also cancels the prefill (see file header)
-        unsafeAtomicAdd(pv, (old == 0.0f) ? -(dist + empty_val) : -dist);   // :273
+        // Negated accumulation (see file header).  The reference starts every sum at the prefill e = 1/res
+        // (0 on the spherical path) and subtracts it again in K2 (:304): the first point contributes
+        // t = fl(e + dist) - e (exact).  The first arriver reproduces that rounding and cancels whatever
+        // the fill pass wrote; later arrivers just add, as the reference's atomics do.
+        const float t = (dist + empty_val) - empty_val;
+        unsafeAtomicAdd(pv, (old == 0.0f) ? -(t + fill_val) : -dist);   // :273
     }
 }
 
 // ---- (3) normalise, per pixel ---------------------------------------------------
 template <bool SPH>
 __global__ __launch_bounds__(kBlock) void normalise_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
-                                                            View5 grid, View5 vox, View5 cnt)
+                                                            View5 grid, View5 vox, View5 cnt, float post_scale,
+                                                            float post_bias)
 {
     const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
@@ -152,7 +158,8 @@ __global__ __launch_bounds__(kBlock) void normalise_kernel(Dims D, View4 depth, 
         const float s = *pv;
         if (s < 0.0f) {                                               // still a raw (negated) sum
             const float k = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
-            *pv = (0.0f - s) / k;                                     // :304 (mean distance)
+            // :304 (mean distance); post = identity, or the layer's shift 1 - res*tdf folded in
+            *pv = post_bias + post_scale * ((0.0f - s) / k);
         }
     }
 }
@@ -212,7 +219,7 @@ __device__ __forceinline__ double wave_sum(double v)
 
 __global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 depth, View2 fl, View2 camdist,
                                                                View5 cnt, View5 gin, View4 gdepth,
-                                                               View2 gcam, View2 gfl)
+                                                               View2 gcam, View2 gfl, float gscale)
 {
     __shared__ double red[2][kBlock / 64];
     const int img = blockIdx.y;
@@ -237,7 +244,8 @@ __global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 dept
                 const float cos_cc = (rx * qx) + (ry * qy) + (rz * qz); // :448
                 float ptnum = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
                 if (ptnum < 1.0f) ptnum = 1.0f;
-                const float gd = gin.p[n * gin.s0 + c * gin.s1 + ix * gin.s2 + iy * gin.s3 + iz * gin.s4];
+                // gscale = 1, or -res when the incoming gradient is w.r.t. the shifted output 1 - res*tdf
+                const float gd = gin.p[n * gin.s0 + c * gin.s1 + ix * gin.s2 + iy * gin.s3 + iz * gin.s4] * gscale;
                 gd_out = -gd * cos_cc / ptnum;                          // :455
                 const float L3 = L * L * L;
                 const float gfx = ((gx - cx) / Dn) * (u_w * u_w + u_h * u_h) / L3;   // :459
@@ -361,7 +369,8 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
 
 template <bool SPH>
 int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *camdist, const genre_tensor *fl,
-                 const genre_tensor *grid, const genre_tensor *voxel, const genre_tensor *cnt, void *stream)
+                 const genre_tensor *grid, const genre_tensor *voxel, const genre_tensor *cnt, void *stream,
+                 bool shifted = false)
 {
     Dims D{};
     if (!check_image(op, depth, D)) return 0;
@@ -382,13 +391,23 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
     // camera path: prefill 1/res (cam_back_projection.py:23-24) and bias 1/max(res) (:304,:829) are the
     // same number for the cubic grids the reference builds; spherical path: prefill 0, bias 0 (:695).
     const float empty_val = SPH ? 0.0f : (float)(1.0 / (double)mx);
-    if (!launch_fill2(D, voxel, empty_val, cnt, 0.0f, st)) return 0;
+    // optional fused epilogue of Camera_back_projection_layer.shift_tdf (camera_backprojection_module.py:25-28):
+    // out = 1 - res*tdf.  The "negative == raw sum" marker of the normalise pass needs out >= 0, true for
+    // cubic grids (mean distance <= sqrt(3)/2 voxel).
+    float post_scale = 1.0f, post_bias = 0.0f, fill_val = empty_val;
+    if (shifted) {
+        GENRE_REQUIRE(D.X == D.Y && D.Y == D.Z, "%s: the fused shift needs a cubic grid", op);
+        post_scale = -(float)mx; post_bias = 1.0f;
+        fill_val = 1.0f - (float)mx * empty_val;
+    }
+    if (!launch_fill2(D, voxel, fill_val, cnt, 0.0f, st)) return 0;
     const int64_t npix = (int64_t)D.N * D.NC * D.H * D.W;
     if (npix == 0 || (int64_t)D.X * D.Y * D.Z == 0) return 1;
     const int g = grid_for(npix);
-    scatter_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), empty_val);
+    scatter_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), empty_val, fill_val);
     GENRE_LAUNCH_CHECK("projection forward");
-    normalise_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt));
+    normalise_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), post_scale,
+                                                post_bias);
     GENRE_LAUNCH_CHECK("safe divide");
     return 1;
 }
@@ -412,13 +431,11 @@ extern "C" int genre_spherical_back_proj_forward(const genre_tensor *depth, cons
     return forward_impl<true>("spherical_back_proj_forward", depth, nullptr, nullptr, grid_in, voxel, cnt, stream);
 }
 
-extern "C" int genre_back_projection_backward(const genre_tensor *depth, const genre_tensor *fl,
-                                              const genre_tensor *camdist, const genre_tensor *cnt,
-                                              const genre_tensor *grad_in, const genre_tensor *grad_depth,
-                                              const genre_tensor *grad_camdist, const genre_tensor *grad_fl,
-                                              void *stream)
+static int backward_impl(const char *op, const genre_tensor *depth, const genre_tensor *fl,
+                         const genre_tensor *camdist, const genre_tensor *cnt, const genre_tensor *grad_in,
+                         const genre_tensor *grad_depth, const genre_tensor *grad_camdist,
+                         const genre_tensor *grad_fl, void *stream, bool shifted)
 {
-    const char *op = "back_projection_backward";
     Dims D{};
     if (!check_image(op, depth, D) || !check_scalar(op, "fl", fl, D) || !check_scalar(op, "camdist", camdist, D) ||
         !check_volume(op, "cnt", cnt, D, true) || !check_volume(op, "grad_in", grad_in, D, false) ||
@@ -435,11 +452,43 @@ extern "C" int genre_back_projection_backward(const genre_tensor *depth, const g
     GENRE_REQUIRE(imgs <= 65535, "%s: N*NC must be <= 65535", op);
     int bx = ceil_div(npix, kBlock);
     if (bx > 256) bx = 256;
+    float gscale = 1.0f;
+    if (shifted) {
+        GENRE_REQUIRE(D.X == D.Y && D.Y == D.Z, "%s: the fused shift needs a cubic grid", op);
+        gscale = -(float)D.X;
+    }
     cam_backward_kernel<<<dim3(bx, imgs), kBlock, 0, st>>>(D, view4(depth), view2(fl), view2(camdist), view5(cnt),
                                                           view5(grad_in), view4(grad_depth), view2(grad_camdist),
-                                                          view2(grad_fl));
+                                                          view2(grad_fl), gscale);
     GENRE_LAUNCH_CHECK("projection backward");
     return 1;
+}
+
+extern "C" int genre_back_projection_backward(const genre_tensor *depth, const genre_tensor *fl,
+                                              const genre_tensor *camdist, const genre_tensor *cnt,
+                                              const genre_tensor *grad_in, const genre_tensor *grad_depth,
+                                              const genre_tensor *grad_camdist, const genre_tensor *grad_fl,
+                                              void *stream)
+{
+    return backward_impl("back_projection_backward", depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist,
+                         grad_fl, stream, false);
+}
+
+extern "C" int genre_back_projection_forward_shifted(const genre_tensor *depth, const genre_tensor *camdist,
+                                                     const genre_tensor *fl, const genre_tensor *voxel,
+                                                     const genre_tensor *cnt, void *stream)
+{
+    return forward_impl<false>("back_projection_forward_shifted", depth, camdist, fl, nullptr, voxel, cnt, stream, true);
+}
+
+extern "C" int genre_back_projection_backward_shifted(const genre_tensor *depth, const genre_tensor *fl,
+                                                      const genre_tensor *camdist, const genre_tensor *cnt,
+                                                      const genre_tensor *grad_in, const genre_tensor *grad_depth,
+                                                      const genre_tensor *grad_camdist,
+                                                      const genre_tensor *grad_fl, void *stream)
+{
+    return backward_impl("back_projection_backward_shifted", depth, fl, camdist, cnt, grad_in, grad_depth,
+                         grad_camdist, grad_fl, stream, true);
 }
 
 extern "C" int genre_get_surface_mask(const genre_tensor *depth, const genre_tensor *camdist,

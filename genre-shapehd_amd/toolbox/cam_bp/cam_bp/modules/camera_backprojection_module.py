@@ -6,6 +6,7 @@ import torch
 from torch import nn
 
 from ..functions import CameraBackProjection
+from ..functions.cam_back_projection import ShiftedCameraBackProjection
 
 
 class Camera_back_projection_layer(nn.Module):
@@ -31,8 +32,9 @@ class Camera_back_projection_layer(nn.Module):
             fl = self._const(fl, n, depth_t.device)
         if type(cam_dist) == float:
             cam_dist = self._const(cam_dist, n, depth_t.device)
-        df = CameraBackProjection.apply(depth_t, fl, cam_dist, self.res)
-        return self.shift_tdf(df) if shift else df
+        if shift:       # 1 - res*tdf evaluated inside the native op (same values as shift_tdf(df))
+            return ShiftedCameraBackProjection.apply(depth_t, fl, cam_dist, self.res)
+        return CameraBackProjection.apply(depth_t, fl, cam_dist, self.res)
 
     @staticmethod
     def shift_tdf(input_tdf, res=128):

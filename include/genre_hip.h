@@ -82,6 +82,19 @@ int genre_back_projection_backward(const genre_tensor *depth, const genre_tensor
                                    const genre_tensor *grad_camdist, const genre_tensor *grad_fl,
                                    void *stream);
 
+/* Extensions: the same two ops with Camera_back_projection_layer.shift_tdf
+ * (camera_backprojection_module.py:25-28) folded in: forward writes
+ * voxel = 1 - res*tdf (res = X = Y = Z; 0 where empty), backward takes the gradient
+ * w.r.t. that shifted output.  Saves one full-volume elementwise pass each way. */
+int genre_back_projection_forward_shifted(const genre_tensor *depth, const genre_tensor *camdist,
+                                          const genre_tensor *fl, const genre_tensor *voxel,
+                                          const genre_tensor *cnt, void *stream);
+int genre_back_projection_backward_shifted(const genre_tensor *depth, const genre_tensor *fl,
+                                           const genre_tensor *camdist, const genre_tensor *cnt,
+                                           const genre_tensor *grad_in, const genre_tensor *grad_depth,
+                                           const genre_tensor *grad_camdist, const genre_tensor *grad_fl,
+                                           void *stream);
+
 /* Replaces get_surface_mask (back_projection.c:30-38 -> :840-891, kernel
  * :310-358).  mask [N,NC,X,Y,Z] := 1, except 0 for empty voxels (cnt <= 1e-5)
  * that lie behind the observed surface. */

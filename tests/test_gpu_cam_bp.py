@@ -143,12 +143,25 @@ def test_surface_mask(name, genre, oracle, dev):
 
 
 def test_layer_shift(genre, oracle, dev):
-    d = inputs.sphere_depth(noise_seed=2)
-    fl, cd = inputs.cam_params(1)
-    tdf_o, _ = oracle.back_projection_forward(d, cd, fl)
+    """the layer folds shift_tdf (1 - 128*tdf) into the native op; it must equal the unfused
+    composition bit for bit where the sum order is unique, and its gradient must be -128 x the plain one"""
+    d = inputs.batch_depth(2)
+    fl, cd = inputs.cam_params(2)
+    tdf_o, cnt_o = oracle.back_projection_forward(d, cd, fl)
     layer = genre.Camera_back_projection_layer().to(dev)
-    out = layer(t(d, dev))                                       # fl=418.3, cam_dist=2.2, shift
-    assert np.abs(out.cpu().numpy() - (1 - 128 * tdf_o)).max() <= 128 * TOL
+    dt = t(d, dev).requires_grad_(True)
+    out = layer(dt)                                              # fl=418.3, cam_dist=2.2, shift
+    ref = (1 - np.float32(128) * tdf_o).astype(np.float32)
+    assert np.abs(out.detach().cpu().numpy() - ref).max() <= 128 * TOL
+    uniq = cnt_o <= 1
+    assert np.array_equal(out.detach().cpu().numpy()[uniq], ref[uniq])
+    assert np.array_equal(layer.shift_tdf(torch.from_numpy(tdf_o)).numpy(), ref)
+    g = np.random.default_rng(4).standard_normal(tdf_o.shape).astype(np.float32)
+    out.backward(t(g, dev))
+    for i in range(2):
+        gd_o, _, _ = oracle.back_projection_backward(d[i:i + 1], fl[i:i + 1], cd[i:i + 1], cnt_o[i:i + 1],
+                                                     (np.float32(-128) * g[i:i + 1]).astype(np.float32))
+        assert np.abs(dt.grad[i:i + 1].cpu().numpy() - gd_o).max() <= 128 * TOL
     out2 = layer(t(d, dev), shift=False)
     assert np.abs(out2.cpu().numpy() - tdf_o).max() <= TOL
 
