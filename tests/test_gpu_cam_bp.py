@@ -46,6 +46,70 @@ def test_camera_forward(name, genre, oracle, dev):
     assert np.array_equal(tdf.cpu().numpy()[cnt_o == 0], tdf_o[cnt_o == 0])
 
 
+def _odd_cases():
+    rng = np.random.default_rng(17)
+    out = []
+    for (H, res, flv, cdv) in ((64, 32, 100.0, 2.0), (96, 48, 150.0, 1.5), (100, 50, 200.0, 3.0), (37, 20, 60.0, 0.9)):
+        d = rng.uniform(cdv - 0.6, cdv + 0.6, (2, 1, H, H)).astype(np.float32)
+        d[rng.random(d.shape) < 0.2] = 0.0
+        d[rng.random(d.shape) < 0.05] = -1.0
+        out.append((d, np.full((2, 1), flv, np.float32), np.full((2, 1), cdv, np.float32), res))
+    rng = np.random.default_rng(23)                     # camera INSIDE the grid: zero-depth pixels land in a voxel
+    d = rng.uniform(0.0, 0.8, (1, 1, 32, 32)).astype(np.float32)
+    d[rng.random(d.shape) < 0.3] = 0.0
+    out.append((d, np.full((1, 1), 40.0, np.float32), np.full((1, 1), 0.3, np.float32), 16))
+    return out
+
+
+def check_forward_cases(oracle, dev, exact):
+    """shared by the in-process (scatter) test and the GENRE_CAMBP_GATHER=1 subprocess: cnt exact always;
+    tdf bit-exact on every voxel when `exact`, else <= 1e-5 and bit-exact where a voxel has one point"""
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    fl1, cd1 = inputs.cam_params(1)
+    cases = [(d, fl1, cd1, 128) for d in depth_cases().values()] + _odd_cases()
+    for d, fl, cd, res in cases:
+        tdf_o, cnt_o = oracle.back_projection_forward(d, cd, fl, res)
+        runs = []
+        for _ in range(2):
+            tdf = torch.empty((d.shape[0], 1, res, res, res), device=dev)
+            cnt = torch.empty_like(tdf)
+            cam_bp_lib.back_projection_forward(t(d, dev), t(cd, dev), t(fl, dev), tdf, cnt)
+            runs.append((tdf.cpu().numpy(), cnt.cpu().numpy()))
+        tdf, cnt = runs[0]
+        assert np.array_equal(cnt, cnt_o), (d.shape, res)
+        if exact:
+            assert np.array_equal(tdf, tdf_o), (d.shape, res)
+            assert np.array_equal(tdf, runs[1][0]) and np.array_equal(cnt, runs[1][1])     # deterministic
+        else:
+            assert np.abs(tdf - tdf_o).max() <= TOL
+            assert np.array_equal(tdf[cnt_o <= 1], tdf_o[cnt_o <= 1])
+
+
+def test_camera_forward_odd_sizes_and_cameras(genre, oracle, dev):
+    """non-power-of-two grids / images, several cameras, camera inside the grid (default scatter path)"""
+    check_forward_cases(oracle, dev, exact=False)
+
+
+def test_camera_forward_gather_bit_exact_subprocess(dev):
+    """GENRE_CAMBP_GATHER=1: the single-launch gather kernel sums a voxel's points in the reference's serial
+    pixel order -- tdf must equal the CPU oracle BIT FOR BIT on every voxel and repeat exactly"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import torch\n"
+        "from oracle.oracle import Oracle\n"
+        "import genre_shapehd_amd\n"
+        "import test_gpu_cam_bp as T\n"
+        "T.check_forward_cases(Oracle(), torch.device('cuda:0'), exact=True)\n"
+        "print('ok')\n" % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, GENRE_CAMBP_GATHER="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
 def test_camera_forward_is_idempotent_on_dirty_outputs(genre, oracle, dev):
     """outputs are fully defined by the call (no dependence on what the buffers held)"""
     from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
@@ -106,8 +170,9 @@ def test_camera_backward(name, genre, oracle, dev):
     # per-pixel terms are bit-identical; only the summation differs.  The reference adds ~19k fp32
     # terms serially (its own rounding noise ~1e-5 relative); we reduce in fp64.  Check against the
     # fp64-accumulated oracle tightly and against the fp32 serial oracle at its own noise level.
-    assert abs(flt.grad.item() - gf_d.item()) <= 1e-6 * max(1.0, abs(gf_d.item()))
-    assert abs(cdt.grad.item() - gc_d.item()) <= 1e-6 * max(1.0, abs(gc_d.item()))
+    # (<= 256 per-block fp64 partial sums are combined with fp32 atomics: ~1e-6 relative, order-dependent)
+    assert abs(flt.grad.item() - gf_d.item()) <= 5e-6 * max(1.0, abs(gf_d.item()))
+    assert abs(cdt.grad.item() - gc_d.item()) <= 5e-6 * max(1.0, abs(gc_d.item()))
     assert abs(flt.grad.item() - gf_o.item()) <= 1e-4 * max(1.0, abs(gf_o.item()))
     assert abs(cdt.grad.item() - gc_o.item()) <= 1e-4 * max(1.0, abs(gc_o.item()))
 
@@ -127,8 +192,8 @@ def test_camera_backward_batch(genre, oracle, dev):
         gd_o, gc_o, gf_o, gc_d, gf_d = oracle.back_projection_backward(
             d[i:i + 1], fl[i:i + 1], cd[i:i + 1], cnt_o[i:i + 1], g[i:i + 1], with_double=True)
         assert np.abs(dt.grad[i:i + 1].cpu().numpy() - gd_o).max() <= TOL
-        assert abs(flt.grad[i].item() - gf_d.item()) <= 1e-6 * max(1.0, abs(gf_d.item()))
-        assert abs(cdt.grad[i].item() - gc_d.item()) <= 1e-6 * max(1.0, abs(gc_d.item()))
+        assert abs(flt.grad[i].item() - gf_d.item()) <= 5e-6 * max(1.0, abs(gf_d.item()))
+        assert abs(cdt.grad[i].item() - gc_d.item()) <= 5e-6 * max(1.0, abs(gc_d.item()))
 
 
 @pytest.mark.parametrize("name", ["sphere", "sphere_noise", "random_negbg"])
