@@ -5,10 +5,10 @@
 // CPU path my_lib.c:6-118.  The reference launches a fixed <<<(32,16),512>>>
 // grid twice on the DEFAULT stream; at batch 1 only 4 of its 512 blocks work.
 //
-// Here ONE launch covers both directions.  A workgroup owns 64 queries (one per
+// Here ONE launch covers both directions.  A workgroup owns 128 queries (two per
 // lane) and its 16 waves each scan a different slice of the target cloud, so a
-// 2048 x 2048 problem already puts one wave on every SIMD of 64 CUs and a
-// batch fills the chip.  Target coordinates are wave-uniform, so they are read
+// 2048 x 2048 problem already puts a wave on every SIMD of 32 CUs and a batch
+// fills the chip.  Target coordinates are wave-uniform, so they are read
 // through the scalar cache (s_load) straight into SGPR operands of the VALU
 // ops -- no LDS staging, no broadcast reads.  The 16 partial minima are merged
 // through LDS in slice order with a strict '<', which is exactly the
@@ -34,14 +34,22 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float tx, 
     return x * x + y * y + z * z;                          // :18
 }
 
+// Q queries per lane (register blocking: one set of scalar target loads feeds Q distance pipelines).
+// Minimum tracking is done per CHUNK of 4 targets: m = min(d0..d3) (2 instructions) and one strict-less
+// update of (best, chunk) instead of four compare/select pairs; the index inside the winning chunk is
+// resolved once at the end as the first target whose distance equals the minimum.  Same answer as the
+// reference's "if (d < best)" per target: the earliest chunk that attains the minimum wins, and inside it
+// the earliest target.  (v_min_f32 ignores a NaN operand, like the always-false compare does.)
+constexpr int kQ = 2;
+
 __global__ __launch_bounds__(kNndBlock) void nnd_forward_kernel(int n, int m, int qblocks1,
                                                                  const float *__restrict__ xyz1,
                                                                  const float *__restrict__ xyz2,
                                                                  float *__restrict__ dist1, int *__restrict__ idx1,
                                                                  float *__restrict__ dist2, int *__restrict__ idx2)
 {
-    __shared__ float s_d[kSlices][64];
-    __shared__ int s_i[kSlices][64];
+    __shared__ float s_d[kSlices][64 * kQ];
+    __shared__ int s_i[kSlices][64 * kQ];
 
     const int b = blockIdx.y;
     const bool dir2 = (int)blockIdx.x >= qblocks1;
@@ -54,54 +62,88 @@ __global__ __launch_bounds__(kNndBlock) void nnd_forward_kernel(int n, int m, in
 
     const int lane = threadIdx.x & 63;
     const int slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = qb * 64 + lane;
-    const bool valid = j < nq;
-
     const int per = (nt + kSlices - 1) / kSlices;
     const int k0 = slice * per;
     int k1 = k0 + per;
     if (k1 > nt) k1 = nt;
 
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (valid) { qx = Q[j * 3 + 0]; qy = Q[j * 3 + 1]; qz = Q[j * 3 + 2]; }
-
-    float best = 0.0f;
-    int besti = 0;
+    float qx[kQ], qy[kQ], qz[kQ], best[kQ];
+    int bchunk[kQ];                                          // first target index of the best chunk
+#pragma unroll
+    for (int u = 0; u < kQ; u++) {
+        const int j = qb * 64 * kQ + u * 64 + lane;
+        qx[u] = qy[u] = qz[u] = 0.f;
+        if (j < nq) { qx[u] = Q[j * 3 + 0]; qy[u] = Q[j * 3 + 1]; qz[u] = Q[j * 3 + 2]; }
+        best[u] = 0.0f; bchunk[u] = 0;
+    }
     if (k0 < k1) {
         const float *__restrict__ t = T + (int64_t)k0 * 3;
-        best = sqdist(qx, qy, qz, t[0], t[1], t[2]);       // "k==0 ||" of my_lib.c:20
-        besti = k0;
-        int k = k0 + 1;
-        const float *__restrict__ tp = t + 3;
-        for (; k + 4 <= k1; k += 4, tp += 12) {
-            const float d0 = sqdist(qx, qy, qz, tp[0], tp[1], tp[2]);
-            const float d1 = sqdist(qx, qy, qz, tp[3], tp[4], tp[5]);
-            const float d2 = sqdist(qx, qy, qz, tp[6], tp[7], tp[8]);
-            const float d3 = sqdist(qx, qy, qz, tp[9], tp[10], tp[11]);
-            if (d0 < best) { best = d0; besti = k; }
-            if (d1 < best) { best = d1; besti = k + 1; }
-            if (d2 < best) { best = d2; besti = k + 2; }
-            if (d3 < best) { best = d3; besti = k + 3; }
-        }
-        for (; k < k1; k++, tp += 3) {
-            const float d = sqdist(qx, qy, qz, tp[0], tp[1], tp[2]);
-            if (d < best) { best = d; besti = k; }
-        }
-    }
-    s_d[slice][lane] = best;
-    s_i[slice][lane] = besti;
-    __syncthreads();
-    if (slice == 0 && valid) {
-        // slice 0 is never empty when nt > 0; nt == 0 leaves (0, 0) like my_lib.c:12-13
+        // the first chunk initialises ("k==0 ||" of my_lib.c:20); it may be shorter than 4
+        const int first_len = (k1 - k0 < 4) ? k1 - k0 : 4;
 #pragma unroll
-        for (int s = 1; s < kSlices; s++) {
-            if (s * per < nt) {
-                const float d = s_d[s][lane];
-                if (d < best) { best = d; besti = s_i[s][lane]; }
+        for (int u = 0; u < kQ; u++) {
+            float mch = sqdist(qx[u], qy[u], qz[u], t[0], t[1], t[2]);
+            for (int e = 1; e < first_len; e++) mch = fminf(mch, sqdist(qx[u], qy[u], qz[u], t[e * 3], t[e * 3 + 1], t[e * 3 + 2]));
+            best[u] = mch; bchunk[u] = k0;
+        }
+        int k = k0 + first_len;
+        const float *__restrict__ tp = t + first_len * 3;
+        for (; k + 4 <= k1; k += 4, tp += 12) {
+            const float t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3], t4 = tp[4], t5 = tp[5];
+            const float t6 = tp[6], t7 = tp[7], t8 = tp[8], t9 = tp[9], t10 = tp[10], t11 = tp[11];
+#pragma unroll
+            for (int u = 0; u < kQ; u++) {
+                const float d0 = sqdist(qx[u], qy[u], qz[u], t0, t1, t2);
+                const float d1 = sqdist(qx[u], qy[u], qz[u], t3, t4, t5);
+                const float d2 = sqdist(qx[u], qy[u], qz[u], t6, t7, t8);
+                const float d3 = sqdist(qx[u], qy[u], qz[u], t9, t10, t11);
+                const float mch = fminf(fminf(d0, d1), fminf(d2, d3));
+                if (mch < best[u]) { best[u] = mch; bchunk[u] = k; }
             }
         }
-        dout[j] = best;
-        iout[j] = besti;
+        for (; k < k1; k++, tp += 3) {                       // tail: chunks of one
+#pragma unroll
+            for (int u = 0; u < kQ; u++) {
+                const float d = sqdist(qx[u], qy[u], qz[u], tp[0], tp[1], tp[2]);
+                if (d < best[u]) { best[u] = d; bchunk[u] = k; }
+            }
+        }
+        // resolve the index inside the winning chunk: first target (<= 4 candidates) with d == best
+#pragma unroll
+        for (int u = 0; u < kQ; u++) {
+            const int c0 = bchunk[u];
+            int found = c0;
+            bool done = false;
+            for (int e = 0; e < 4; e++) {
+                const int kk = c0 + e;
+                if (kk < k1 && !done) {
+                    const float d = sqdist(qx[u], qy[u], qz[u], T[(int64_t)kk * 3], T[(int64_t)kk * 3 + 1], T[(int64_t)kk * 3 + 2]);
+                    if (d == best[u]) { found = kk; done = true; }
+                }
+            }
+            bchunk[u] = found;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kQ; u++) { s_d[slice][u * 64 + lane] = best[u]; s_i[slice][u * 64 + lane] = bchunk[u]; }
+    __syncthreads();
+    // merge the slices in order with a strict '<' (first minimum wins); kQ*64 queries by the first kQ waves
+    if (slice < kQ) {
+        const int u = slice;
+        const int j = qb * 64 * kQ + u * 64 + lane;
+        if (j < nq) {
+            float bd = s_d[0][u * 64 + lane];
+            int bi = s_i[0][u * 64 + lane];                  // slice 0 is never empty when nt > 0;
+#pragma unroll                                               // nt == 0 leaves (0, 0) like my_lib.c:12-13
+            for (int sl = 1; sl < kSlices; sl++) {
+                if (sl * per < nt) {
+                    const float d = s_d[sl][u * 64 + lane];
+                    if (d < bd) { bd = d; bi = s_i[sl][u * 64 + lane]; }
+                }
+            }
+            dout[j] = bd;
+            iout[j] = bi;
+        }
     }
 }
 
@@ -193,7 +235,7 @@ extern "C" int genre_nnd_forward(const genre_tensor *xyz1, const genre_tensor *x
         !check_per_point(op, "idx1", idx1, true, B, n) || !check_per_point(op, "idx2", idx2, true, B, m))
         return 0;
     GENRE_REQUIRE(B <= 65535, "%s: batch must be <= 65535", op);
-    const int qb1 = ceil_div(n, 64), qb2 = ceil_div(m, 64);
+    const int qb1 = ceil_div(n, 64 * kQ), qb2 = ceil_div(m, 64 * kQ);
     if (B == 0 || qb1 + qb2 == 0) return 1;
     nnd_forward_kernel<<<dim3(qb1 + qb2, (unsigned)B), kNndBlock, 0, (hipStream_t)stream>>>(
         (int)n, (int)m, qb1, (const float *)xyz1->data, (const float *)xyz2->data, (float *)dist1->data,
