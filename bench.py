@@ -62,7 +62,7 @@ class HotPath(torch.nn.Module):
 
     def forward(self, depth):
         proj = self.cam(depth)                                        # fl=418.3, cam_dist=2.2, 1-128*tdf
-        sph = self.render(torch.clamp(proj * 50, 1e-5, 1 - 1e-5))
+        sph = self.render(proj, pre_scale=50.0)                       # == render(clamp(proj*50, 1e-5, 1-1e-5)), :124
         return self.G.sph_pad(sph, 16)
 
 
@@ -114,12 +114,13 @@ def kernel_table(G, dev, B):
         T = _fused_render.tables_for(vox.shape, dev, mod._dirs64, mod.z_res)
         vbuf = torch.empty((B * 128 * 128 * mod.z_res,), device=dev)
         scratch = torch.empty((vbuf.numel() + 4,), device=dev)
+        proj = 1 - 128 * tdf
         t = event_time_us(lambda: render_lib.render_spherical_forward(
-            vox, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"]), iters, 5)
+            proj, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0), iters, 5)
         rows["render_fwd_fused"] = dict(us=t, bytes=B * BYTES_RENDER_FUSED,
                                         kernels="render_sample_brick_kernel+render_scan_fwd_kernel")
         t = event_time_us(lambda: render_lib.render_spherical_backward(
-            vox, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"], vbuf, T["kin"]),
+            proj, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"], vbuf, T["kin"], 50.0),
             iters, 5)
         rows["render_bwd_fused"] = dict(us=t, bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
                                         kernels="render_scan_bwd_kernel+render_bwd_brick_kernel")

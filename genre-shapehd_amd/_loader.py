@@ -38,6 +38,7 @@ def _load():
     if lib.genre_abi_version() != ABI_VERSION:
         raise ImportError("libgenre_hip.so ABI %d != expected %d -- rebuild" % (lib.genre_abi_version(), ABI_VERSION))
     T, V = C.POINTER(GenreTensor), C.c_void_p
+    scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float]}
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
                         ("genre_get_surface_mask", 5), ("genre_back_projection_forward_shifted", 5),
                         ("genre_back_projection_backward_shifted", 8), ("genre_spherical_back_proj_forward", 4),
@@ -48,7 +49,7 @@ def _load():
         fn = getattr(lib, name, None)
         if fn is None:
             continue
-        fn.argtypes = [T] * nargs + [V]
+        fn.argtypes = [T] * nargs + scalars.get(name, []) + [V]
         fn.restype = C.c_int
     return lib
 
@@ -80,7 +81,7 @@ def _desc(t, what):
     return d
 
 
-def _call(name, *tensors):
+def _call(name, *tensors, scalars=()):
     """Enqueue `name` on torch's current stream of the tensors' device; raise on failure
     (the reference raised via THError("aborting"), back_projection.c:13-15)."""
     dev = tensors[0].device
@@ -94,7 +95,7 @@ def _call(name, *tensors):
         descs.append(_desc(t, "%s arg %d" % (name, k)))
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        ok = getattr(_lib, name)(*[None if d is None else C.byref(d) for d in descs], C.c_void_p(stream))
+        ok = getattr(_lib, name)(*[None if d is None else C.byref(d) for d in descs], *scalars, C.c_void_p(stream))
     if ok != 1:
         raise RuntimeError("%s failed: %s" % (name, _lib.genre_last_error().decode()))
     return 1
@@ -161,19 +162,20 @@ class _RenderLib:
 
     @staticmethod
     def render_spherical_forward(vox, dirs64_as_f32, depth_weight, out,
-                                 v_scratch=None, fwd_table=None, fwd_chunks=None, kin=None):
+                                 v_scratch=None, fwd_table=None, fwd_chunks=None, kin=None, pre_scale=0.0):
         """with the four optional tensors: LDS-staged brick sampling + scan (v_scratch receives the raw
         sample values); without: one wave-per-ray gather kernel"""
         return _call("genre_render_spherical_forward", vox, dirs64_as_f32, depth_weight, out,
-                     v_scratch, fwd_table, fwd_chunks, kin)
+                     v_scratch, fwd_table, fwd_chunks, kin, scalars=(C.c_float(pre_scale),))
 
     @staticmethod
     def render_spherical_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                                  dp_scratch=None, brick_table=None, chunk_list=None, v_scratch=None, kin=None):
+                                  dp_scratch=None, brick_table=None, chunk_list=None, v_scratch=None, kin=None,
+                                  pre_scale=0.0):
         """dp_scratch/brick_table/chunk_list given: brick-owned backward (no global atomics), re-using the
         forward's v_scratch when it is passed too; without: global-atomic scatter fallback"""
         return _call("genre_render_spherical_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                     dp_scratch, brick_table, chunk_list, v_scratch, kin)
+                     dp_scratch, brick_table, chunk_list, v_scratch, kin, scalars=(C.c_float(pre_scale),))
 
 
 class _MyLib:

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void normalise_kernel(Dims D, View4 depth, 
 // projects to a ~2x2 pixel window), re-evaluates the reference's per-pixel arithmetic for them and keeps
 // those that land in itself.  Exactly the same set of points per voxel as the scatter (every candidate
 // is checked with the bit-identical index maths), summed in row-major pixel order -- the order of the
-// reference's serial index loop -- so tdf is DETERMINISTIC and bit-identical to the CPU oracle, and
+// reference's serial index loop -- so tdf is DETERMINISTIC and bit-identical to a serial CPU evaluation of the reference, and
 // every output element is written exactly once with no atomics, no prefill pass and no second launch.
 // A workgroup owns an 8x8x32 voxel brick; one cooperative min/max scan of the depth pixels under the
 // brick's footprint rejects the ~90 % of bricks that no point can reach, which then cost only their

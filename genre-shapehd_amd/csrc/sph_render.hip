@@ -50,7 +50,8 @@ struct RenderDims {
     int sx, sy, sz;                              // element strides of one image's volume (fit in int)
     double step;                                 // 1/(ZR-1)
     float lo, hi;                                // clamp bounds of spherical_proj.py:66
-};
+    float pre_scale;                             // != 0: the volume is clamp(vox * pre_scale, lo, hi), formed on the
+};                                               //       fly (the caller's `clamp(proj * 50, 1e-5, 1 - 1e-5)` folded in)
 
 // sample k of the ray with doubled direction 2*dir (fp64): spherical_proj.py:50-56
 __device__ __forceinline__ void sample_pos(const RenderDims &D, double dx2, double dy2, double dz2, int k,
@@ -358,7 +359,10 @@ __global__ __launch_bounds__(kBlock) void render_sample_brick_kernel(RenderDims 
         const int lz = t % kTile, ly = (t / kTile) % kTile, lx = t / (kTile * kTile);
         const int x = ox + lx, y = oy + ly, z = oz + lz;
         float val = 0.f;
-        if (x >= 0 && x < D.X && y >= 0 && y < D.Y && z >= 0 && z < D.Z) val = base[x * D.sx + y * D.sy + z * D.sz];
+        if (x >= 0 && x < D.X && y >= 0 && y < D.Y && z >= 0 && z < D.Z) {
+            val = base[x * D.sx + y * D.sy + z * D.sz];
+            if (D.pre_scale != 0.0f) val = fminf(fmaxf(val * D.pre_scale, D.lo), D.hi);   // depth_pred_with_sph_inpaint.py:124
+        }
         tile[t] = val;
     }
     __syncthreads();
@@ -481,7 +485,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                                                                    const float *__restrict__ dpbuf,
                                                                    const int *__restrict__ brick_table,
                                                                    const int *__restrict__ chunk_list,
-                                                                   const unsigned *__restrict__ dpmax_bits, View5 gvox)
+                                                                   const unsigned *__restrict__ dpmax_bits, View5 vox,
+                                                                   View5 gvox)
 {
     __shared__ unsigned long long tile[kBrick * kBrick * kBrick];
     // fixed-point scale 2^(44-e), 2^e >= max|dL/dp| (see file header); max == 0 -> everything is 0
@@ -557,12 +562,17 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
     __syncthreads();
     const int n = img / D.NC, cc = img % D.NC;
     float *gbase = gvox.p + n * gvox.s0 + cc * gvox.s1;
+    const float *vbase = vox.p + n * vox.s0 + cc * vox.s1;
     for (int t = threadIdx.x; t < kBrick * kBrick * kBrick; t += kBlock) {
         const int lz = t % kBrick, ly = (t / kBrick) % kBrick, lx = t / (kBrick * kBrick);
         const int x = ox + lx, y = oy + ly, z = oz + lz;
         if (x < D.X && y < D.Y && z < D.Z) {
             float *dst = gbase + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
-            const float val = (float)((double)(long long)tile[t] * inv_scale);
+            float val = (float)((double)(long long)tile[t] * inv_scale);
+            if (D.pre_scale != 0.0f) {                       // adjoint of clamp(x * pre_scale, lo, hi)
+                const float tv = vbase[x * D.sx + y * D.sy + z * D.sz] * D.pre_scale;
+                val = (tv >= D.lo && tv <= D.hi) ? val * D.pre_scale : 0.0f;
+            }
             if (!shared) *dst = val;
             else if (tile[t] != 0ull) unsafeAtomicAdd(dst, val);
         }
@@ -698,11 +708,14 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
                                               const genre_tensor *depth_weight, const genre_tensor *out,
                                               const genre_tensor *v_scratch, const genre_tensor *fwd_table,
                                               const genre_tensor *fwd_chunks, const genre_tensor *kin,
-                                              void *stream)
+                                              float pre_scale, void *stream)
 {
     const char *op = "render_spherical_forward";
     RenderDims D{};
     if (!check_render(op, vox, dirs, depth_weight, out, D)) return 0;
+    D.pre_scale = pre_scale;
+    GENRE_REQUIRE(pre_scale == 0.0f || (v_scratch && fwd_table && fwd_chunks && kin),
+                  "%s: pre_scale needs the brick path (pass the tables)", op);
     const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
     if (rays == 0) return 1;
     hipStream_t st = (hipStream_t)stream;
@@ -735,11 +748,14 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                                                const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
                                                const genre_tensor *brick_table, const genre_tensor *chunk_list,
                                                const genre_tensor *v_scratch, const genre_tensor *kin,
-                                               void *stream)
+                                               float pre_scale, void *stream)
 {
     const char *op = "render_spherical_backward";
     RenderDims D{};
     if (!check_render(op, vox, dirs, depth_weight, grad_out, D)) return 0;
+    D.pre_scale = pre_scale;
+    GENRE_REQUIRE(pre_scale == 0.0f || (brick_table && chunk_list && dp_scratch && v_scratch && kin),
+                  "%s: pre_scale needs the brick path with the forward's v_scratch", op);
     GENRE_REQUIRE(is_f32(grad_vox, 5) && same_shape(grad_vox, vox), "%s: grad_vox must have the shape of vox", op);
     GENRE_REQUIRE(D.ZR <= 256, "%s: fused backward supports z_res <= 256", op);
     hipStream_t st = (hipStream_t)stream;
@@ -779,7 +795,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
         }
         render_bwd_brick_kernel<<<dim3(rows, D.N * D.NC), kBlock, 0, st>>>(
             D, (const double *)dirs->data, (const float *)dp_scratch->data, (const int *)brick_table->data,
-            (const int *)chunk_list->data, dpmax, view5(grad_vox));
+            (const int *)chunk_list->data, dpmax, view5(vox), view5(grad_vox));
         GENRE_LAUNCH_CHECK("render_spherical backward (bricks)");
         return 1;
     }

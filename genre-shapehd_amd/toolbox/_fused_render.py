@@ -127,10 +127,11 @@ def tables_for(vox_shape, device, dirs64, z_res):
 
 
 class RenderSphericalFused(Function):
-    """apply(vox [N,NC,X,Y,Z], dirs64 [R,R,3] float64, depth_weight [ZR]) -> [N,NC,R,R]"""
+    """apply(vox [N,NC,X,Y,Z], dirs64 [R,R,3] float64, depth_weight [ZR], pre_scale=0.0) -> [N,NC,R,R];
+    pre_scale != 0 renders clamp(vox * pre_scale, 1e-5, 1 - 1e-5) without materialising it"""
 
     @staticmethod
-    def forward(ctx, vox, dirs64, depth_weight):
+    def forward(ctx, vox, dirs64, depth_weight, pre_scale=0.0):
         assert vox.dim() == 5 and vox.is_cuda and vox.dtype == torch.float32
         assert dirs64.dtype == torch.float64 and dirs64.dim() == 3 and dirs64.is_contiguous()
         lib = _loader().render_lib
@@ -140,8 +141,9 @@ class RenderSphericalFused(Function):
         rays = vox.shape[0] * vox.shape[1] * res * res
         v = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
         lib.render_spherical_forward(vox, dirs64.view(torch.float32), depth_weight, out,
-                                     v, t["fwd_table"], t["fwd_chunks"], t["kin"])
+                                     v, t["fwd_table"], t["fwd_chunks"], t["kin"], float(pre_scale))
         ctx.save_for_backward(vox, dirs64, depth_weight, v)
+        ctx.pre_scale = float(pre_scale)
         return out
 
     @staticmethod
@@ -154,5 +156,5 @@ class RenderSphericalFused(Function):
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
         scratch = torch.empty((v.numel() + 4,), dtype=torch.float32, device=vox.device)
         lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,
-                                      scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"])
-        return grad_vox, None, None
+                                      scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"], ctx.pre_scale)
+        return grad_vox, None, None, None

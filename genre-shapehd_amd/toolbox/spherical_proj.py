@@ -73,10 +73,16 @@ class render_spherical(torch.nn.Module):
         return (_fused_render.available() and vox.is_cuda and vox.dtype == torch.float32
                 and self.z_res <= 256)
 
-    def forward(self, vox):
+    def forward(self, vox, pre_scale=None):
+        """vox [N,C,X,Y,Z] -> [N,C,res,res].  Extension: `pre_scale=s` renders
+        clamp(vox * s, 1e-5, 1 - 1e-5) -- the expression GenRe feeds this module
+        (depth_pred_with_sph_inpaint.py:124, s = 50) -- without materialising it on the fused path."""
         if self._use_fused(vox):
             from . import _fused_render
-            return _fused_render.RenderSphericalFused.apply(vox, self._dirs64, self.depth_weight)
+            return _fused_render.RenderSphericalFused.apply(vox, self._dirs64, self.depth_weight,
+                                                            0.0 if pre_scale is None else float(pre_scale))
+        if pre_scale is not None:
+            vox = torch.clamp(vox * pre_scale, 1e-5, 1 - 1e-5)
         grid = self.grid.expand(vox.shape[0], -1, -1, -1, -1)
         vox = vox.permute(0, 1, 4, 3, 2)
         prob_sph = torch.nn.functional.grid_sample(vox, grid, mode='bilinear', padding_mode='zeros',

@@ -178,12 +178,17 @@ int genre_nnd_backward(const genre_tensor *xyz1, const genre_tensor *xyz2,
  *                trilinear corner inside the volume appears exactly once, under the brick
  *                of its (clamped) base corner
  *   kin        : int32 [R*R], first such sample of each ray (they form a suffix)
+ * pre_scale != 0 (brick path only): the rendered volume is
+ * clamp(vox * pre_scale, 1e-5, 1-1e-5) formed on the fly -- the caller-side
+ * `torch.clamp(proj * 50, 1e-5, 1 - 1e-5)` of depth_pred_with_sph_inpaint.py:124 folded
+ * in (two full-volume elementwise passes less each way); backward then returns the
+ * gradient w.r.t. the un-scaled, un-clamped vox.
  * Reference builder of the tables: genre-shapehd_amd/toolbox/_fused_render.py. */
 int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *dirs,
                                    const genre_tensor *depth_weight, const genre_tensor *out,
                                    const genre_tensor *v_scratch, const genre_tensor *fwd_table,
                                    const genre_tensor *fwd_chunks, const genre_tensor *kin,
-                                   void *stream);
+                                   float pre_scale, void *stream);
 
 /* Adjoint of the above w.r.t. vox (what autograd derives for the reference's
  * op chain).  grad_out [N,NC,R,R] -> grad_vox [N,NC,X,Y,Z], fully written.
@@ -204,7 +209,7 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
                                     const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
                                     const genre_tensor *brick_table, const genre_tensor *chunk_list,
                                     const genre_tensor *v_scratch, const genre_tensor *kin,
-                                    void *stream);
+                                    float pre_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -67,3 +67,31 @@ def test_chain_config2(genre, oracle, dev):
     out = genre.sph_pad(render(torch.clamp(proj * 50, 1e-5, 1 - 1e-5)), 16)
     assert out.shape == (2, 1, 160, 160)
     assert (out.cpu() - ref).abs().max().item() <= TOL
+
+
+def test_pre_scale_fusion(genre, oracle, dev):
+    """render(x, pre_scale=50) == render(clamp(x*50, 1e-5, 1-1e-5)): forward bit-for-bit (the tile holds
+    exactly the materialised values), gradient w.r.t. x within tolerance; also against the CPU chain"""
+    from genre_shapehd_amd.toolbox import _fused_render
+    if not _fused_render.available():
+        pytest.skip("fused render kernel not in this build")
+    d = inputs.batch_depth(2)
+    fl, cd = inputs.cam_params(2)
+    tdf, _ = oracle.back_projection_forward(d, cd, fl)
+    rng = np.random.default_rng(5)
+    # proj-like volume with values on both sides of the clamp bounds after x50
+    x = ((1 - 128 * tdf) * rng.uniform(0.0, 0.03, tdf.shape)).astype(np.float32)
+    g = torch.from_numpy(rng.standard_normal((2, 1, 128, 128)).astype(np.float32)).to(dev)
+    mod = genre.render_spherical(fused=True).to(dev)
+    xa = torch.from_numpy(x).to(dev).requires_grad_(True)
+    xb = torch.from_numpy(x).to(dev).requires_grad_(True)
+    oa = mod(xa, pre_scale=50.0)
+    ob = mod(torch.clamp(xb * 50.0, 1e-5, 1 - 1e-5))
+    assert torch.equal(oa, ob)
+    oa.backward(g)
+    ob.backward(g)
+    diff = (xa.grad - xb.grad).abs() / (1 + xb.grad.abs())
+    assert diff.max().item() <= 1e-5, diff.max().item()
+    from oracle.torch_oracle import RenderSphericalCPU
+    ref = RenderSphericalCPU(oracle)(torch.clamp(torch.from_numpy(x) * 50.0, 1e-5, 1 - 1e-5))
+    assert (oa.detach().cpu() - ref).abs().max().item() <= TOL
