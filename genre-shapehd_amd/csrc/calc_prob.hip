@@ -87,6 +87,19 @@ __device__ __forceinline__ double wave_incl_sum_down(double v, int lane)
     return v;
 }
 
+// streaming accesses: every byte is touched exactly once, keep it out of the way of L2
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float *p)
+{
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float *p, const float4 &s)
+{
+    const v4f v = {s.x, s.y, s.z, s.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+}
+
 // ---- forward, float4 path: z stride 1, Z % 4 == 0, 16-B aligned rays ----------------
 __global__ __launch_bounds__(kBlock) void stop_fwd_vec4_kernel(RayDims D, RayView pin, RayView pout)
 {
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void stop_fwd_vec4_kernel(RayDims D, RayVie
             const int z = z0 + lane * 4;
             const bool live = z < D.Z;
             float4 p = make_float4(0.f, 0.f, 0.f, 0.f);       // p = 0 -> factor 1 (neutral)
-            if (live) p = *reinterpret_cast<const float4 *>(src + z);
+            if (live) p = nt_load4(src + z);
             const double q0 = 1.0 - (double)p.x, q1 = 1.0 - (double)p.y;
             const double q2 = 1.0 - (double)p.z, q3 = 1.0 - (double)p.w;
             const double e1 = q0, e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void stop_fwd_vec4_kernel(RayDims D, RayVie
                 s.y = (float)((double)p.y * (excl * e1));
                 s.z = (float)((double)p.z * (excl * e2));
                 s.w = (float)((double)p.w * (excl * e3));
-                *reinterpret_cast<float4 *>(dst + z) = s;
+                nt_store4(dst + z, s);
             }
             carry *= __shfl(incl, 63, 64);
         }
@@ -166,10 +179,10 @@ __global__ __launch_bounds__(kBlock) void stop_bwd_vec4_kernel(RayDims D, RayVie
             const bool live = z < D.Z;
             float4 p = make_float4(0.5f, 0.5f, 0.5f, 0.5f), w = make_float4(0.f, 0.f, 0.f, 0.f);
             if (live) {
-                p = *reinterpret_cast<const float4 *>(src + z);
-                w = *reinterpret_cast<const float4 *>(wa + z);
+                p = nt_load4(src + z);
+                w = nt_load4(wa + z);
                 if (FUSED) {
-                    const float4 g = *reinterpret_cast<const float4 *>(wb + z);
+                    const float4 g = nt_load4(wb + z);
                     w.x *= g.x; w.y *= g.y; w.z *= g.z; w.w *= g.w;
                 }
             }
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void stop_bwd_vec4_kernel(RayDims D, RayVie
                 g.z = (float)(w2 / (double)p.z - (after + w3) / (1.0 - (double)p.z));
                 g.y = (float)(w1 / (double)p.y - (after + (w3 + w2)) / (1.0 - (double)p.y));
                 g.x = (float)(w0 / (double)p.x - (after + ((w3 + w2) + w1)) / (1.0 - (double)p.x));
-                *reinterpret_cast<float4 *>(dst + z) = g;
+                nt_store4(dst + z, g);
             }
             carry += __shfl(incl, 0, 64);
         }

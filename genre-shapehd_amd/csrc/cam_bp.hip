@@ -90,10 +90,12 @@ __device__ __forceinline__ void decode_pixel(const Dims &D, int64_t idx, int &n,
 __global__ __launch_bounds__(kBlock) void fill2_vec4_kernel(float4 *__restrict__ a, float va,
                                                              float4 *__restrict__ b, float vb, int64_t n4)
 {
-    const float4 fa = make_float4(va, va, va, va), fb = make_float4(vb, vb, vb, vb);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f fa = {va, va, va, va}, fb = {vb, vb, vb, vb};
+    v4f *pa = reinterpret_cast<v4f *>(a), *pb = reinterpret_cast<v4f *>(b);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
-        a[i] = fa;
-        b[i] = fb;
+        __builtin_nontemporal_store(fa, &pa[i]);       // streaming: nothing re-reads a full line soon
+        __builtin_nontemporal_store(fb, &pb[i]);
     }
 }
 
@@ -130,13 +132,20 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(Dims D, View4 depth, Vi
         const float dist = norm3(gx - centre_f(ix, D.X), gy - centre_f(iy, D.Y), gz - centre_f(iz, D.Z));
         float *pc = cnt.p + n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4;
         float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
-        const float old = unsafeAtomicAdd(pc, 1.0f);                 // :274, hardware global_atomic_add_f32
         // Negated accumulation (see file header).  The reference starts every sum at the prefill e = 1/res
         // (0 on the spherical path) and subtracts it again in K2 (:304): the first point contributes
         // t = fl(e + dist) - e (exact).  The first arriver reproduces that rounding and cancels whatever
         // the fill pass wrote; later arrivers just add, as the reference's atomics do.
         const float t = (dist + empty_val) - empty_val;
-        unsafeAtomicAdd(pv, (old == 0.0f) ? -(t + fill_val) : -dist);   // :273
+        if (fill_val == 0.0f) {
+            // nothing to cancel (spherical path, and the camera path with the shift folded in): no need to
+            // know who is first, so both atomics are fire-and-forget (no return value, no dependent latency)
+            unsafeAtomicAdd(pc, 1.0f);                               // :274
+            unsafeAtomicAdd(pv, -t);                                 // :273
+        } else {
+            const float old = unsafeAtomicAdd(pc, 1.0f);             // hardware global_atomic_add_f32, returning
+            unsafeAtomicAdd(pv, (old == 0.0f) ? -(t + fill_val) : -dist);
+        }
     }
 }
 
