@@ -1,0 +1,46 @@
+"""Runs each hand-written kernel of the step a few times at batch 32 so that
+`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes)
+can attribute HBM-side traffic per dispatch.  Usage on the GPU box:
+  cd /tmp && TMPDIR=/tmp rocprofv3 --pmc FETCH_SIZE -d OUT -o fetch -- python profiles/pmc_targets.py
+  cd /tmp && TMPDIR=/tmp rocprofv3 --pmc WRITE_SIZE -d OUT -o write -- python profiles/pmc_targets.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import inputs  # noqa: E402
+import genre_shapehd_amd as G  # noqa: E402
+from genre_shapehd_amd.toolbox import _fused_render  # noqa: E402
+from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib  # noqa: E402
+from genre_shapehd_amd.toolbox.calc_prob.calc_prob._ext import calc_prob_lib  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev = torch.device("cuda:0")
+d = torch.from_numpy(inputs.batch_depth(B)).to(dev)
+fl = torch.full((B, 1), 418.3, device=dev)
+cd = torch.full((B, 1), 2.2, device=dev)
+tdf = torch.empty((B, 1, 128, 128, 128), device=dev)
+cnt = torch.empty_like(tdf)
+p = torch.rand((B, 1, 128, 128, 256), device=dev).clamp_(1e-5, 1 - 1e-5)
+s = torch.empty_like(p)
+g = torch.randn_like(p)
+o = torch.empty_like(p)
+mod = G.render_spherical(fused=True).to(dev)
+dirs = mod._dirs64.view(torch.float32)
+T = _fused_render.tables_for(tdf.shape, dev, mod._dirs64, 256)
+out = torch.empty((B, 1, 128, 128), device=dev)
+gout = torch.randn_like(out)
+vbuf = torch.empty((B * 128 * 128 * 256,), device=dev)
+scratch = torch.empty((vbuf.numel() + 4,), device=dev)
+gvox = torch.empty_like(tdf)
+lib = _fused_render._loader().render_lib
+for _ in range(3):
+    cam_bp_lib.back_projection_forward_shifted(d, cd, fl, tdf, cnt)
+    calc_prob_lib.calc_prob_forward(p, s)
+    calc_prob_lib.calc_prob_backward_fused(p, s, g, o)
+    lib.render_spherical_forward(tdf, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0)
+    lib.render_spherical_backward(tdf, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"],
+                                  vbuf, T["kin"], 50.0)
+torch.cuda.synchronize()
