@@ -532,13 +532,15 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                 sample_pos(D, dx2[u], dy2[u], dz2[u], kk[u], gx, gy, gz);
                 Cell c;
                 locate(D, gx, gy, gz, c);
-                const double dps = (double)dp[u] * scale;                 // exact (power-of-two scale)
                 const int lx = c.x0 - ox, ly = c.y0 - oy, lz = c.z0 - oz;
                 unsigned long long *tp = tile + (lx * kBrick + ly) * kBrick + lz;
-                // weight (fp32 product, as ATen forms it) x dL/dp is exact in fp64; adding 1.5*2^52 rounds it
-                // to an integer held in the mantissa (|value| <= 2^44): 3 instructions instead of a cvt sequence
-#define GENRE_FIX(i) (unsigned long long)(__double_as_longlong((double)corner_w(c, i) * dps + 6755399441055744.0) - \
-                                          0x4338000000000000LL)
+                // fp32 weight products (x*y first, then *z, as ATen forms them) times dL/dp in fp32, then ONE
+                // fp64 fma with the power-of-two scale and 1.5*2^52: the sum is an integer in the mantissa
+                // (|value| <= 2^44) -- cvt + fma + a subtract on the high word per corner
+                const float wxy[4] = {c.wx0 * c.wy0, c.wx1 * c.wy0, c.wx0 * c.wy1, c.wx1 * c.wy1};
+                const float dpu = dp[u];
+#define GENRE_FIX(i) (unsigned long long)(__double_as_longlong(fma((double)((wxy[(i) & 3] * (((i) & 4) ? c.wz1 : c.wz0)) * dpu), \
+                                                                     scale, 6755399441055744.0)) - 0x4338000000000000LL)
                 if ((unsigned)lx < (unsigned)(kBrick - 1) && (unsigned)ly < (unsigned)(kBrick - 1) &&
                     (unsigned)lz < (unsigned)(kBrick - 1)) {             // all 8 corners inside this brick
 #pragma unroll
