@@ -25,6 +25,7 @@
 // prefix; any strides are accepted (a generic one-sample-per-lane kernel covers
 // layouts the float4 path cannot).
 #include "common.hpp"
+#include "wave_scan.hpp"
 
 #pragma clang fp contract(off)
 
@@ -67,26 +68,6 @@ __device__ __forceinline__ int64_t ray_base(const RayDims &D, const RayView &v, 
     return n * v.sn + c * v.sc + x * v.sx + y * v.sy;
 }
 
-// inclusive wave scans over 64 lanes (fp64 payload = two 32-bit cross-lane moves per step)
-__device__ __forceinline__ double wave_incl_prod_up(double v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_up(v, o, 64);
-        if (lane >= o) v *= t;
-    }
-    return v;
-}
-__device__ __forceinline__ double wave_incl_sum_down(double v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_down(v, o, 64);
-        if (lane + o < 64) v += t;
-    }
-    return v;
-}
-
 // streaming accesses: every byte is touched exactly once, keep it out of the way of L2
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 nt_load4(const float *p)
@@ -118,10 +99,8 @@ __global__ __launch_bounds__(kBlock) void stop_fwd_vec4_kernel(RayDims D, RayVie
             const double q0 = 1.0 - (double)p.x, q1 = 1.0 - (double)p.y;
             const double q2 = 1.0 - (double)p.z, q3 = 1.0 - (double)p.w;
             const double e1 = q0, e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
-            const double incl = wave_incl_prod_up(tot, lane);
-            double excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0;
-            excl *= carry;
+            const double incl = wave_incl_prod(tot);
+            const double excl = wave_prev(1.0, incl) * carry;
             if (live) {
                 float4 s;
                 s.x = (float)((double)p.x * excl);
@@ -130,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void stop_fwd_vec4_kernel(RayDims D, RayVie
                 s.w = (float)((double)p.w * (excl * e3));
                 nt_store4(dst + z, s);
             }
-            carry *= __shfl(incl, 63, 64);
+            carry *= wave_last(incl);
         }
     }
 }
@@ -149,11 +128,10 @@ __global__ __launch_bounds__(kBlock) void stop_fwd_generic_kernel(RayDims D, Ray
             const int z = z0 + lane;
             const bool live = z < D.Z;
             const float p = live ? src[z * pin.sz] : 0.0f;
-            const double incl = wave_incl_prod_up(1.0 - (double)p, lane);
-            double excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0;
+            const double incl = wave_incl_prod(1.0 - (double)p);
+            const double excl = wave_prev(1.0, incl);
             if (live) dst[z * pout.sz] = (float)((double)p * (excl * carry));
-            carry *= __shfl(incl, 63, 64);
+            carry *= wave_last(incl);
         }
     }
 }
@@ -188,10 +166,9 @@ __global__ __launch_bounds__(kBlock) void stop_bwd_vec4_kernel(RayDims D, RayVie
             }
             const double w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;
             const double tot = ((w3 + w2) + w1) + w0;
-            const double incl = wave_incl_sum_down(tot, lane);
-            double after = __shfl_down(incl, 1, 64);          // sum over lanes > lane
-            if (lane == 63) after = 0.0;
-            after += carry;
+            const double incl = wave_incl_sum(tot);            // prefix over lanes <= lane
+            const double chunk_total = wave_last(incl);
+            const double after = (chunk_total - incl) + carry; // sum over lanes > lane (+ later chunks)
             if (live) {
                 float4 g;
                 g.w = (float)(w3 / (double)p.w - after / (1.0 - (double)p.w));
@@ -200,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void stop_bwd_vec4_kernel(RayDims D, RayVie
                 g.x = (float)(w0 / (double)p.x - (after + ((w3 + w2) + w1)) / (1.0 - (double)p.x));
                 nt_store4(dst + z, g);
             }
-            carry += __shfl(incl, 0, 64);
+            carry += chunk_total;
         }
     }
 }
@@ -228,12 +205,11 @@ __global__ __launch_bounds__(kBlock) void stop_bwd_generic_kernel(RayDims D, Ray
                 w = wa[z * a.sz];
                 if (FUSED) w *= wb[z * b.sz];
             }
-            const double incl = wave_incl_sum_down((double)w, lane);
-            double after = __shfl_down(incl, 1, 64);
-            if (lane == 63) after = 0.0;
-            after += carry;
+            const double incl = wave_incl_sum((double)w);
+            const double chunk_total = wave_last(incl);
+            const double after = (chunk_total - incl) + carry;
             if (live) dst[z * gout.sz] = (float)((double)w / (double)p - after / (1.0 - (double)p));
-            carry += __shfl(incl, 0, 64);
+            carry += chunk_total;
         }
     }
 }

@@ -35,6 +35,7 @@
 //   95 % of it atomic throughput (all 16 384 rays converge on the central voxels).  It is kept
 //   as the fallback when no brick tables are passed.
 #include "common.hpp"
+#include "wave_scan.hpp"
 
 #pragma clang fp contract(off)
 
@@ -106,30 +107,7 @@ __device__ __forceinline__ float gather(const RenderDims &D, const float *__rest
     return acc;
 }
 
-__device__ __forceinline__ double wave_incl_prod_up(double v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_up(v, o, 64);
-        if (lane >= o) v *= t;
-    }
-    return v;
-}
-__device__ __forceinline__ double wave_incl_sum_down(double v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_down(v, o, 64);
-        if (lane + o < 64) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_last(wave_incl_sum(v)); }
 
 __device__ __forceinline__ void ray_decode(const RenderDims &D, int64_t r, int64_t &n, int &c, int &q)
 {
@@ -228,16 +206,14 @@ __device__ __forceinline__ double expect4(const RenderDims &D, const float (&p)[
 {
     const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2], q3 = 1.0 - (double)p[3];
     const double e1 = q0, e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
-    const double incl = wave_incl_prod_up(tot, lane);
-    double excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.0;
-    excl *= carry;
+    const double incl = wave_incl_prod(tot);
+    const double excl = wave_prev(1.0, incl) * carry;
     double acc = 0.0;                                                    // sum_k s_k * depth_weight[k]   (:68)
     if (kb + 0 < D.ZR) acc += ((double)p[0] * excl) * (double)dw[kb + 0];
     if (kb + 1 < D.ZR) acc += ((double)p[1] * (excl * e1)) * (double)dw[kb + 1];
     if (kb + 2 < D.ZR) acc += ((double)p[2] * (excl * e2)) * (double)dw[kb + 2];
     if (kb + 3 < D.ZR) acc += ((double)p[3] * (excl * e3)) * (double)dw[kb + 3];
-    carry *= __shfl(incl, 63, 64);
+    carry *= wave_last(incl);
     return acc;
 }
 
@@ -251,18 +227,15 @@ __device__ __forceinline__ void dp4(const RenderDims &D, const float (&p)[4], co
     for (int t = 0; t < 4; t++) w[t] = (kb + t < D.ZR) ? dw[kb + t] : 0.f;
     const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2], q3 = 1.0 - (double)p[3];
     const double e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
-    const double incl = wave_incl_prod_up(tot, lane);
-    double excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.0;
-    const double prod_all = __shfl(incl, 63, 64);
+    const double incl = wave_incl_prod(tot);
+    const double excl = wave_prev(1.0, incl);
+    const double prod_all = wave_last(incl);
     const double T0 = excl, T1 = excl * q0, T2 = excl * e2, T3 = excl * e3;       // transmittance before k
     const double sw0 = (double)p[0] * T0 * (double)w[0], sw1 = (double)p[1] * T1 * (double)w[1];
     const double sw2 = (double)p[2] * T2 * (double)w[2], sw3 = (double)p[3] * T3 * (double)w[3];
     const double lane_sw = ((sw3 + sw2) + sw1) + sw0;
-    const double incl_s = wave_incl_sum_down(lane_sw, lane);
-    double after = __shfl_down(incl_s, 1, 64);
-    if (lane == 63) after = 0.0;
-    after += prod_all;                                                   // prod(1-p) joins the suffix
+    const double incl_s = wave_incl_sum(lane_sw);                        // prefix over lanes <= lane
+    const double after = (wave_last(incl_s) - incl_s) + prod_all;        // suffix; prod(1-p) joins it
     const double A3 = after, A2 = after + sw3, A1 = after + (sw3 + sw2), A0 = after + ((sw3 + sw2) + sw1);
     const double gd = (double)g;
     dp[0] = pass[0] ? (float)(gd * (T0 * (double)w[0] - A0 / q0)) : 0.f;
