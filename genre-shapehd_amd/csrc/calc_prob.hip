@@ -171,10 +171,12 @@ __global__ __launch_bounds__(kBlock) void stop_bwd_vec4_kernel(RayDims D, RayVie
             const double after = (chunk_total - incl) + carry; // sum over lanes > lane (+ later chunks)
             if (live) {
                 float4 g;
-                g.w = (float)(w3 / (double)p.w - after / (1.0 - (double)p.w));
-                g.z = (float)(w2 / (double)p.z - (after + w3) / (1.0 - (double)p.z));
-                g.y = (float)(w1 / (double)p.y - (after + (w3 + w2)) / (1.0 - (double)p.y));
-                g.x = (float)(w0 / (double)p.x - (after + ((w3 + w2) + w1)) / (1.0 - (double)p.x));
+                // fp32 divides (w/p is an fp32 divide in the reference too, :178); the suffix sums stay fp64 and
+                // are rounded once.  An fp64 divide costs ~30 instructions, and there were 8 per lane.
+                g.w = w.w / p.w - (float)after / (1.0f - p.w);
+                g.z = w.z / p.z - (float)(after + w3) / (1.0f - p.z);
+                g.y = w.y / p.y - (float)(after + (w3 + w2)) / (1.0f - p.y);
+                g.x = w.x / p.x - (float)(after + ((w3 + w2) + w1)) / (1.0f - p.x);
                 nt_store4(dst + z, g);
             }
             carry += chunk_total;

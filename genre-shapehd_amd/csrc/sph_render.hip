@@ -238,10 +238,11 @@ __device__ __forceinline__ void dp4(const RenderDims &D, const float (&p)[4], co
     const double after = (wave_last(incl_s) - incl_s) + prod_all;        // suffix; prod(1-p) joins it
     const double A3 = after, A2 = after + sw3, A1 = after + (sw3 + sw2), A0 = after + ((sw3 + sw2) + sw1);
     const double gd = (double)g;
-    dp[0] = pass[0] ? (float)(gd * (T0 * (double)w[0] - A0 / q0)) : 0.f;
-    dp[1] = pass[1] ? (float)(gd * (T1 * (double)w[1] - A1 / q1)) : 0.f;
-    dp[2] = pass[2] ? (float)(gd * (T2 * (double)w[2] - A2 / q2)) : 0.f;
-    dp[3] = pass[3] ? (float)(gd * (T3 * (double)w[3] - A3 / q3)) : 0.f;
+    // fp32 divides for A/(1-p) (an fp64 divide is ~30 instructions); everything feeding them is fp64
+    dp[0] = pass[0] ? (float)(gd * (T0 * (double)w[0] - (double)((float)A0 / (1.0f - p[0])))) : 0.f;
+    dp[1] = pass[1] ? (float)(gd * (T1 * (double)w[1] - (double)((float)A1 / (1.0f - p[1])))) : 0.f;
+    dp[2] = pass[2] ? (float)(gd * (T2 * (double)w[2] - (double)((float)A2 / (1.0f - p[2])))) : 0.f;
+    dp[3] = pass[3] ? (float)(gd * (T3 * (double)w[3] - (double)((float)A3 / (1.0f - p[3])))) : 0.f;
 }
 
 __device__ __forceinline__ void lane_dp(const RenderDims &D, const float *__restrict__ base, double dx2, double dy2,
