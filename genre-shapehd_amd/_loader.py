@@ -42,7 +42,8 @@ def _load():
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
                         ("genre_get_surface_mask", 5), ("genre_back_projection_forward_shifted", 5),
                         ("genre_back_projection_backward_shifted", 8), ("genre_spherical_back_proj_forward", 4),
-                        ("genre_spherical_back_proj_backward", 5), ("genre_calc_prob_forward", 2),
+                        ("genre_spherical_back_proj_backward", 5), ("genre_spherical_back_proj_forward_shifted", 4),
+                        ("genre_spherical_back_proj_backward_shifted", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
                         ("genre_render_spherical_forward", 8), ("genre_render_spherical_backward", 10)):
@@ -138,6 +139,16 @@ class _CamBpLib:
     @staticmethod
     def spherical_back_proj_backward(depth, grid_in, cnt, grad_in, grad_depth):
         return _call("genre_spherical_back_proj_backward", depth, grid_in, cnt, grad_in, grad_depth)
+
+
+    @staticmethod
+    def spherical_back_proj_forward_shifted(depth, grid_in, voxel, cnt):
+        """extension: writes (-tdf + 1/res) * res * clamp(cnt,0,1) (genre_full_model.py:139-142 folded in)"""
+        return _call("genre_spherical_back_proj_forward_shifted", depth, grid_in, voxel, cnt)
+
+    @staticmethod
+    def spherical_back_proj_backward_shifted(depth, grid_in, cnt, grad_in, grad_depth):
+        return _call("genre_spherical_back_proj_backward_shifted", depth, grid_in, cnt, grad_in, grad_depth)
 
 
 class _CalcProbLib:

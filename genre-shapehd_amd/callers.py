@@ -1,0 +1,86 @@
+"""GenRe caller glue around the geometric ops (first step).
+
+The reference's models call the toolbox ops with a few full-volume elementwise passes in between
+(models/depth_pred_with_sph_inpaint.py:120-126, models/genre_full_model.py:122-143).  This module
+re-hosts exactly those two glue sections with the passes folded into the native ops, so that the
+refiner input [N,2,128^3] is written once.  The networks themselves (net1, net2, Unet_3D) are stock
+torch.nn and stay with the caller.
+
+    geo = GenReGeometry().cuda()
+    proj_depth, sph_in = geo.depth_to_spherical(pred_abs_depth)       # :120-126  -> net2
+    refine_input, cnt  = geo.refiner_input(pred_sph_full, proj_depth) # :122-127,134-143 -> Unet_3D
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+from .toolbox.cam_bp.cam_bp.modules.camera_backprojection_module import Camera_back_projection_layer
+from .toolbox.spherical_proj import gen_sph_grid, render_spherical, sph_pad
+
+LO, HI = 1e-5, 1 - 1e-5
+
+
+class RefinerInput(Function):
+    """(pred_sph_full [N,1,H,W], grid [N,1,h,w,3], proj_depth [N,1,R,R,R], margin) ->
+    (refine_input [N,2,R,R,R], cnt [N,1,R,R,R]) with
+
+        channel 0 = (-tdf + 1/R) * R * clamp(cnt,0,1),  (tdf, cnt) = SphericalBackProjection(1 - crop(sph), grid, R)
+        channel 1 = clamp(proj_depth / 50, 1e-5, 1-1e-5)
+
+    i.e. genre_full_model.py:134-143 and :125-126.  Channel 0 is written by the native op straight into
+    the output (its normalise pass applies the post-transform), channel 1 by one elementwise kernel with
+    `out=`; the reference's torch.cat copy and four full-volume elementwise passes disappear."""
+
+    @staticmethod
+    def forward(ctx, pred_sph_full, grid, proj_depth, margin):
+        n, _, h, w = pred_sph_full.shape
+        res = proj_depth.shape[2]
+        inv = (1 - pred_sph_full[:, :, margin:h - margin, margin:w - margin]).contiguous()
+        out = torch.empty((n, 2, res, res, res), dtype=proj_depth.dtype, device=proj_depth.device)
+        cnt = torch.empty((n, 1, res, res, res), dtype=proj_depth.dtype, device=proj_depth.device)
+        cam_bp_lib.spherical_back_proj_forward_shifted(inv, grid, out[:, 0:1], cnt)
+        torch.clamp(proj_depth / 50, LO, HI, out=out[:, 1:2])
+        ctx.save_for_backward(inv, grid, cnt, proj_depth)
+        ctx.margin = margin
+        ctx.sph_shape = pred_sph_full.shape
+        ctx.mark_non_differentiable(cnt)
+        return out, cnt
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out, grad_cnt):
+        inv, grid, cnt, proj_depth = ctx.saved_tensors
+        m = ctx.margin
+        grad_sph = grad_proj = None
+        if ctx.needs_input_grad[0]:
+            gd = torch.empty_like(inv)
+            cam_bp_lib.spherical_back_proj_backward_shifted(inv, grid, cnt, grad_out[:, 0:1], gd)
+            grad_sph = torch.zeros(ctx.sph_shape, dtype=gd.dtype, device=gd.device)
+            grad_sph[:, :, m:ctx.sph_shape[2] - m, m:ctx.sph_shape[3] - m] = -gd          # d(1 - crop)/d sph
+        if ctx.needs_input_grad[2]:
+            t = proj_depth / 50
+            grad_proj = grad_out[:, 1:2] * ((t >= LO) & (t <= HI)).to(grad_out.dtype) / 50
+        return grad_sph, None, grad_proj, None
+
+
+class GenReGeometry(nn.Module):
+    def __init__(self, padding_margin=16, res=128):
+        super().__init__()
+        self.margin = padding_margin
+        self.res = res
+        self.proj_depth = Camera_back_projection_layer(res)
+        self.render_spherical = render_spherical()
+        self.register_buffer('grid', gen_sph_grid(res))                  # genre_full_model.py:108
+
+    def depth_to_spherical(self, pred_abs_depth):
+        """depth_pred_with_sph_inpaint.py:120-129 -> (out_1['proj_depth'], out_1['pred_sph_partial'])"""
+        proj = self.proj_depth(pred_abs_depth)                           # 1 - 128*tdf, shift folded into the op
+        sph_in = self.render_spherical(proj, pre_scale=50.0)             # == render(clamp(proj*50, 1e-5, 1-1e-5))
+        return proj * 50, sph_pad(sph_in, self.margin)
+
+    def refiner_input(self, pred_sph_full, proj_depth):
+        """genre_full_model.py:122-127,134-143 -> (refine_input [N,2,R,R,R], cnt)"""
+        grid = self.grid.expand(pred_sph_full.shape[0], -1, -1, -1, -1)
+        return RefinerInput.apply(pred_sph_full, grid, proj_depth, self.margin)

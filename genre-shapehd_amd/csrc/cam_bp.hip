@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(Dims D, View4 depth, Vi
 template <bool SPH>
 __global__ __launch_bounds__(kBlock) void normalise_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
                                                             View5 grid, View5 vox, View5 cnt, float post_scale,
-                                                            float post_bias)
+                                                            float post_bias, int post_mode)
 {
     const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
@@ -168,8 +168,11 @@ __global__ __launch_bounds__(kBlock) void normalise_kernel(Dims D, View4 depth, 
         const float s = *pv;
         if (s < 0.0f) {                                               // still a raw (negated) sum
             const float k = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
-            // :304 (mean distance); post = identity, or the layer's shift 1 - res*tdf folded in
-            *pv = post_bias + post_scale * ((0.0f - s) / k);
+            // :304 (mean distance); post = identity (scale 1, bias 0), the camera layer's shift 1 - res*tdf
+            // (mode 0 with scale -res, bias 1), or GenRe's spherical glue (-tdf + 1/res)*res (mode 1,
+            // genre_full_model.py:141: post_bias holds 1/res, post_scale holds res)
+            const float mean = (0.0f - s) / k;
+            *pv = post_mode == 1 ? (-mean + post_bias) * post_scale : post_bias + post_scale * mean;
         }
     }
 }
@@ -473,7 +476,7 @@ __global__ void zero2_kernel(View2 a, View2 b, int N, int NC)
 
 // ---- K6: spherical backward (:560-626) ---------------------------------------------
 __global__ __launch_bounds__(kBlock) void sph_backward_kernel(Dims D, View4 depth, View5 grid, View5 cnt,
-                                                               View5 gin, View4 gdepth)
+                                                               View5 gin, View4 gdepth, float gscale)
 {
     const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
     const View2 none = {nullptr, 0, 0};
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void sph_backward_kernel(Dims D, View4 dept
                 float ptnum = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
                 if (ptnum < 1.0f) ptnum = 1.0f;
                 if ((double)dist < 1e-5) dist = (float)1e-5;
-                const float gd = gin.p[n * gin.s0 + c * gin.s1 + ix * gin.s2 + iy * gin.s3 + iz * gin.s4];
+                const float gd = gin.p[n * gin.s0 + c * gin.s1 + ix * gin.s2 + iy * gin.s3 + iz * gin.s4] * gscale;
                 out = gd * (d - cos_cc) / (ptnum * dist);               // :621
             }
         }
@@ -596,10 +599,16 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
     // out = 1 - res*tdf.  The "negative == raw sum" marker of the normalise pass needs out >= 0, true for
     // cubic grids (mean distance <= sqrt(3)/2 voxel).
     float post_scale = 1.0f, post_bias = 0.0f, fill_val = empty_val;
+    int post_mode = 0;
     if (shifted) {
         GENRE_REQUIRE(D.X == D.Y && D.Y == D.Z, "%s: the fused shift needs a cubic grid", op);
-        post_scale = -(float)mx; post_bias = 1.0f;
-        fill_val = 1.0f - (float)mx * empty_val;
+        if (SPH) {          // (-tdf + 1/res) * res * clamp(cnt,0,1)  (genre_full_model.py:139-142); empty -> 0
+            post_mode = 1; post_scale = (float)mx; post_bias = (float)(1.0 / (double)mx);
+            fill_val = 0.0f;
+        } else {            // 1 - res * tdf  (camera_backprojection_module.py:25-28)
+            post_scale = -(float)mx; post_bias = 1.0f;
+            fill_val = 1.0f - (float)mx * empty_val;
+        }
     }
     if (!SPH && !use_scatter_camera()) {
         // single-launch gather formulation (see cam_gather_kernel); bias of K2 (:304,:829) = 1/max(res)
@@ -629,7 +638,7 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
     scatter_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), empty_val, fill_val);
     GENRE_LAUNCH_CHECK("projection forward");
     normalise_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), post_scale,
-                                                post_bias);
+                                                post_bias, post_mode);
     GENRE_LAUNCH_CHECK("safe divide");
     return 1;
 }
@@ -730,11 +739,10 @@ extern "C" int genre_get_surface_mask(const genre_tensor *depth, const genre_ten
     return 1;
 }
 
-extern "C" int genre_spherical_back_proj_backward(const genre_tensor *depth, const genre_tensor *grid_in,
-                                                  const genre_tensor *cnt, const genre_tensor *grad_in,
-                                                  const genre_tensor *grad_depth, void *stream)
+static int sph_backward_impl(const char *op, const genre_tensor *depth, const genre_tensor *grid_in,
+                             const genre_tensor *cnt, const genre_tensor *grad_in, const genre_tensor *grad_depth,
+                             void *stream, bool shifted)
 {
-    const char *op = "spherical_back_proj_backward";
     Dims D{};
     if (!check_image(op, depth, D)) return 0;
     GENRE_REQUIRE(is_f32(grid_in, 5) && grid_in->size[0] == D.N && grid_in->size[1] == D.NC &&
@@ -745,9 +753,37 @@ extern "C" int genre_spherical_back_proj_backward(const genre_tensor *depth, con
         return 0;
     const int64_t npix = (int64_t)D.N * D.NC * D.H * D.W;
     if (npix == 0) return 1;
+    float gscale = 1.0f;
+    if (shifted) {
+        GENRE_REQUIRE(D.X == D.Y && D.Y == D.Z, "%s: the fused glue needs a cubic grid", op);
+        gscale = -(float)D.X;
+    }
     sph_backward_kernel<<<grid_for(npix), kBlock, 0, (hipStream_t)stream>>>(D, view4(depth), view5(grid_in),
                                                                             view5(cnt), view5(grad_in),
-                                                                            view4(grad_depth));
+                                                                            view4(grad_depth), gscale);
     GENRE_LAUNCH_CHECK("spherical projection backward");
     return 1;
+}
+
+extern "C" int genre_spherical_back_proj_backward(const genre_tensor *depth, const genre_tensor *grid_in,
+                                                  const genre_tensor *cnt, const genre_tensor *grad_in,
+                                                  const genre_tensor *grad_depth, void *stream)
+{
+    return sph_backward_impl("spherical_back_proj_backward", depth, grid_in, cnt, grad_in, grad_depth, stream, false);
+}
+
+extern "C" int genre_spherical_back_proj_forward_shifted(const genre_tensor *depth, const genre_tensor *grid_in,
+                                                         const genre_tensor *voxel, const genre_tensor *cnt,
+                                                         void *stream)
+{
+    return forward_impl<true>("spherical_back_proj_forward_shifted", depth, nullptr, nullptr, grid_in, voxel, cnt, stream,
+                              true);
+}
+
+extern "C" int genre_spherical_back_proj_backward_shifted(const genre_tensor *depth, const genre_tensor *grid_in,
+                                                          const genre_tensor *cnt, const genre_tensor *grad_in,
+                                                          const genre_tensor *grad_depth, void *stream)
+{
+    return sph_backward_impl("spherical_back_proj_backward_shifted", depth, grid_in, cnt, grad_in, grad_depth, stream,
+                             true);
 }

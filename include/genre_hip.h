@@ -116,6 +116,17 @@ int genre_spherical_back_proj_backward(const genre_tensor *depth, const genre_te
                                        const genre_tensor *cnt, const genre_tensor *grad_in,
                                        const genre_tensor *grad_depth, void *stream);
 
+/* Extensions: the same two ops with GenRe's caller-side glue (genre_full_model.py:139-142)
+ * folded in: forward writes voxel = (-tdf + 1/res) * res * clamp(cnt, 0, 1) (0 where empty),
+ * backward takes the gradient w.r.t. that.  voxel may be a strided view, e.g. channel 0 of the
+ * [N,2,R,R,R] refiner input. */
+int genre_spherical_back_proj_forward_shifted(const genre_tensor *depth, const genre_tensor *grid_in,
+                                              const genre_tensor *voxel, const genre_tensor *cnt,
+                                              void *stream);
+int genre_spherical_back_proj_backward_shifted(const genre_tensor *depth, const genre_tensor *grid_in,
+                                               const genre_tensor *cnt, const genre_tensor *grad_in,
+                                               const genre_tensor *grad_depth, void *stream);
+
 /* ---- calc_prob : toolbox/calc_prob/calc_prob/src/calc_prob.h:1-2 ---------- */
 
 /* Replaces calc_prob_forward (calc_prob.c:9-17 -> calc_prob_kernel.cu:191-226,

@@ -149,3 +149,33 @@ class HotPathCPU:
         out = self.forward(depth)
         out.backward(grad_out)
         return out.detach(), depth.grad
+
+
+class GenReGlueCPU:
+    """the two glue sections of the reference's GenRe models on CPU torch + the oracle
+    (depth_pred_with_sph_inpaint.py:120-129, genre_full_model.py:122-127,134-143)"""
+
+    def __init__(self, backend, margin=16):
+        self.hot = HotPathCPU(backend)
+        self.sph_bp = make_functions(backend)[2].apply
+        self.margin = margin
+        self.grid = torch.from_numpy(unit_dirs(128).reshape(1, 1, 128, 128, 3)).float()
+
+    def depth_to_spherical(self, depth):
+        n = depth.shape[0]
+        tdf = self.hot.cam(depth, torch.full((n, 1), self.hot.fl), torch.full((n, 1), self.hot.cam_dist), 128)
+        proj = 1 - 128 * tdf
+        sph_in = self.hot.render(torch.clamp(proj * 50, 1e-5, 1 - 1e-5))
+        return proj * 50, sph_pad(sph_in, self.margin)
+
+    def refiner_input(self, sph, proj_depth):
+        b, _, h, w = sph.shape
+        m = self.margin
+        grid = self.grid.expand(b, -1, -1, -1, -1)
+        crop = sph[:, :, m:h - m, m:w - m]
+        proj_df, cnt = self.sph_bp(1 - crop, grid, 128)
+        mask = torch.clamp(cnt.detach(), 0, 1)
+        proj_df = (-proj_df + 1 / 128) * 128
+        proj_df = proj_df * mask
+        pd = torch.clamp(proj_depth / 50, 1e-5, 1 - 1e-5)
+        return torch.cat((proj_df, pd), dim=1), cnt
