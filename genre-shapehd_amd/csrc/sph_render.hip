@@ -515,21 +515,18 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                 const float dpu = dp[u];
 #define GENRE_FIX(i) (unsigned long long)(__double_as_longlong(fma((double)((wxy[(i) & 3] * (((i) & 4) ? c.wz1 : c.wz0)) * dpu), \
                                                                      scale, 6755399441055744.0)) - 0x4338000000000000LL)
-                if ((unsigned)lx < (unsigned)(kBrick - 1) && (unsigned)ly < (unsigned)(kBrick - 1) &&
-                    (unsigned)lz < (unsigned)(kBrick - 1)) {             // all 8 corners inside this brick
+                // ONE predicated path (a fast "all corners inside" branch would run in addition to the general one
+                // in most waves, because interior and face samples share waves): per-axis ownership bits, then
+                // eight exec-masked ds_add_u64
+                const bool ax0 = (unsigned)lx < (unsigned)kBrick, ax1 = (unsigned)(lx + 1) < (unsigned)kBrick;
+                const bool ay0 = (unsigned)ly < (unsigned)kBrick, ay1 = (unsigned)(ly + 1) < (unsigned)kBrick;
+                const bool az0 = (unsigned)lz < (unsigned)kBrick, az1 = (unsigned)(lz + 1) < (unsigned)kBrick;
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
+                for (int i = 0; i < 8; i++) {
+                    const bool own = ((i & 1) ? ax1 : ax0) && ((i & 2) ? ay1 : ay0) && ((i & 4) ? az1 : az0);
+                    if (own)
                         atomicAdd(tp + ((i & 1) ? kBrick * kBrick : 0) + ((i & 2) ? kBrick : 0) + ((i & 4) ? 1 : 0),
                                   GENRE_FIX(i));                          // ds_add_u64
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int cx = lx + (i & 1), cy = ly + ((i >> 1) & 1), cz = lz + ((i >> 2) & 1);
-                        if ((unsigned)cx < (unsigned)kBrick && (unsigned)cy < (unsigned)kBrick &&
-                            (unsigned)cz < (unsigned)kBrick)
-                            atomicAdd(tp + ((i & 1) ? kBrick * kBrick : 0) + ((i & 2) ? kBrick : 0) + ((i & 4) ? 1 : 0),
-                                      GENRE_FIX(i));
-                    }
                 }
 #undef GENRE_FIX
             }
