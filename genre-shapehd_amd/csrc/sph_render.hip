@@ -309,8 +309,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_dp_kernel(RenderDims D, Vie
 }
 
 // ---- brick path, forward: LDS-staged voxel tiles ----------------------------------------------------
-// fwd_table [rows,4] = (brick id, begin, end, -) into fwd_chunks; every in-volume sample appears once,
-// under the brick that holds its base corner.  The workgroup stages the brick plus a one-voxel halo
+// fwd_table [rows,4] = (brick id, begin, end, -) into fwd_list (entries (ray << 8) | k); every in-volume
+// sample appears once, under the brick that holds its base corner.  The workgroup stages the brick plus a one-voxel halo
 // (18^3 floats, zeros outside the volume) with coalesced row reads -- each voxel leaves HBM/L2 once per
 // row instead of once per tap -- then evaluates its samples with 8 LDS reads each and writes the raw
 // value v[ray, k] (16 consecutive floats per chunk).
@@ -318,7 +318,7 @@ constexpr int kTile = kBrick + 2;
 __global__ __launch_bounds__(kBlock) void render_sample_brick_kernel(RenderDims D, View5 vox,
                                                                       const double *__restrict__ dirs,
                                                                       const int *__restrict__ fwd_table,
-                                                                      const int *__restrict__ fwd_chunks,
+                                                                      const int *__restrict__ fwd_list,
                                                                       float *__restrict__ vbuf)
 {
     __shared__ float tile[kTile * kTile * kTile];
@@ -341,16 +341,17 @@ __global__ __launch_bounds__(kBlock) void render_sample_brick_kernel(RenderDims 
     }
     __syncthreads();
     float *__restrict__ vi = vbuf + (int64_t)img * D.R * D.R * D.ZR;
-    const int lane = threadIdx.x & 63, sub = lane & 15, g4 = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int c0 = begin + wave * 64; c0 < end; c0 += kWavesPerBlock * 64) {
-        const int nvalid = (end - c0 < 64) ? end - c0 : 64;
-        const unsigned myword = (lane < nvalid) ? (unsigned)fwd_chunks[c0 + lane] : 0u;
-        for (int s = 0; s * 4 < nvalid; s++) {
-            const int ci = s * 4 + g4;
-            const unsigned ent = (unsigned)__shfl((int)myword, ci & 63, 64);
-            const int q = (int)(ent >> 12), k = (int)((ent >> 4) & 255u) + sub;
-            if (!(ci < nvalid && sub <= (int)(ent & 15u))) continue;
+    // one lane per listed sample (entries are sorted by ray, then sample: neighbouring lanes mostly share the
+    // ray, so the direction loads coalesce to a few addresses and the v stores to 64-byte runs)
+    for (int e0 = begin + threadIdx.x; e0 < end; e0 += 2 * kBlock) {
+        const int e1 = e0 + kBlock;
+        const unsigned ent0 = (unsigned)fwd_list[e0];
+        const unsigned ent1 = e1 < end ? (unsigned)fwd_list[e1] : ent0;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (u == 1 && e1 >= end) break;
+            const unsigned ent = u ? ent1 : ent0;
+            const int q = (int)(ent >> 8), k = (int)(ent & 255u);
             float gx, gy, gz;
             sample_pos(D, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, k, gx, gy, gz);
             Cell c;
@@ -452,9 +453,8 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
 // brick_table [rows,4] = (brick id, begin, end, mode) into chunk_list, heaviest first; mode 0: the
 // row covers the whole brick (plain stores); mode 1: the brick's list is split over several rows
 // (each flushes its tile with atomics onto the brick pre-zeroed by zero_shared_bricks_kernel).
-// chunk_list entries = (ray q << 12) | (first sample k << 4) | (len - 1): up to 16 CONSECUTIVE samples
-// of one ray, handled by 16 adjacent lanes -- the list word and the ray direction are broadcast
-// loads and the dL/dp read is one 64-byte segment.
+// chunk_list entries = (ray q << 8) | sample k, sorted by (brick, ray, sample): one lane per entry, so the
+// VALU-bound loop runs on full waves; neighbouring lanes read consecutive dL/dp values.
 __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, const double *__restrict__ dirs,
                                                                    const float *__restrict__ dpbuf,
                                                                    const int *__restrict__ brick_table,
@@ -477,58 +477,47 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
     for (int t = threadIdx.x; t < kBrick * kBrick * kBrick; t += kBlock) tile[t] = 0ull;
     __syncthreads();
     const float *__restrict__ dpi = dpbuf + (int64_t)img * D.R * D.R * D.ZR;
-    // A wave takes 64 consecutive list words with ONE coalesced load, then walks them four at a time
-    // (16 lanes per chunk), batching the dependent dL/dp and direction loads of four steps so that the
-    // loop exposes ~5 memory latencies per 64 chunks instead of 32.
-    const int lane = threadIdx.x & 63, sub = lane & 15, g4 = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int c0 = begin + wave * 64; c0 < end; c0 += kWavesPerBlock * 64) {
-        const int nvalid = (end - c0 < 64) ? end - c0 : 64;
-        const unsigned myword = (lane < nvalid) ? (unsigned)chunk_list[c0 + lane] : 0u;
-        for (int s0 = 0; s0 * 4 < nvalid; s0 += 4) {
-            float dp[4];
-            int qq[4], kk[4];
-            double dx2[4], dy2[4], dz2[4];
+    // One lane per listed sample, four samples per thread in flight: list words first (coalesced), then the
+    // dependent dL/dp loads of all four (64-byte runs: entries are sorted by ray, then sample), then the work.
+    for (int e0 = begin + threadIdx.x; e0 < end; e0 += 4 * kBlock) {
+        unsigned ent[4];
+        float dp[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int ci = (s0 + u) * 4 + g4;
-                const unsigned ent = (unsigned)__shfl((int)myword, ci & 63, 64);
-                qq[u] = (int)(ent >> 12);
-                kk[u] = (int)((ent >> 4) & 255u) + sub;
-                const bool act = ci < nvalid && sub <= (int)(ent & 15u);
-                dp[u] = act ? dpi[(int64_t)qq[u] * D.ZR + kk[u]] : 0.f;
-                dx2[u] = dirs[qq[u] * 3 + 0] * 2; dy2[u] = dirs[qq[u] * 3 + 1] * 2; dz2[u] = dirs[qq[u] * 3 + 2] * 2;
-            }
+        for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * kBlock;
+            ent[u] = e < end ? (unsigned)chunk_list[e] : 0xffffffffu;
+        }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (dp[u] == 0.0f) continue;
-                float gx, gy, gz;
-                sample_pos(D, dx2[u], dy2[u], dz2[u], kk[u], gx, gy, gz);
-                Cell c;
-                locate(D, gx, gy, gz, c);
-                const int lx = c.x0 - ox, ly = c.y0 - oy, lz = c.z0 - oz;
-                unsigned long long *tp = tile + (lx * kBrick + ly) * kBrick + lz;
-                // fp32 weight products (x*y first, then *z, as ATen forms them) times dL/dp in fp32, then ONE
-                // fp64 fma with the power-of-two scale and 1.5*2^52: the sum is an integer in the mantissa
-                // (|value| <= 2^44) -- cvt + fma + a subtract on the high word per corner
-                const float wxy[4] = {c.wx0 * c.wy0, c.wx1 * c.wy0, c.wx0 * c.wy1, c.wx1 * c.wy1};
-                const float dpu = dp[u];
-#define GENRE_FIX(i) (unsigned long long)(__double_as_longlong(fma((double)((wxy[(i) & 3] * (((i) & 4) ? c.wz1 : c.wz0)) * dpu), \
-                                                                     scale, 6755399441055744.0)) - 0x4338000000000000LL)
-                // ONE predicated path (a fast "all corners inside" branch would run in addition to the general one
-                // in most waves, because interior and face samples share waves): per-axis ownership bits, then
-                // eight exec-masked ds_add_u64
-                const bool ax0 = (unsigned)lx < (unsigned)kBrick, ax1 = (unsigned)(lx + 1) < (unsigned)kBrick;
-                const bool ay0 = (unsigned)ly < (unsigned)kBrick, ay1 = (unsigned)(ly + 1) < (unsigned)kBrick;
-                const bool az0 = (unsigned)lz < (unsigned)kBrick, az1 = (unsigned)(lz + 1) < (unsigned)kBrick;
+        for (int u = 0; u < 4; u++)
+            dp[u] = ent[u] != 0xffffffffu ? dpi[(int64_t)(ent[u] >> 8) * D.ZR + (ent[u] & 255u)] : 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const bool own = ((i & 1) ? ax1 : ax0) && ((i & 2) ? ay1 : ay0) && ((i & 4) ? az1 : az0);
-                    if (own)
-                        atomicAdd(tp + ((i & 1) ? kBrick * kBrick : 0) + ((i & 2) ? kBrick : 0) + ((i & 4) ? 1 : 0),
-                                  GENRE_FIX(i));                          // ds_add_u64
-                }
-#undef GENRE_FIX
+        for (int u = 0; u < 4; u++) {
+            if (dp[u] == 0.0f) continue;
+            const int q = (int)(ent[u] >> 8), k = (int)(ent[u] & 255u);
+            float gx, gy, gz;
+            sample_pos(D, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, k, gx, gy, gz);
+            Cell c;
+            locate(D, gx, gy, gz, c);
+            const int lx = c.x0 - ox, ly = c.y0 - oy, lz = c.z0 - oz;
+            unsigned long long *tp = tile + (lx * kBrick + ly) * kBrick + lz;
+            // fp32 weight products (x*y first, then *z, as ATen forms them) times dL/dp in fp32, then ONE
+            // fp64 fma with the power-of-two scale and 1.5*2^52: the sum is an integer in the mantissa
+            // (|value| <= 2^44) -- cvt + fma + a subtract on the high word per corner
+            const float wxy[4] = {c.wx0 * c.wy0, c.wx1 * c.wy0, c.wx0 * c.wy1, c.wx1 * c.wy1};
+            const float dpu = dp[u];
+            // ONE predicated path (a fast "all corners inside" branch would run in addition to the general one
+            // in most waves): per-axis ownership bits, then eight exec-masked ds_add_u64
+            const bool ax0 = (unsigned)lx < (unsigned)kBrick, ax1 = (unsigned)(lx + 1) < (unsigned)kBrick;
+            const bool ay0 = (unsigned)ly < (unsigned)kBrick, ay1 = (unsigned)(ly + 1) < (unsigned)kBrick;
+            const bool az0 = (unsigned)lz < (unsigned)kBrick, az1 = (unsigned)(lz + 1) < (unsigned)kBrick;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const bool own = ((i & 1) ? ax1 : ax0) && ((i & 2) ? ay1 : ay0) && ((i & 4) ? az1 : az0);
+                if (own)
+                    atomicAdd(tp + ((i & 1) ? kBrick * kBrick : 0) + ((i & 2) ? kBrick : 0) + ((i & 4) ? 1 : 0),
+                              (unsigned long long)(__double_as_longlong(fma((double)((wxy[i & 3] * ((i & 4) ? c.wz1 : c.wz0)) * dpu),
+                                                                           scale, 6755399441055744.0)) -
+                                                   0x4338000000000000LL));   // ds_add_u64
             }
         }
     }
@@ -671,7 +660,7 @@ static int check_tables(const char *op, const RenderDims &D, const genre_tensor 
                       table->size[0] < (1 << 30),
                   "%s: brick table must be a contiguous int32 [rows >= %d, 4] tensor", op, nb);
     GENRE_REQUIRE(is_i32(chunks, 1) && is_contiguous(chunks), "%s: chunk list must be int32 [S]", op);
-    GENRE_REQUIRE((int64_t)D.R * D.R < (1 << 20) && D.ZR <= 256, "%s: brick path needs R*R < 2^20 and ZR <= 256", op);
+    GENRE_REQUIRE((int64_t)D.R * D.R < (1 << 24) && D.ZR <= 256, "%s: brick path needs R*R < 2^24 and ZR <= 256", op);
     GENRE_REQUIRE(D.N * D.NC <= 65535, "%s: N*NC must be <= 65535", op);
     rows = (int)table->size[0];
     return 1;

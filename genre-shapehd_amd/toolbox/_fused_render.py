@@ -18,9 +18,9 @@ from torch.autograd.function import once_differentiable
 from .calc_prob.calc_prob._ext import _loader
 
 BRICK = 16              # must match kBrick in csrc/sph_render.hip
-SPLIT_BWD = 512         # backward rows above this many 16-sample chunks are split (atomic flush)
-SPLIT_FWD = 1024        # forward rows may be split freely (every sample is written exactly once) ...
-SPLIT_FWD_SMALL = 256   # ... more finely when fewer than SMALL_BATCH images have to fill 256 CUs
+SPLIT_BWD = 8192        # backward rows above this many samples are split (atomic flush)
+SPLIT_FWD = 16384       # forward rows may be split freely (every sample is written exactly once) ...
+SPLIT_FWD_SMALL = 4096  # ... more finely when fewer than SMALL_BATCH images have to fill 256 CUs
 SMALL_BATCH = 4
 _TABLES = {}
 
@@ -29,20 +29,12 @@ def available():
     return _loader().has_symbol("genre_render_spherical_forward")
 
 
-def _chunk_rows(bricks, q, k, nb, split, shared_mode):
-    """sorted (brick, q, k) triples -> (table [rows,4], chunk words): runs of consecutive k of one ray
-    inside one brick cut into chunks of <= 16 samples; rows = (brick, begin, end, mode) heaviest first"""
-    n = len(bricks)
-    new_run = np.ones(n, bool)
-    new_run[1:] = (bricks[1:] != bricks[:-1]) | (q[1:] != q[:-1]) | (k[1:] != k[:-1] + 1)
-    run_start = np.maximum.accumulate(np.where(new_run, np.arange(n), 0))
-    starts = np.flatnonzero((np.arange(n) - run_start) % 16 == 0)
-    lens = np.diff(np.append(starts, n))
-    assert n == 0 or (lens.min() >= 1 and lens.max() <= 16)
-    words = ((q[starts] << 12) | (k[starts] << 4) | (lens - 1)).astype(np.uint32).view(np.int32)
-    cb = bricks[starts]
-    begin = np.searchsorted(cb, np.arange(nb), side="left")
-    end = np.searchsorted(cb, np.arange(nb), side="right")
+def _rows(bricks, q, k, nb, split, shared_mode):
+    """sorted (brick, q, k) triples -> (table [rows,4], sample words (q << 8) | k); rows = (brick, begin, end,
+    mode) heaviest first, bricks with more than `split` samples cut into several rows"""
+    words = ((q << 8) | k).astype(np.uint32).view(np.int32)
+    begin = np.searchsorted(bricks, np.arange(nb), side="left")
+    end = np.searchsorted(bricks, np.arange(nb), side="right")
     rows = []
     for b in range(nb):
         cnt = int(end[b] - begin[b])
@@ -66,10 +58,11 @@ def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT_BWD, split_fwd=SPLIT_
     int32 arrays:
       bwd_table/bwd_chunks : every sample listed under each brick one of its 8 corners falls in
       fwd_table/fwd_chunks : every in-volume sample listed once, under the brick of its base corner
+                             (list entries are (ray << 8) | k, sorted by brick, ray, sample)
       kin                  : per ray, the first sample with a corner inside the volume (the inside
                              samples of a ray are always a suffix: rays end at the centre)"""
     R = dirs64.shape[0]
-    assert z_res <= 256 and R * R < (1 << 20)
+    assert z_res <= 256 and R * R < (1 << 24)
     d2 = dirs64.reshape(-1, 3).astype(np.float64) * 2.0
     step = 1.0 / (z_res - 1) if z_res > 1 else 0.0
     alpha = np.arange(z_res, dtype=np.float64) * step
@@ -98,7 +91,7 @@ def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT_BWD, split_fwd=SPLIT_
     def finish(keys, split_at, mode):
         keys = np.sort(np.concatenate(keys)) if keys else np.zeros((0,), np.int64)
         sid = keys & 0xFFFFFFFF
-        return _chunk_rows((keys >> 32).astype(np.int64), sid // z_res, sid % z_res, nb, split_at, mode)
+        return _rows((keys >> 32).astype(np.int64), sid // z_res, sid % z_res, nb, split_at, mode)
 
     bkeys = []
     for cx in axes[0]:

@@ -184,10 +184,9 @@ int genre_nnd_backward(const genre_tensor *xyz1, const genre_tensor *xyz2,
  *                trilinear value of every in-volume sample, layout [ray][k]
  *   fwd_table  : int32 [rows,4] = (brick id, begin, end, 0): rows of fwd_chunks handled by
  *                one workgroup; brick id = (bx*nby+by)*nbz+bz over 16^3-voxel bricks
- *   fwd_chunks : int32 [S], entry (ray i*R+j) << 12 | k0 << 4 | (len-1): samples
- *                k0..k0+len-1 (len <= 16) of that ray; every sample with at least one
+ *   fwd_chunks : int32 [S], entry (ray i*R+j) << 8 | k; every sample with at least one
  *                trilinear corner inside the volume appears exactly once, under the brick
- *                of its (clamped) base corner
+ *                of its (clamped) base corner, sorted by (brick, ray, k)
  *   kin        : int32 [R*R], first such sample of each ray (they form a suffix)
  * pre_scale != 0 (brick path only): the rendered volume is
  * clamp(vox * pre_scale, 1e-5, 1-1e-5) formed on the fly -- the caller-side
