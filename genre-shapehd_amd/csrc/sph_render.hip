@@ -330,10 +330,10 @@ __global__ __launch_bounds__(kBlock) void render_sample_brick_kernel(RenderDims 
               oz = (brick % nbz) * kBrick - 1;                            // tile origin (incl. halo)
     const float *__restrict__ base = vox.p + (img / D.NC) * vox.s0 + (img % D.NC) * vox.s1;
     for (int t = threadIdx.x; t < kTile * kTile * kTile; t += kBlock) {
-        const int lz = t % kTile, ly = (t / kTile) % kTile, lx = t / (kTile * kTile);
+        const int lx = t / (kTile * kTile), r = t - lx * (kTile * kTile), ly = r / kTile, lz = r - ly * kTile;
         const int x = ox + lx, y = oy + ly, z = oz + lz;
         float val = 0.f;
-        if (x >= 0 && x < D.X && y >= 0 && y < D.Y && z >= 0 && z < D.Z) {
+        if ((unsigned)x < (unsigned)D.X && (unsigned)y < (unsigned)D.Y && (unsigned)z < (unsigned)D.Z) {
             val = base[x * D.sx + y * D.sy + z * D.sz];
             if (D.pre_scale != 0.0f) val = fminf(fmaxf(val * D.pre_scale, D.lo), D.hi);   // depth_pred_with_sph_inpaint.py:124
         }
@@ -377,7 +377,9 @@ __device__ __forceinline__ void load_v4(const float *__restrict__ vray, int kb, 
     }
 }
 
-// forward scan over the raw values.  grid = (blocks, N*NC); a wave keeps two rays in flight.
+// forward scan over the raw values.  grid = (blocks, N*NC).  A wave owns rays w0, w0+nw, ... (<= 64 of them):
+// their kin[] entries (which gate the v loads) are fetched up front with ONE load, one per lane, so the loop
+// has no dependent load chain, and two rays are in flight per iteration.
 __global__ __launch_bounds__(kBlock) void render_scan_fwd_kernel(RenderDims D, const float *__restrict__ vbuf,
                                                                   const int *__restrict__ kin,
                                                                   const float *__restrict__ dw, View4 out)
@@ -388,28 +390,36 @@ __global__ __launch_bounds__(kBlock) void render_scan_fwd_kernel(RenderDims D, c
     const int nw = gridDim.x * kWavesPerBlock;
     const float *__restrict__ vimg = vbuf + (int64_t)img * rr * D.ZR;
     float *oimg = out.p + (img / D.NC) * out.s0 + (img % D.NC) * out.s1;
-    for (int q = w0; q < rr; q += 2 * nw) {
-        const int qb = q + nw;
-        const bool hasb = qb < rr;
-        float va[4], vb[4];
-        load_v4(vimg + (int64_t)q * D.ZR, kb, kin[q], D.ZR, va);
-        load_v4(vimg + (int64_t)(hasb ? qb : q) * D.ZR, kb, kin[hasb ? qb : q], D.ZR, vb);
-        float p[4];
-        bool pass[4];
-        double carry = 1.0;
-        clamp4(D, va, kb, p, pass);
-        double total = wave_sum(expect4(D, p, dw, kb, lane, carry)) + carry;
-        if (lane == 0) oimg[(q / D.R) * out.s2 + (q % D.R) * out.s3] = (float)total;
-        if (hasb) {
-            carry = 1.0;
-            clamp4(D, vb, kb, p, pass);
-            total = wave_sum(expect4(D, p, dw, kb, lane, carry)) + carry;
-            if (lane == 0) oimg[(qb / D.R) * out.s2 + (qb % D.R) * out.s3] = (float)total;
+    for (int qbase = w0; qbase < rr; qbase += 64 * nw) {
+        const int myq = qbase + lane * nw;
+        const int mykin = myq < rr ? kin[myq] : D.ZR;
+        for (int it = 0; it < 64; it += 2) {
+            const int q = qbase + it * nw;
+            if (q >= rr) break;
+            const int qb = q + nw;
+            const bool hasb = qb < rr;
+            float va[4], vb[4];
+            load_v4(vimg + (int64_t)q * D.ZR, kb, __builtin_amdgcn_readlane(mykin, it), D.ZR, va);
+            load_v4(vimg + (int64_t)(hasb ? qb : q) * D.ZR, kb, __builtin_amdgcn_readlane(mykin, hasb ? it + 1 : it),
+                    D.ZR, vb);
+            float p[4];
+            bool pass[4];
+            double carry = 1.0;
+            clamp4(D, va, kb, p, pass);
+            double total = wave_sum(expect4(D, p, dw, kb, lane, carry)) + carry;
+            if (lane == 0) oimg[(q / D.R) * out.s2 + (q % D.R) * out.s3] = (float)total;
+            if (hasb) {
+                carry = 1.0;
+                clamp4(D, vb, kb, p, pass);
+                total = wave_sum(expect4(D, p, dw, kb, lane, carry)) + carry;
+                if (lane == 0) oimg[(qb / D.R) * out.s2 + (qb % D.R) * out.s3] = (float)total;
+            }
         }
     }
 }
 
-// backward scan: v -> dL/dp (same maths as render_bwd_dp_kernel without the sampling)
+// backward scan: v -> dL/dp (same maths as render_bwd_dp_kernel without the sampling); kin[] and the rays'
+// output gradients are prefetched one per lane like above
 __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, const float *__restrict__ vbuf,
                                                                   const int *__restrict__ kin,
                                                                   const float *__restrict__ dw, View4 gout,
@@ -424,26 +434,33 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
     float *__restrict__ dimg = dpbuf + (int64_t)img * rr * D.ZR;
     const float *gimg = gout.p + (img / D.NC) * gout.s0 + (img % D.NC) * gout.s1;
     float wmax = 0.f;
-    for (int q = w0; q < rr; q += 2 * nw) {
-        const int qb = q + nw;
-        const bool hasb = qb < rr;
-        const int q2 = hasb ? qb : q;
-        float va[4], vb[4];
-        load_v4(vimg + (int64_t)q * D.ZR, kb, kin[q], D.ZR, va);
-        load_v4(vimg + (int64_t)q2 * D.ZR, kb, kin[q2], D.ZR, vb);
-        const float ga = gimg[(q / D.R) * gout.s2 + (q % D.R) * gout.s3];
-        const float gb = gimg[(q2 / D.R) * gout.s2 + (q2 % D.R) * gout.s3];
-        float p[4], dp[4];
-        bool pass[4];
-        dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
-        if (ga != 0.0f) { clamp4(D, va, kb, p, pass); dp4(D, p, pass, dw, ga, lane, dp); }
-        wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
-        store_dp(D, dimg + (int64_t)q * D.ZR + kb, lane, dp);
-        if (hasb) {
+    for (int qbase = w0; qbase < rr; qbase += 64 * nw) {
+        const int myq = qbase + lane * nw;
+        const int mykin = myq < rr ? kin[myq] : D.ZR;
+        const float myg = myq < rr ? gimg[(myq / D.R) * gout.s2 + (myq % D.R) * gout.s3] : 0.f;
+        for (int it = 0; it < 64; it += 2) {
+            const int q = qbase + it * nw;
+            if (q >= rr) break;
+            const int qb = q + nw;
+            const bool hasb = qb < rr;
+            const int itb = hasb ? it + 1 : it, q2 = hasb ? qb : q;
+            float va[4], vb[4];
+            load_v4(vimg + (int64_t)q * D.ZR, kb, __builtin_amdgcn_readlane(mykin, it), D.ZR, va);
+            load_v4(vimg + (int64_t)q2 * D.ZR, kb, __builtin_amdgcn_readlane(mykin, itb), D.ZR, vb);
+            const float ga = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(myg), it));
+            const float gb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(myg), itb));
+            float p[4], dp[4];
+            bool pass[4];
             dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
-            if (gb != 0.0f) { clamp4(D, vb, kb, p, pass); dp4(D, p, pass, dw, gb, lane, dp); }
+            if (ga != 0.0f) { clamp4(D, va, kb, p, pass); dp4(D, p, pass, dw, ga, lane, dp); }
             wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
-            store_dp(D, dimg + (int64_t)qb * D.ZR + kb, lane, dp);
+            store_dp(D, dimg + (int64_t)q * D.ZR + kb, lane, dp);
+            if (hasb) {
+                dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
+                if (gb != 0.0f) { clamp4(D, vb, kb, p, pass); dp4(D, p, pass, dw, gb, lane, dp); }
+                wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
+                store_dp(D, dimg + (int64_t)qb * D.ZR + kb, lane, dp);
+            }
         }
     }
     publish_max(wmax, lane, dpmax_bits);
