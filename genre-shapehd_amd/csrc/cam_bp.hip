@@ -560,15 +560,26 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
     return 1;
 }
 
-// The camera forward has two implementations.  Default: fill + scatter + normalise (three launches, hardware
-// float atomics; fastest measured: 6.4 us/image at batch 32, ~13 us at batch 1; sums of voxels hit more than
-// once depend on atomic order, as in the reference).  GENRE_CAMBP_GATHER=1 selects the single-launch gather
-// kernel: deterministic and bit-identical to the serial reference order, 7.4 us/image at batch 32 but ~48 us
-// at batch 1 (a live brick is one long divergent workgroup).  The spherical path always scatters.
-inline bool use_scatter_camera()
+// The camera forward has two implementations (GENRE_CAMBP_MODE = scatter | gather):
+//  scatter  (default) fill + scatter + normalise: three launches, hardware float atomics; 5.5-6.4 us/image at
+//           batch 32, ~13 us at batch 1; sums of voxels hit more than once depend on atomic order, as in the
+//           reference.
+//  gather   cam_gather_kernel: one launch, deterministic and bit-identical to the serial reference order;
+//           7.4 us/image at batch 32, ~48 us at batch 1 (a live brick is one long divergent workgroup).
+// (A third, slab-owned single-launch variant -- one x-plane quarter per workgroup accumulated in LDS -- was
+// measured at 9-11 us/image at batch 32 and 18 us at batch 1: its pixel screen is one exposed global-load
+// latency per batch of loads and never beat the three short launches, so it was dropped.)
+// The spherical path always scatters.
+enum CamMode { kScatter, kGather };
+inline CamMode cam_mode()
 {
-    static const bool v = [] { const char *e = getenv("GENRE_CAMBP_GATHER"); return !(e && e[0] == '1'); }();
-    return v;
+    static const CamMode m = [] {
+        const char *e = getenv("GENRE_CAMBP_MODE");
+        if (e) return e[0] == 'g' ? kGather : kScatter;
+        const char *g = getenv("GENRE_CAMBP_GATHER");
+        return (g && g[0] == '1') ? kGather : kScatter;
+    }();
+    return m;
 }
 
 template <bool SPH>
@@ -610,13 +621,14 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
             fill_val = 1.0f - (float)mx * empty_val;
         }
     }
-    if (!SPH && !use_scatter_camera()) {
-        // single-launch gather formulation (see cam_gather_kernel); bias of K2 (:304,:829) = 1/max(res)
+    const CamMode mode = SPH ? kScatter : cam_mode();
+    if (mode != kScatter) {
         const int64_t nvox = (int64_t)D.X * D.Y * D.Z;
         if (nvox == 0 || D.N * D.NC == 0) return 1;
         GENRE_REQUIRE(D.N * D.NC <= 65535, "%s: N*NC must be <= 65535", op);
-        const int bricks = ((D.X + kGX - 1) / kGX) * ((D.Y + kGY - 1) / kGY) * ((D.Z + kGZ - 1) / kGZ);
         const float prefill = (float)(1.0 / (double)D.X);               // cam_back_projection.py:23-24 (res = X)
+        const float bias = 1.0f / (float)mx;                             // K2: dist_bias / max(res)  (:304,:829)
+        const int bricks = ((D.X + kGX - 1) / kGX) * ((D.Y + kGY - 1) / kGY) * ((D.Z + kGZ - 1) / kGZ);
         // float4 fill of dead bricks needs unit z stride and 16-byte aligned z-rows in both outputs
         auto rows_aligned = [&](const genre_tensor *t) {
             if (t->stride[4] != 1 || !aligned16(t->data) || (D.Z % 4) != 0) return false;
@@ -626,8 +638,8 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         };
         const int vec_ok = rows_aligned(voxel) && rows_aligned(cnt);
         cam_gather_kernel<<<dim3(bricks, D.N * D.NC), kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel),
-                                                                      view5(cnt), prefill, 1.0f / (float)mx,
-                                                                      post_scale, post_bias, fill_val, vec_ok);
+                                                                      view5(cnt), prefill, bias, post_scale, post_bias,
+                                                                      fill_val, vec_ok);
         GENRE_LAUNCH_CHECK("projection forward (gather)");
         return 1;
     }

@@ -90,9 +90,7 @@ def test_camera_forward_odd_sizes_and_cameras(genre, oracle, dev):
     check_forward_cases(oracle, dev, exact=False)
 
 
-def test_camera_forward_gather_bit_exact_subprocess(dev):
-    """GENRE_CAMBP_GATHER=1: the single-launch gather kernel sums a voxel's points in the reference's serial
-    pixel order -- tdf must equal the CPU oracle BIT FOR BIT on every voxel and repeat exactly"""
+def _run_cases_in_subprocess(mode, exact):
     import os
     import subprocess
     import sys
@@ -103,11 +101,17 @@ def test_camera_forward_gather_bit_exact_subprocess(dev):
         "from oracle.oracle import Oracle\n"
         "import genre_shapehd_amd\n"
         "import test_gpu_cam_bp as T\n"
-        "T.check_forward_cases(Oracle(), torch.device('cuda:0'), exact=True)\n"
-        "print('ok')\n" % (root, os.path.join(root, "tests")))
-    env = dict(os.environ, GENRE_CAMBP_GATHER="1")
+        "T.check_forward_cases(Oracle(), torch.device('cuda:0'), exact=%r)\n"
+        "print('ok')\n" % (root, os.path.join(root, "tests"), exact))
+    env = dict(os.environ, GENRE_CAMBP_MODE=mode)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_camera_forward_gather_bit_exact_subprocess(dev):
+    """GENRE_CAMBP_MODE=gather: the single-launch gather kernel sums a voxel's points in the reference's serial
+    pixel order -- tdf must equal the CPU oracle BIT FOR BIT on every voxel and repeat exactly"""
+    _run_cases_in_subprocess("gather", True)
 
 
 def test_camera_forward_is_idempotent_on_dirty_outputs(genre, oracle, dev):
