@@ -329,31 +329,50 @@ __global__ __launch_bounds__(kBlock) void render_sample_brick_kernel(RenderDims 
     const int ox = (brick / (nby * nbz)) * kBrick - 1, oy = ((brick / nbz) % nby) * kBrick - 1,
               oz = (brick % nbz) * kBrick - 1;                            // tile origin (incl. halo)
     const float *__restrict__ base = vox.p + (img / D.NC) * vox.s0 + (img % D.NC) * vox.s1;
-    for (int t = threadIdx.x; t < kTile * kTile * kTile; t += kBlock) {
+    // all of a thread's tile elements are requested before the first one is used: written as a plain loop the
+    // compiler waits for every load in turn (23 exposed latencies per workgroup)
+    constexpr int kPerThread = (kTile * kTile * kTile + kBlock - 1) / kBlock;
+    float vals[kPerThread];
+#pragma unroll
+    for (int i = 0; i < kPerThread; i++) {
+        const int t = threadIdx.x + i * kBlock;
         const int lx = t / (kTile * kTile), r = t - lx * (kTile * kTile), ly = r / kTile, lz = r - ly * kTile;
         const int x = ox + lx, y = oy + ly, z = oz + lz;
-        float val = 0.f;
-        if ((unsigned)x < (unsigned)D.X && (unsigned)y < (unsigned)D.Y && (unsigned)z < (unsigned)D.Z) {
-            val = base[x * D.sx + y * D.sy + z * D.sz];
-            if (D.pre_scale != 0.0f) val = fminf(fmaxf(val * D.pre_scale, D.lo), D.hi);   // depth_pred_with_sph_inpaint.py:124
+        vals[i] = 0.f;
+        if (t < kTile * kTile * kTile && (unsigned)x < (unsigned)D.X && (unsigned)y < (unsigned)D.Y &&
+            (unsigned)z < (unsigned)D.Z) {
+            vals[i] = base[x * D.sx + y * D.sy + z * D.sz];
+            if (D.pre_scale != 0.0f) vals[i] = fminf(fmaxf(vals[i] * D.pre_scale, D.lo), D.hi);   // depth_pred_with_sph_inpaint.py:124
         }
-        tile[t] = val;
+    }
+#pragma unroll
+    for (int i = 0; i < kPerThread; i++) {
+        const int t = threadIdx.x + i * kBlock;
+        if (t < kTile * kTile * kTile) tile[t] = vals[i];
     }
     __syncthreads();
     float *__restrict__ vi = vbuf + (int64_t)img * D.R * D.R * D.ZR;
     // one lane per listed sample (entries are sorted by ray, then sample: neighbouring lanes mostly share the
     // ray, so the direction loads coalesce to a few addresses and the v stores to 64-byte runs)
-    for (int e0 = begin + threadIdx.x; e0 < end; e0 += 2 * kBlock) {
-        const int e1 = e0 + kBlock;
-        const unsigned ent0 = (unsigned)fwd_list[e0];
-        const unsigned ent1 = e1 < end ? (unsigned)fwd_list[e1] : ent0;
+    for (int e0 = begin + threadIdx.x; e0 < end; e0 += 4 * kBlock) {
+        unsigned ent[4];
+        double d2[4][3];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            if (u == 1 && e1 >= end) break;
-            const unsigned ent = u ? ent1 : ent0;
-            const int q = (int)(ent >> 8), k = (int)(ent & 255u);
+        for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * kBlock;
+            ent[u] = (unsigned)fwd_list[e < end ? e : e0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = (int)(ent[u] >> 8);
+            d2[u][0] = dirs[q * 3 + 0]; d2[u][1] = dirs[q * 3 + 1]; d2[u][2] = dirs[q * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (e0 + u * kBlock >= end) break;
+            const int q = (int)(ent[u] >> 8), k = (int)(ent[u] & 255u);
             float gx, gy, gz;
-            sample_pos(D, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, k, gx, gy, gz);
+            sample_pos(D, d2[u][0] * 2, d2[u][1] * 2, d2[u][2] * 2, k, gx, gy, gz);
             Cell c;
             locate(D, gx, gy, gz, c);
             const float *tp = tile + ((c.x0 - ox) * kTile + (c.y0 - oy)) * kTile + (c.z0 - oz);
@@ -504,15 +523,20 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
             const int e = e0 + u * kBlock;
             ent[u] = e < end ? (unsigned)chunk_list[e] : 0xffffffffu;
         }
+        double d2[4][3];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            dp[u] = ent[u] != 0xffffffffu ? dpi[(int64_t)(ent[u] >> 8) * D.ZR + (ent[u] & 255u)] : 0.f;
+        for (int u = 0; u < 4; u++) {
+            const bool ok = ent[u] != 0xffffffffu;
+            const int q = ok ? (int)(ent[u] >> 8) : 0;
+            dp[u] = ok ? dpi[(int64_t)q * D.ZR + (ent[u] & 255u)] : 0.f;
+            d2[u][0] = dirs[q * 3 + 0]; d2[u][1] = dirs[q * 3 + 1]; d2[u][2] = dirs[q * 3 + 2];
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (dp[u] == 0.0f) continue;
-            const int q = (int)(ent[u] >> 8), k = (int)(ent[u] & 255u);
+            const int k = (int)(ent[u] & 255u);
             float gx, gy, gz;
-            sample_pos(D, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, k, gx, gy, gz);
+            sample_pos(D, d2[u][0] * 2, d2[u][1] * 2, d2[u][2] * 2, k, gx, gy, gz);
             Cell c;
             locate(D, gx, gy, gz, c);
             const int lx = c.x0 - ox, ly = c.y0 - oy, lz = c.z0 - oz;
