@@ -265,14 +265,27 @@ __global__ __launch_bounds__(kBlock) void cam_gather_kernel(Dims D, View4 depth,
     // are tall and narrow (~20 x 130 px), so threads are laid out 32 wide x 8 high.
     Band bb{3.0e38f, 0.0f, 0};
     if (bww > 0 && bwh > 0) {
-        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-        for (int r = ty; r < bwh; r += kBlock / 32)
-            for (int q = tx; q < bww; q += 32) {
-                const float d = dimg[(bw.h0 + r) * depth.s2 + (bw.w0 + q) * depth.s3];
-                if (staged) s_depth[r * bww + q] = d;
+        // 16 pixel loads in flight per thread (a plain loop waits for each load: one exposed latency per pixel)
+        constexpr int kDeep = 16;
+        const int area = bww * bwh;
+        for (int t0 = threadIdx.x; t0 < area; t0 += kDeep * kBlock) {
+            float dv[kDeep];
+#pragma unroll
+            for (int u = 0; u < kDeep; u++) {
+                const int t = t0 + u * kBlock;
+                const int r = t / bww, q = t - r * bww;
+                dv[u] = t < area ? dimg[(bw.h0 + r) * depth.s2 + (bw.w0 + q) * depth.s3] : -1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kDeep; u++) {
+                const int t = t0 + u * kBlock;
+                if (t >= area) continue;
+                const float d = dv[u];
+                if (staged) s_depth[t] = d;
                 if (d > 0.0f) { bb.dmin = fminf(bb.dmin, d); bb.dmax = fmaxf(bb.dmax, d); }
                 else if (!(d < 0.0f)) bb.any_zero = 1;  // d == 0 (or NaN): lands at x = -cam_dist
             }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -565,7 +578,8 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
 //           batch 32, ~13 us at batch 1; sums of voxels hit more than once depend on atomic order, as in the
 //           reference.
 //  gather   cam_gather_kernel: one launch, deterministic and bit-identical to the serial reference order;
-//           7.4 us/image at batch 32, ~48 us at batch 1 (a live brick is one long divergent workgroup).
+//           6.6 us/image at batch 32, ~42 us at batch 1 (in a live brick the exact arithmetic runs on almost
+//           every candidate iteration of a wave, because lanes find their hits at different iterations).
 // (A third, slab-owned single-launch variant -- one x-plane quarter per workgroup accumulated in LDS -- was
 // measured at 9-11 us/image at batch 32 and 18 us at batch 1: its pixel screen is one exposed global-load
 // latency per batch of loads and never beat the three short launches, so it was dropped.)
