@@ -159,8 +159,28 @@ def batch1_graph(G, dev):
         body()
     us = event_time_us(graph.replay, 20, 3) / reps
     nbytes = BYTES_CAM_FWD + BYTES_CP_FWD
-    return dict(us_per_image=us, GBs=nbytes / us / 1e3, frac=nbytes / us / 1e3 / HBM_PEAK_GBS,
-                launches_per_image=4, note="HIP-graph replay of 20x(cam_bp fwd + calc_prob fwd), batch 1")
+    res = dict(us_per_image=us, GBs=nbytes / us / 1e3, frac=nbytes / us / 1e3 / HBM_PEAK_GBS,
+               launches_per_image=4, note="HIP-graph replay of 20x(cam_bp fwd + calc_prob fwd), batch 1")
+    try:        # forward of the whole configs[1] chain at batch 1, also from a graph (never fatal for the bench line)
+        chain = HotPath(G, True).to(dev)
+        with torch.no_grad():
+            for _ in range(3):
+                chain(d)
+            torch.cuda.synchronize()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                chain(d)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                for _ in range(reps):
+                    out = chain(d)
+            res["chain_fwd_us_per_image"] = event_time_us(g2.replay, 20, 3) / reps
+    except Exception as e:      # pragma: no cover
+        res["chain_fwd_us_per_image"] = None
+        res["chain_fwd_error"] = str(e)[:200]
+    return res
 
 
 def cpu_baseline(budget_s):
