@@ -70,8 +70,9 @@ class render_spherical(torch.nn.Module):
         if self.fused is not None:
             return self.fused
         from . import _fused_render
+        # the brick kernels take rays of up to 256 samples in float4 groups; other shapes use the op sequence
         return (_fused_render.available() and vox.is_cuda and vox.dtype == torch.float32
-                and self.z_res <= 256)
+                and self.z_res <= 256 and self.z_res % 4 == 0 and self.sph_res * self.sph_res < (1 << 24))
 
     def forward(self, vox, pre_scale=None):
         """vox [N,C,X,Y,Z] -> [N,C,res,res].  Extension: `pre_scale=s` renders

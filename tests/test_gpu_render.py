@@ -95,3 +95,32 @@ def test_pre_scale_fusion(genre, oracle, dev):
     from oracle.torch_oracle import RenderSphericalCPU
     ref = RenderSphericalCPU(oracle)(torch.clamp(torch.from_numpy(x) * 50.0, 1e-5, 1 - 1e-5))
     assert (oa.detach().cpu() - ref).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("res,sph_res,z_res", [(24, 16, 32), (40, 24, 64), (16, 8, 12), (33, 20, 100)])
+def test_render_odd_geometries(res, sph_res, z_res, genre, oracle, dev):
+    """partial bricks (res not a multiple of 16), small ray fans, short rays: the brick tables are built for
+    any geometry; forward and backward against the CPU restatement, fused vs unfused on the GPU"""
+    from genre_shapehd_amd.toolbox import _fused_render
+    if not _fused_render.available():
+        pytest.skip("fused render kernel not in this build")
+    from oracle.torch_oracle import RenderSphericalCPU
+    rng = np.random.default_rng(res * 1000 + z_res)
+    ax = (np.arange(res) + 0.5) / res - 0.5
+    r2 = ax[:, None, None] ** 2 + (ax[None, :, None] - 0.07) ** 2 + (ax[None, None, :] + 0.04) ** 2
+    v = (0.003 + 0.5 * np.exp(-r2 / 0.03) + rng.uniform(0, 0.02, (res,) * 3)).astype(np.float32)[None, None]
+    v = np.concatenate([v, v[:, :, ::-1].copy()], 0)
+    vc = torch.from_numpy(v).requires_grad_(True)
+    ref = RenderSphericalCPU(oracle, sph_res, z_res)(vc)
+    g = torch.from_numpy(rng.standard_normal(ref.shape).astype(np.float32))
+    ref.backward(g)
+    outs = {}
+    for fused in (True, False):
+        vt = torch.from_numpy(v).to(dev).requires_grad_(True)
+        out = genre.render_spherical(sph_res, z_res, fused=fused).to(dev)(vt)
+        assert out.shape == (2, 1, sph_res, sph_res)
+        out.backward(g.to(dev))
+        outs[fused] = (out.detach().cpu(), vt.grad.cpu())
+        assert (outs[fused][0] - ref.detach()).abs().max().item() <= TOL, (fused, res)
+        d = (outs[fused][1] - vc.grad).abs() / (1 + vc.grad.abs())
+        assert d.max().item() <= 2e-5, (fused, res, d.max().item())
