@@ -116,40 +116,71 @@ __global__ __launch_bounds__(kBlock) void fill2_strided_kernel(Dims D, View5 a, 
 
 // ---- (2) scatter --------------------------------------------------------------
 template <bool SPH>
+__device__ __forceinline__ void scatter_pixel(const Dims &D, const View4 &depth, const View2 &camdist, const View2 &fl,
+                                              const View5 &grid, const View5 &vox, const View5 &cnt, float empty_val,
+                                              float fill_val, int64_t idx)
+{
+    int n, c, h, w;
+    decode_pixel(D, idx, n, c, h, w);
+    float d_raw, gx, gy, gz, u_h, u_w, f;
+    if (!pixel_point<SPH>(D, depth, camdist, fl, grid, n, c, h, w, d_raw, gx, gy, gz, u_h, u_w, f)) return;
+    const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
+    if (!in_grid(D, ix, iy, iz)) return;                             // :252
+    const float dist = norm3(gx - centre_f(ix, D.X), gy - centre_f(iy, D.Y), gz - centre_f(iz, D.Z));
+    float *pc = cnt.p + n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4;
+    float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
+    // Negated accumulation (see file header).  The reference starts every sum at the prefill e = 1/res
+    // (0 on the spherical path) and subtracts it again in K2 (:304): the first point contributes
+    // t = fl(e + dist) - e (exact).  The first arriver reproduces that rounding and cancels whatever
+    // the fill pass wrote; later arrivers just add, as the reference's atomics do.
+    const float t = (dist + empty_val) - empty_val;
+    if (fill_val == 0.0f) {
+        // nothing to cancel (spherical path, and the camera path with the shift folded in): no need to
+        // know who is first, so both atomics are fire-and-forget (no return value, no dependent latency)
+        unsafeAtomicAdd(pc, 1.0f);                                   // :274
+        unsafeAtomicAdd(pv, -t);                                     // :273
+    } else {
+        const float old = unsafeAtomicAdd(pc, 1.0f);                 // hardware global_atomic_add_f32, returning
+        unsafeAtomicAdd(pv, (old == 0.0f) ? -(t + fill_val) : -dist);
+    }
+}
+
+template <bool SPH>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
                                                           View5 grid, View5 vox, View5 cnt, float empty_val,
                                                           float fill_val)
 {
     const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * kBlock) {
-        int n, c, h, w;
-        decode_pixel(D, idx, n, c, h, w);
-        float d_raw, gx, gy, gz, u_h, u_w, f;
-        if (!pixel_point<SPH>(D, depth, camdist, fl, grid, n, c, h, w, d_raw, gx, gy, gz, u_h, u_w, f)) continue;
-        const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
-        if (!in_grid(D, ix, iy, iz)) continue;                       // :252
-        const float dist = norm3(gx - centre_f(ix, D.X), gy - centre_f(iy, D.Y), gz - centre_f(iz, D.Z));
-        float *pc = cnt.p + n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4;
-        float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
-        // Negated accumulation (see file header).  The reference starts every sum at the prefill e = 1/res
-        // (0 on the spherical path) and subtracts it again in K2 (:304): the first point contributes
-        // t = fl(e + dist) - e (exact).  The first arriver reproduces that rounding and cancels whatever
-        // the fill pass wrote; later arrivers just add, as the reference's atomics do.
-        const float t = (dist + empty_val) - empty_val;
-        if (fill_val == 0.0f) {
-            // nothing to cancel (spherical path, and the camera path with the shift folded in): no need to
-            // know who is first, so both atomics are fire-and-forget (no return value, no dependent latency)
-            unsafeAtomicAdd(pc, 1.0f);                               // :274
-            unsafeAtomicAdd(pv, -t);                                 // :273
-        } else {
-            const float old = unsafeAtomicAdd(pc, 1.0f);             // hardware global_atomic_add_f32, returning
-            unsafeAtomicAdd(pv, (old == 0.0f) ? -(t + fill_val) : -dist);
-        }
-    }
+         idx += (int64_t)gridDim.x * kBlock)
+        scatter_pixel<SPH>(D, depth, camdist, fl, grid, vox, cnt, empty_val, fill_val, idx);
 }
 
 // ---- (3) normalise, per pixel ---------------------------------------------------
+template <bool SPH>
+__device__ __forceinline__ void normalise_pixel(const Dims &D, const View4 &depth, const View2 &camdist,
+                                                const View2 &fl, const View5 &grid, const View5 &vox,
+                                                const View5 &cnt, float post_scale, float post_bias, int post_mode,
+                                                int64_t idx)
+{
+    int n, c, h, w;
+    decode_pixel(D, idx, n, c, h, w);
+    float d_raw, gx, gy, gz, u_h, u_w, f;
+    if (!pixel_point<SPH>(D, depth, camdist, fl, grid, n, c, h, w, d_raw, gx, gy, gz, u_h, u_w, f)) return;
+    const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
+    if (!in_grid(D, ix, iy, iz)) return;
+    float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
+    const float s = *pv;
+    if (s < 0.0f) {                                                   // still a raw (negated) sum
+        const float k = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
+        // :304 (mean distance); post = identity (scale 1, bias 0), the camera layer's shift 1 - res*tdf
+        // (mode 0 with scale -res, bias 1), or GenRe's spherical glue (-tdf + 1/res)*res (mode 1,
+        // genre_full_model.py:141: post_bias holds 1/res, post_scale holds res)
+        const float mean = (0.0f - s) / k;
+        *pv = post_mode == 1 ? (-mean + post_bias) * post_scale : post_bias + post_scale * mean;
+    }
+}
+
 template <bool SPH>
 __global__ __launch_bounds__(kBlock) void normalise_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
                                                             View5 grid, View5 vox, View5 cnt, float post_scale,
@@ -157,24 +188,8 @@ __global__ __launch_bounds__(kBlock) void normalise_kernel(Dims D, View4 depth, 
 {
     const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * kBlock) {
-        int n, c, h, w;
-        decode_pixel(D, idx, n, c, h, w);
-        float d_raw, gx, gy, gz, u_h, u_w, f;
-        if (!pixel_point<SPH>(D, depth, camdist, fl, grid, n, c, h, w, d_raw, gx, gy, gz, u_h, u_w, f)) continue;
-        const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
-        if (!in_grid(D, ix, iy, iz)) continue;
-        float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
-        const float s = *pv;
-        if (s < 0.0f) {                                               // still a raw (negated) sum
-            const float k = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
-            // :304 (mean distance); post = identity (scale 1, bias 0), the camera layer's shift 1 - res*tdf
-            // (mode 0 with scale -res, bias 1), or GenRe's spherical glue (-tdf + 1/res)*res (mode 1,
-            // genre_full_model.py:141: post_bias holds 1/res, post_scale holds res)
-            const float mean = (0.0f - s) / k;
-            *pv = post_mode == 1 ? (-mean + post_bias) * post_scale : post_bias + post_scale * mean;
-        }
-    }
+         idx += (int64_t)gridDim.x * kBlock)
+        normalise_pixel<SPH>(D, depth, camdist, fl, grid, vox, cnt, post_scale, post_bias, post_mode, idx);
 }
 
 // ---- camera forward, single-launch GATHER formulation --------------------------------------------
@@ -582,7 +597,11 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
 //           every candidate iteration of a wave, because lanes find their hits at different iterations).
 // (A third, slab-owned single-launch variant -- one x-plane quarter per workgroup accumulated in LDS -- was
 // measured at 9-11 us/image at batch 32 and 18 us at batch 1: its pixel screen is one exposed global-load
-// latency per batch of loads and never beat the three short launches, so it was dropped.)
+// latency per batch of loads and never beat the three short launches, so it was dropped.  A fourth -- the three
+// phases in ONE launch of co-resident workgroups separated by two device-wide barriers -- was 44 us at batch 1:
+// tools/grid_barrier_bench.hip measures 3.9 us per barrier on 256 workgroups before any fence (256 same-address
+// arrivals at ~10 ns each + the polling), +1.9 us for the L2 write-back and +1.7 us for the invalidate each side
+// needs so that the XCDs' L2s agree; a kernel boundary inside a HIP graph costs ~1 us.)
 // The spherical path always scatters.
 enum CamMode { kScatter, kGather };
 inline CamMode cam_mode()
@@ -657,8 +676,8 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         GENRE_LAUNCH_CHECK("projection forward (gather)");
         return 1;
     }
-    if (!launch_fill2(D, voxel, fill_val, cnt, 0.0f, st)) return 0;
     const int64_t npix = (int64_t)D.N * D.NC * D.H * D.W;
+    if (!launch_fill2(D, voxel, fill_val, cnt, 0.0f, st)) return 0;
     if (npix == 0 || (int64_t)D.X * D.Y * D.Z == 0) return 1;
     const int g = grid_for(npix);
     scatter_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), empty_val, fill_val);

@@ -242,32 +242,35 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
 }
 
-// dL/dp of the lane's 4 samples (ZR <= 256: the whole ray is one chunk), clamp-masked
-__device__ __forceinline__ void dp4(const RenderDims &D, const float (&p)[4], const bool (&pass)[4],
-                                    const float *__restrict__ dw, float g, int lane, float (&dp)[4])
+// dL/dp of the lane's 4 samples (ZR <= 256: the whole ray is one chunk), clamp-masked; w = load_w4()
+__device__ __forceinline__ void dp4w(const float (&p)[4], const bool (&pass)[4], const double (&w)[4], float g,
+                                     float (&dp)[4])
 {
-    const int kb = lane * 4;
-    float w[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) w[t] = (kb + t < D.ZR) ? dw[kb + t] : 0.f;
     const double q0 = 1.0 - (double)p[0], q1 = 1.0 - (double)p[1], q2 = 1.0 - (double)p[2], q3 = 1.0 - (double)p[3];
     const double e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
     const double incl = wave_incl_prod(tot);
     const double excl = wave_prev(1.0, incl);
     const double prod_all = wave_last(incl);
-    const double T0 = excl, T1 = excl * q0, T2 = excl * e2, T3 = excl * e3;       // transmittance before k
-    const double sw0 = (double)p[0] * T0 * (double)w[0], sw1 = (double)p[1] * T1 * (double)w[1];
-    const double sw2 = (double)p[2] * T2 * (double)w[2], sw3 = (double)p[3] * T3 * (double)w[3];
+    const double Tw0 = excl * w[0], Tw1 = (excl * q0) * w[1], Tw2 = (excl * e2) * w[2], Tw3 = (excl * e3) * w[3];
+    const double sw0 = (double)p[0] * Tw0, sw1 = (double)p[1] * Tw1;      // s_k w_k, T_k = transmittance before k
+    const double sw2 = (double)p[2] * Tw2, sw3 = (double)p[3] * Tw3;
     const double lane_sw = ((sw3 + sw2) + sw1) + sw0;
     const double incl_s = wave_incl_sum(lane_sw);                        // prefix over lanes <= lane
     const double after = (wave_last(incl_s) - incl_s) + prod_all;        // suffix; prod(1-p) joins it
     const double A3 = after, A2 = after + sw3, A1 = after + (sw3 + sw2), A0 = after + ((sw3 + sw2) + sw1);
     const double gd = (double)g;
     // fp32 divides for A/(1-p) (an fp64 divide is ~30 instructions); everything feeding them is fp64
-    dp[0] = pass[0] ? (float)(gd * (T0 * (double)w[0] - (double)((float)A0 / (1.0f - p[0])))) : 0.f;
-    dp[1] = pass[1] ? (float)(gd * (T1 * (double)w[1] - (double)((float)A1 / (1.0f - p[1])))) : 0.f;
-    dp[2] = pass[2] ? (float)(gd * (T2 * (double)w[2] - (double)((float)A2 / (1.0f - p[2])))) : 0.f;
-    dp[3] = pass[3] ? (float)(gd * (T3 * (double)w[3] - (double)((float)A3 / (1.0f - p[3])))) : 0.f;
+    dp[0] = pass[0] ? (float)(gd * (Tw0 - (double)((float)A0 / (1.0f - p[0])))) : 0.f;
+    dp[1] = pass[1] ? (float)(gd * (Tw1 - (double)((float)A1 / (1.0f - p[1])))) : 0.f;
+    dp[2] = pass[2] ? (float)(gd * (Tw2 - (double)((float)A2 / (1.0f - p[2])))) : 0.f;
+    dp[3] = pass[3] ? (float)(gd * (Tw3 - (double)((float)A3 / (1.0f - p[3])))) : 0.f;
+}
+__device__ __forceinline__ void dp4(const RenderDims &D, const float (&p)[4], const bool (&pass)[4],
+                                    const float *__restrict__ dw, float g, int lane, float (&dp)[4])
+{
+    double w[4];
+    load_w4(D, dw, lane * 4, w);
+    dp4w(p, pass, w, g, dp);
 }
 
 __device__ __forceinline__ void lane_dp(const RenderDims &D, const float *__restrict__ base, double dx2, double dy2,
@@ -480,6 +483,8 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
     float *__restrict__ dimg = dpbuf + (int64_t)img * rr * D.ZR;
     const float *gimg = gout.p + (img / D.NC) * gout.s0 + (img % D.NC) * gout.s1;
     float wmax = 0.f;
+    double w4[4];
+    load_w4(D, dw, kb, w4);
     for (int qbase = w0; qbase < rr; qbase += 64 * nw) {
         const int myq = qbase + lane * nw;
         const int mykin = myq < rr ? kin[myq] : D.ZR;
@@ -498,12 +503,12 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
             float p[4], dp[4];
             bool pass[4];
             dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
-            if (ga != 0.0f) { clamp4(D, va, kb, p, pass); dp4(D, p, pass, dw, ga, lane, dp); }
+            if (ga != 0.0f) { clamp4(D, va, kb, p, pass); dp4w(p, pass, w4, ga, dp); }
             wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
             store_dp(D, dimg + (int64_t)q * D.ZR + kb, lane, dp);
             if (hasb) {
                 dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
-                if (gb != 0.0f) { clamp4(D, vb, kb, p, pass); dp4(D, p, pass, dw, gb, lane, dp); }
+                if (gb != 0.0f) { clamp4(D, vb, kb, p, pass); dp4w(p, pass, w4, gb, dp); }
                 wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
                 store_dp(D, dimg + (int64_t)qb * D.ZR + kb, lane, dp);
             }
@@ -572,7 +577,9 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
             // fp64 fma with the power-of-two scale and 1.5*2^52: the sum is an integer in the mantissa
             // (|value| <= 2^44) -- cvt + fma + a subtract on the high word per corner
             const float wxy[4] = {c.wx0 * c.wy0, c.wx1 * c.wy0, c.wx0 * c.wy1, c.wx1 * c.wy1};
-            const float dpu = dp[u];
+            // dL/dp joins the z weight once per sample instead of once per corner (one fp32 rounding placed
+            // differently from ATen's ((wx*wy)*wz)*g -- far below the fixed-point quantum)
+            const float wzd0 = c.wz0 * dp[u], wzd1 = c.wz1 * dp[u];
             // ONE predicated path (a fast "all corners inside" branch would run in addition to the general one
             // in most waves): per-axis ownership bits, then eight exec-masked ds_add_u64
             const bool ax0 = (unsigned)lx < (unsigned)kBrick, ax1 = (unsigned)(lx + 1) < (unsigned)kBrick;
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                 const bool own = ((i & 1) ? ax1 : ax0) && ((i & 2) ? ay1 : ay0) && ((i & 4) ? az1 : az0);
                 if (own)
                     atomicAdd(tp + ((i & 1) ? kBrick * kBrick : 0) + ((i & 2) ? kBrick : 0) + ((i & 4) ? 1 : 0),
-                              (unsigned long long)(__double_as_longlong(fma((double)((wxy[i & 3] * ((i & 4) ? c.wz1 : c.wz0)) * dpu),
+                              (unsigned long long)(__double_as_longlong(fma((double)(wxy[i & 3] * ((i & 4) ? wzd1 : wzd0)),
                                                                            scale, 6755399441055744.0)) -
                                                    0x4338000000000000LL));   // ds_add_u64
             }
