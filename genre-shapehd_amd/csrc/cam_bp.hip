@@ -438,6 +438,12 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Four pixels per thread are in flight (depth loads, then the dependent cnt / grad_in gathers, then the
+// arithmetic), and the launch keeps the TOTAL number of workgroups near 512: grad_fl / grad_camdist of all
+// images share one cache line each, and same-line float atomics retire at ~10 ns apiece -- 8192 workgroups
+// (256 per image at batch 32) made this kernel 85 us of atomic queueing around 3 us of work.
+constexpr int kBwdUnroll = 4;
+
 __global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 depth, View2 fl, View2 camdist,
                                                                View5 cnt, View5 gin, View4 gdepth,
                                                                View2 gcam, View2 gfl, float gscale)
@@ -447,36 +453,72 @@ __global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 dept
     const int n = img / D.NC, c = img % D.NC;
     const int npix = D.H * D.W;
     double acc_fl = 0.0, acc_cd = 0.0;
-    const View5 nogrid = {nullptr, 0, 0, 0, 0, 0};
-    for (int p = blockIdx.x * kBlock + threadIdx.x; p < npix; p += gridDim.x * kBlock) {
-        const int h = p / D.W, w = p % D.W;
-        float gd_out = 0.0f;
-        float d_i, gx, gy, gz, u_h, u_w, f;
-        if (pixel_point<false>(D, depth, camdist, fl, nogrid, n, c, h, w, d_i, gx, gy, gz, u_h, u_w, f)) {
-            const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
-            if (in_grid(D, ix, iy, iz)) {
-                const float cx = centre_d(ix, D.X), cy = centre_d(iy, D.Y), cz = centre_d(iz, D.Z);
-                float L = norm3(u_h, u_w, f);                           // :432
-                if ((double)L < 1e-5) L = (float)1e-5;
-                const float rx = -f / L, ry = u_w / L, rz = u_h / L;    // :436-438
-                float Dn = norm3(gx - cx, gy - cy, gz - cz);            // :440
-                if ((double)Dn < 1e-5) Dn = (float)1e-5;
-                const float qx = (gx - cx) / Dn, qy = (gy - cy) / Dn, qz = (gz - cz) / Dn;
-                const float cos_cc = (rx * qx) + (ry * qy) + (rz * qz); // :448
-                float ptnum = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
-                if (ptnum < 1.0f) ptnum = 1.0f;
-                // gscale = 1, or -res when the incoming gradient is w.r.t. the shifted output 1 - res*tdf
-                const float gd = gin.p[n * gin.s0 + c * gin.s1 + ix * gin.s2 + iy * gin.s3 + iz * gin.s4] * gscale;
-                gd_out = -gd * cos_cc / ptnum;                          // :455
-                const float L3 = L * L * L;
-                const float gfx = ((gx - cx) / Dn) * (u_w * u_w + u_h * u_h) / L3;   // :459
-                const float gfy = ((gy - cy) / Dn) * (u_w * f) / L3;                 // :460
-                const float gfz = ((gz - cz) / Dn) * (u_h * f) / L3;                 // :461
-                acc_fl += (double)((gfx + gfy + gfz) * gd * d_i / ptnum);            // :462
-                acc_cd += (double)(-qx * gd / ptnum);                                // :469
+    const float f = fl.p[n * fl.s0 + c * fl.s1];
+    const float cam_dist = camdist.p[n * camdist.s0 + c * camdist.s1];
+    const float *dimg = depth.p + n * depth.s0 + c * depth.s1;
+    float *gdimg = gdepth.p + n * gdepth.s0 + c * gdepth.s1;
+    const float *cimg = cnt.p + n * cnt.s0 + c * cnt.s1;
+    const float *gimg = gin.p + n * gin.s0 + c * gin.s1;
+    for (int p0 = blockIdx.x * (kBlock * kBwdUnroll) + threadIdx.x; p0 < npix;
+         p0 += gridDim.x * (kBlock * kBwdUnroll)) {
+        float d_i[kBwdUnroll], gx[kBwdUnroll], gy[kBwdUnroll], gz[kBwdUnroll], u_h[kBwdUnroll], u_w[kBwdUnroll];
+        float ptnum[kBwdUnroll], gd[kBwdUnroll];
+        int ix[kBwdUnroll], iy[kBwdUnroll], iz[kBwdUnroll];
+        bool live[kBwdUnroll];
+#pragma unroll
+        for (int u = 0; u < kBwdUnroll; u++) {
+            const int p = p0 + u * kBlock;
+            d_i[u] = -1.0f;
+            if (p < npix) d_i[u] = dimg[(p / D.W) * depth.s2 + (p % D.W) * depth.s3];
+        }
+#pragma unroll
+        for (int u = 0; u < kBwdUnroll; u++) {
+            const int p = p0 + u * kBlock;
+            const int h = p / D.W, w = p % D.W;
+            live[u] = !(d_i[u] < 0.0f);                                 // :225
+            // camera model of :231-242 (same sequence as pixel_point<false>)
+            u_h[u] = (float)h - ((float)D.H - 1.0f) / 2.0f;
+            u_w[u] = (float)w - ((float)D.W - 1.0f) / 2.0f;
+            const float cos_theta = f / norm3(u_h[u], u_w[u], f);
+            const float d = d_i[u] * cos_theta;
+            gy[u] = -d * u_w[u] / f;
+            gz[u] = -d * u_h[u] / f;
+            gx[u] = d - cam_dist;
+            ix[u] = vox_index(gx[u], D.X); iy[u] = vox_index(gy[u], D.Y); iz[u] = vox_index(gz[u], D.Z);
+            live[u] = live[u] && in_grid(D, ix[u], iy[u], iz[u]);
+            ptnum[u] = 1.0f; gd[u] = 0.0f;
+            if (live[u]) {
+                ptnum[u] = cimg[ix[u] * cnt.s2 + iy[u] * cnt.s3 + iz[u] * cnt.s4];
+                gd[u] = gimg[ix[u] * gin.s2 + iy[u] * gin.s3 + iz[u] * gin.s4];
             }
         }
-        gdepth.p[n * gdepth.s0 + c * gdepth.s1 + h * gdepth.s2 + w * gdepth.s3] = gd_out;
+#pragma unroll
+        for (int u = 0; u < kBwdUnroll; u++) {
+            const int p = p0 + u * kBlock;
+            float gd_out = 0.0f;
+            if (live[u]) {
+                const float cx = centre_d(ix[u], D.X), cy = centre_d(iy[u], D.Y), cz = centre_d(iz[u], D.Z);
+                float L = norm3(u_h[u], u_w[u], f);                     // :432
+                if ((double)L < 1e-5) L = (float)1e-5;
+                const float rx = -f / L, ry = u_w[u] / L, rz = u_h[u] / L;   // :436-438
+                float Dn = norm3(gx[u] - cx, gy[u] - cy, gz[u] - cz);   // :440
+                if ((double)Dn < 1e-5) Dn = (float)1e-5;
+                const float qx = (gx[u] - cx) / Dn, qy = (gy[u] - cy) / Dn, qz = (gz[u] - cz) / Dn;
+                const float cos_cc = (rx * qx) + (ry * qy) + (rz * qz); // :448
+                float k = ptnum[u];
+                if (k < 1.0f) k = 1.0f;
+                // gscale = 1, or -res when the incoming gradient is w.r.t. the shifted output 1 - res*tdf
+                const float g = gd[u] * gscale;
+                gd_out = -g * cos_cc / k;                               // :455
+                const float L3 = L * L * L;
+                const float gfx = ((gx[u] - cx) / Dn) * (u_w[u] * u_w[u] + u_h[u] * u_h[u]) / L3;   // :459
+                const float gfy = ((gy[u] - cy) / Dn) * (u_w[u] * f) / L3;                          // :460
+                const float gfz = ((gz[u] - cz) / Dn) * (u_h[u] * f) / L3;                          // :461
+                acc_fl += (double)((gfx + gfy + gfz) * g * d_i[u] / k);                             // :462
+                acc_cd += (double)(-qx * g / k);                                                    // :469
+            }
+            if (p < npix) gdimg[(p / D.W) * gdepth.s2 + (p % D.W) * gdepth.s3] = gd_out;
+        }
     }
     acc_fl = wave_sum(acc_fl);
     acc_cd = wave_sum(acc_cd);
@@ -726,8 +768,9 @@ static int backward_impl(const char *op, const genre_tensor *depth, const genre_
     const int npix = D.H * D.W;
     if (npix == 0) return 1;
     GENRE_REQUIRE(imgs <= 65535, "%s: N*NC must be <= 65535", op);
-    int bx = ceil_div(npix, kBlock);
-    if (bx > 256) bx = 256;
+    int bx = ceil_div(npix, kBlock * kBwdUnroll);                       // ~512 workgroups in total (see kernel)
+    const int cap = imgs >= 512 ? 1 : 512 / imgs;
+    if (bx > cap) bx = cap;
     float gscale = 1.0f;
     if (shifted) {
         GENRE_REQUIRE(D.X == D.Y && D.Y == D.Z, "%s: the fused shift needs a cubic grid", op);

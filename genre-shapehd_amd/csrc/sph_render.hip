@@ -358,19 +358,34 @@ __global__ __launch_bounds__(kBlock) void render_sample_brick_kernel(RenderDims 
               oz = (brick % nbz) * kBrick - 1;                            // tile origin (incl. halo)
     const float *__restrict__ base = vox.p + (img / D.NC) * vox.s0 + (img % D.NC) * vox.s1;
     // all of a thread's tile elements are requested before the first one is used: written as a plain loop the
-    // compiler waits for every load in turn (23 exposed latencies per workgroup)
+    // compiler waits for every load in turn (23 exposed latencies per workgroup).  Element t = thread + i*256
+    // is walked incrementally -- 256 = 14*kTile + 4 -- so the loop has no division and no address multiply
+    // (runtime strides make those quarter-rate v_mul_lo_u32: they were ~30 % of this kernel's issue time).
     constexpr int kPerThread = (kTile * kTile * kTile + kBlock - 1) / kBlock;
+    static_assert(kBlock < kTile * kTile && kBlock / kTile == 14 && kBlock % kTile == 4, "tile walk constants");
     float vals[kPerThread];
+    {
+        int lz = (int)threadIdx.x % kTile, ly = (int)threadIdx.x / kTile;
+        int x = ox, y = oy + ly, z = oz + lz;
+        int off = x * D.sx + y * D.sy + z * D.sz;
+        const int step = 14 * D.sy + 4 * D.sz, wrap_z = D.sy - kTile * D.sz, wrap_y = D.sx - kTile * D.sy;
+        unsigned inside = 0;                        // bit i: element i lies in the volume
 #pragma unroll
-    for (int i = 0; i < kPerThread; i++) {
-        const int t = threadIdx.x + i * kBlock;
-        const int lx = t / (kTile * kTile), r = t - lx * (kTile * kTile), ly = r / kTile, lz = r - ly * kTile;
-        const int x = ox + lx, y = oy + ly, z = oz + lz;
-        vals[i] = 0.f;
-        if (t < kTile * kTile * kTile && (unsigned)x < (unsigned)D.X && (unsigned)y < (unsigned)D.Y &&
-            (unsigned)z < (unsigned)D.Z) {
-            vals[i] = base[x * D.sx + y * D.sy + z * D.sz];
-            if (D.pre_scale != 0.0f) vals[i] = fminf(fmaxf(vals[i] * D.pre_scale, D.lo), D.hi);   // depth_pred_with_sph_inpaint.py:124
+        for (int i = 0; i < kPerThread; i++) {
+            vals[i] = 0.f;
+            if ((int)threadIdx.x + i * kBlock < kTile * kTile * kTile && (unsigned)x < (unsigned)D.X &&
+                (unsigned)y < (unsigned)D.Y && (unsigned)z < (unsigned)D.Z) {
+                vals[i] = base[off];
+                inside |= 1u << i;
+            }
+            lz += 4; z += 4; ly += 14; y += 14; off += step;
+            if (lz >= kTile) { lz -= kTile; z -= kTile; ly += 1; y += 1; off += wrap_z; }
+            if (ly >= kTile) { ly -= kTile; y -= kTile; x += 1; off += wrap_y; }
+        }
+        if (D.pre_scale != 0.0f) {                  // clamp(x * pre_scale)  (depth_pred_with_sph_inpaint.py:124);
+#pragma unroll                                      // halo cells outside the volume stay 0 (grid_sample zero padding)
+            for (int i = 0; i < kPerThread; i++)
+                if (inside & (1u << i)) vals[i] = fminf(fmaxf(vals[i] * D.pre_scale, D.lo), D.hi);
         }
     }
 #pragma unroll
