@@ -126,6 +126,19 @@ def kernel_table(G, dev, B):
                                         kernels="render_scan_bwd_kernel+render_bwd_brick_kernel")
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3
+    # Chamfer forward, both directions, B x 2048 x 2048 (configs[0]'s cloud size): fp32-VALU bound, 8 flops per
+    # pair (3 sub, 3 mul, 2 add -- no fma: the distance must round like the reference's expression)
+    from genre_shapehd_amd.toolbox.nndistance._ext import my_lib
+    n = 2048
+    a = torch.rand((B, n, 3), device=dev)
+    b = torch.rand((B, n, 3), device=dev)
+    d1 = torch.empty((B, n), device=dev); d2 = torch.empty((B, n), device=dev)
+    i1 = torch.empty((B, n), device=dev, dtype=torch.int32); i2 = torch.empty_like(i1)
+    t = event_time_us(lambda: my_lib.nnd_forward_cuda(a, b, d1, d2, i1, i2), iters, 5)
+    flops = 2 * B * n * n * 8
+    rows["nnd_fwd"] = dict(us=t, bytes=B * n * (2 * 12 + 2 * 8), kernels="nnd_forward_kernel", TFLOPs=flops / t / 1e6,
+                           frac_fp32_valu=flops / t / 1e6 / 157.3, pairs=2 * B * n * n)
+    rows["nnd_fwd"]["GBs"] = rows["nnd_fwd"]["bytes"] / t / 1e3
     return rows
 
 
@@ -250,7 +263,7 @@ def main():
     if rank == 0:
         rows = kernel_table(G, dev, B)
         # dominant hand-written kernel of the step = the one moving the most algorithmic bytes
-        in_step = [k for k in rows if not (fused and k.startswith("calc_prob"))]
+        in_step = [k for k in rows if not (fused and k.startswith("calc_prob")) and k != "nnd_fwd"]
         dom_name = max(in_step, key=lambda k: rows[k]["us"])
         dom = rows[dom_name]
         m2_us = rows["cam_bp_fwd"]["us"] + rows["calc_prob_fwd"]["us"]
@@ -273,6 +286,9 @@ def main():
                    "achieved": m2_bytes / m2_us / 1e3, "unit": "GB/s", "frac": m2_bytes / m2_us / 1e3 / HBM_PEAK_GBS,
                    "us_per_image": m2_us / B},
             "kernels": {k: {"us": round(v["us"], 2), "GBs": round(v["GBs"], 1)} for k, v in rows.items()},
+            "nnd": {"what": "Chamfer forward, both directions, %d x 2048 x 2048; 8 fp32 flops per pair, no fma" % B,
+                    "TFLOPs": rows["nnd_fwd"]["TFLOPs"], "peak": 157.3, "frac": rows["nnd_fwd"]["frac_fp32_valu"],
+                    "pairs_per_s": rows["nnd_fwd"]["pairs"] / rows["nnd_fwd"]["us"] * 1e6},
             "batch1": batch1_graph(G, dev),
         }
         if not args.no_cpu_baseline:

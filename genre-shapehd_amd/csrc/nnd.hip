@@ -6,13 +6,21 @@
 // grid twice on the DEFAULT stream; at batch 1 only 4 of its 512 blocks work.
 //
 // Here ONE launch covers both directions.  A workgroup owns 128 queries (two per
-// lane) and its 16 waves each scan a different slice of the target cloud, so a
-// 2048 x 2048 problem already puts a wave on every SIMD of 32 CUs and a batch
-// fills the chip.  Target coordinates are wave-uniform, so they are read
-// through the scalar cache (s_load) straight into SGPR operands of the VALU
-// ops -- no LDS staging, no broadcast reads.  The 16 partial minima are merged
-// through LDS in slice order with a strict '<', which is exactly the
+// lane, riding in the two halves of packed-fp32 ops) and its waves each scan a
+// different slice of the target cloud: 16 slices for a lone cloud pair, so that
+// 2048 x 2048 already puts a wave on every SIMD of 32 CUs; 8, 4 or 2 once the
+// batch alone fills the chip (longer scans per wave, less prologue and merge per
+// pair).  Target coordinates are wave-uniform, so they are read through the
+// scalar cache (s_load, prefetched one chunk ahead) straight into SGPR operands
+// of the VALU ops -- no LDS staging, no broadcast reads.  The partial minima are
+// merged through LDS in slice order with a strict '<', which is exactly the
 // reference's "first minimum wins" (my_lib.c:20, nnd_cuda.cu:26,120).
+//
+// Issue cost on gfx950 (tools/valu_rate_bench.hip, tools/pk_f32_bench.hip): a
+// v_pk_{add,mul}_f32 takes ~4.2 cycles per wave for two pairs, a plain fp32 op on
+// VGPRs ~2.5 for one (4.2 with an SGPR operand), v_min_f32 / v_min3_f32 ~4.3.  The
+// scan is 4 packed ops + ~0.9 min + ~0.5 select per pair = ~22 cycles: a ceiling of
+// ~56 TFLOP/s for this un-fused 8-flop formulation (measured: 45 at 32 x 2048^2).
 //
 // Distances use the reference's fp32 expression x*x + y*y + z*z evaluated left
 // to right WITHOUT fma contraction, so dist is bit-identical to the CPU
@@ -25,8 +33,8 @@
 namespace genre {
 namespace {
 
-constexpr int kSlices = 16;                 // waves per workgroup
-constexpr int kNndBlock = kSlices * 64;
+constexpr int kMaxSlices = 16;              // waves per workgroup: 16 for a lone cloud pair, fewer (longer scans per
+                                            // wave, less prologue/merge per pair) once the batch fills the chip
 
 __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float tx, float ty, float tz)
 {
@@ -34,15 +42,24 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float tx, 
     return x * x + y * y + z * z;                          // :18
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 sqdist2(f2 qx, f2 qy, f2 qz, float tx, float ty, float tz)
+{
+    const f2 x = tx - qx, y = ty - qy, z = tz - qz;
+    return x * x + y * y + z * z;
+}
+
 // Q queries per lane (register blocking: one set of scalar target loads feeds Q distance pipelines).
-// Minimum tracking is done per CHUNK of 4 targets: m = min(d0..d3) (2 instructions) and one strict-less
-// update of (best, chunk) instead of four compare/select pairs; the index inside the winning chunk is
+// Minimum tracking is done per CHUNK of kC = 8 targets: m = min(d0..d7) (v_min3 tree) and one strict-less
+// update of (best, chunk) instead of eight compare/select pairs; the index inside the winning chunk is
 // resolved once at the end as the first target whose distance equals the minimum.  Same answer as the
 // reference's "if (d < best)" per target: the earliest chunk that attains the minimum wins, and inside it
 // the earliest target.  (v_min_f32 ignores a NaN operand, like the always-false compare does.)
 constexpr int kQ = 2;
+constexpr int kC = 8;
 
-__global__ __launch_bounds__(kNndBlock) void nnd_forward_kernel(int n, int m, int qblocks1,
+template <int kSlices>
+__global__ __launch_bounds__(kSlices * 64) void nnd_forward_kernel(int n, int m, int qblocks1,
                                                                  const float *__restrict__ xyz1,
                                                                  const float *__restrict__ xyz2,
                                                                  float *__restrict__ dist1, int *__restrict__ idx1,
@@ -78,48 +95,83 @@ __global__ __launch_bounds__(kNndBlock) void nnd_forward_kernel(int n, int m, in
     }
     if (k0 < k1) {
         const float *__restrict__ t = T + (int64_t)k0 * 3;
-        // the first chunk initialises ("k==0 ||" of my_lib.c:20); it may be shorter than 4
-        const int first_len = (k1 - k0 < 4) ? k1 - k0 : 4;
+        // the slice's first target initialises ("k==0 ||" of my_lib.c:20) -- even a NaN/inf distance, as in the
+        // reference; the chunked scan then starts at that same target again (an equal distance never replaces)
 #pragma unroll
-        for (int u = 0; u < kQ; u++) {
-            float mch = sqdist(qx[u], qy[u], qz[u], t[0], t[1], t[2]);
-            for (int e = 1; e < first_len; e++) mch = fminf(mch, sqdist(qx[u], qy[u], qz[u], t[e * 3], t[e * 3 + 1], t[e * 3 + 2]));
-            best[u] = mch; bchunk[u] = k0;
+        for (int u = 0; u < kQ; u++) { best[u] = sqdist(qx[u], qy[u], qz[u], t[0], t[1], t[2]); bchunk[u] = k0; }
+        int k = k0;
+        const float *__restrict__ tp = t;
+        // main loop: the two queries of a lane ride in the two halves of packed fp32 ops (v_pk_add_f32 with a
+        // negated operand, v_pk_mul_f32: IEEE results identical to the scalar forms, 2 pairs per instruction)
+        static_assert(kQ == 2, "the packed main loop carries exactly two queries per lane");
+        const f2 px = {qx[0], qx[1]}, py = {qy[0], qy[1]}, pz = {qz[0], qz[1]};
+        // the chunk after the current one is requested before the current one is evaluated: scalar loads return
+        // out of order, so their only wait is "all outstanding" -- without the prefetch every iteration starts
+        // with an exposed scalar-cache round trip
+        float c[3 * kC];
+        if (k + kC <= k1) {
+#pragma unroll
+            for (int e = 0; e < 3 * kC; e++) c[e] = tp[e];              // wave-uniform: s_load into SGPR operands
         }
-        int k = k0 + first_len;
-        const float *__restrict__ tp = t + first_len * 3;
-        for (; k + 4 <= k1; k += 4, tp += 12) {
-            const float t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3], t4 = tp[4], t5 = tp[5];
-            const float t6 = tp[6], t7 = tp[7], t8 = tp[8], t9 = tp[9], t10 = tp[10], t11 = tp[11];
+        for (; k + kC <= k1; k += kC, tp += 3 * kC) {
+            float nx[3 * kC];
+            const float *__restrict__ tn = (k + 2 * kC <= k1) ? tp + 3 * kC : tp;   // last round: harmless re-read
+#pragma unroll
+            for (int e = 0; e < 3 * kC; e++) nx[e] = tn[e];
+            __builtin_amdgcn_sched_barrier(0);                          // keep the requests ahead of the arithmetic
+            f2 d[kC];
+#pragma unroll
+            for (int e = 0; e < kC; e++) d[e] = sqdist2(px, py, pz, c[3 * e], c[3 * e + 1], c[3 * e + 2]);
 #pragma unroll
             for (int u = 0; u < kQ; u++) {
-                const float d0 = sqdist(qx[u], qy[u], qz[u], t0, t1, t2);
-                const float d1 = sqdist(qx[u], qy[u], qz[u], t3, t4, t5);
-                const float d2 = sqdist(qx[u], qy[u], qz[u], t6, t7, t8);
-                const float d3 = sqdist(qx[u], qy[u], qz[u], t9, t10, t11);
-                const float mch = fminf(fminf(d0, d1), fminf(d2, d3));
+                const float mch = fminf(fminf(fminf(d[0][u], d[1][u]), fminf(d[2][u], d[3][u])),
+                                        fminf(fminf(d[4][u], d[5][u]), fminf(d[6][u], d[7][u])));
                 if (mch < best[u]) { best[u] = mch; bchunk[u] = k; }
             }
+#pragma unroll
+            for (int e = 0; e < 3 * kC; e++) c[e] = nx[e];
         }
-        for (; k < k1; k++, tp += 3) {                       // tail: chunks of one
+        if (k < k1 && k1 - k0 >= kC) {
+            // ragged end: one more chunk over the slice's LAST kC targets.  It overlaps the previous chunk; the
+            // re-evaluated targets cannot win (their distance is >= best, and only '<' replaces), and if a new
+            // one wins, no re-evaluated target can equal the new minimum, so the first-match resolve stays right.
+            k = k1 - kC;
+            tp = T + (int64_t)k * 3;
+            f2 d[kC];
+#pragma unroll
+            for (int e = 0; e < kC; e++) d[e] = sqdist2(px, py, pz, tp[3 * e], tp[3 * e + 1], tp[3 * e + 2]);
+#pragma unroll
+            for (int u = 0; u < kQ; u++) {
+                const float mch = fminf(fminf(fminf(d[0][u], d[1][u]), fminf(d[2][u], d[3][u])),
+                                        fminf(fminf(d[4][u], d[5][u]), fminf(d[6][u], d[7][u])));
+                if (mch < best[u]) { best[u] = mch; bchunk[u] = k; }
+            }
+            k = k1;
+        }
+        for (; k < k1; k++, tp += 3) {                       // slices shorter than kC: chunks of one
 #pragma unroll
             for (int u = 0; u < kQ; u++) {
                 const float d = sqdist(qx[u], qy[u], qz[u], tp[0], tp[1], tp[2]);
                 if (d < best[u]) { best[u] = d; bchunk[u] = k; }
             }
         }
-        // resolve the index inside the winning chunk: first target (<= 4 candidates) with d == best
+        // resolve the index inside the winning chunk: first target (<= kC candidates) with d == best.  All
+        // candidate coordinates are requested up front (one exposed latency, not kC dependent ones); a candidate
+        // past the slice end is clamped onto the last target -- it can only repeat a distance already seen.
 #pragma unroll
         for (int u = 0; u < kQ; u++) {
             const int c0 = bchunk[u];
+            float cx[kC], cy[kC], cz[kC];
+#pragma unroll
+            for (int e = 0; e < kC; e++) {
+                const int kk = (c0 + e < k1) ? c0 + e : k1 - 1;
+                cx[e] = T[(int64_t)kk * 3]; cy[e] = T[(int64_t)kk * 3 + 1]; cz[e] = T[(int64_t)kk * 3 + 2];
+            }
             int found = c0;
-            bool done = false;
-            for (int e = 0; e < 4; e++) {
-                const int kk = c0 + e;
-                if (kk < k1 && !done) {
-                    const float d = sqdist(qx[u], qy[u], qz[u], T[(int64_t)kk * 3], T[(int64_t)kk * 3 + 1], T[(int64_t)kk * 3 + 2]);
-                    if (d == best[u]) { found = kk; done = true; }
-                }
+#pragma unroll
+            for (int e = kC - 1; e >= 0; e--) {                          // descending: the earliest match is kept
+                const int kk = (c0 + e < k1) ? c0 + e : k1 - 1;
+                if (sqdist(qx[u], qy[u], qz[u], cx[e], cy[e], cz[e]) == best[u]) found = kk;
             }
             bchunk[u] = found;
         }
@@ -237,9 +289,22 @@ extern "C" int genre_nnd_forward(const genre_tensor *xyz1, const genre_tensor *x
     GENRE_REQUIRE(B <= 65535, "%s: batch must be <= 65535", op);
     const int qb1 = ceil_div(n, 64 * kQ), qb2 = ceil_div(m, 64 * kQ);
     if (B == 0 || qb1 + qb2 == 0) return 1;
-    nnd_forward_kernel<<<dim3(qb1 + qb2, (unsigned)B), kNndBlock, 0, (hipStream_t)stream>>>(
-        (int)n, (int)m, qb1, (const float *)xyz1->data, (const float *)xyz2->data, (float *)dist1->data,
-        (int *)idx1->data, (float *)dist2->data, (int *)idx2->data);
+    // slices per workgroup: as few as still put ~8 waves on each of the 1024 SIMDs
+    const int64_t groups = (int64_t)B * (qb1 + qb2);
+    int slices = kMaxSlices;
+    while (slices > 2 && groups * (slices / 2) >= 8192) slices /= 2;
+    const dim3 grid(qb1 + qb2, (unsigned)B);
+#define GENRE_NND_LAUNCH(S)                                                                                        \
+    nnd_forward_kernel<S><<<grid, S * 64, 0, (hipStream_t)stream>>>(                                               \
+        (int)n, (int)m, qb1, (const float *)xyz1->data, (const float *)xyz2->data, (float *)dist1->data,           \
+        (int *)idx1->data, (float *)dist2->data, (int *)idx2->data)
+    switch (slices) {
+    case 16: GENRE_NND_LAUNCH(16); break;
+    case 8: GENRE_NND_LAUNCH(8); break;
+    case 4: GENRE_NND_LAUNCH(4); break;
+    default: GENRE_NND_LAUNCH(2); break;
+    }
+#undef GENRE_NND_LAUNCH
     GENRE_LAUNCH_CHECK("nnd updateOutput");
     return 1;
 }

@@ -43,4 +43,12 @@ for _ in range(3):
     lib.render_spherical_forward(tdf, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0)
     lib.render_spherical_backward(tdf, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"],
                                   vbuf, T["kin"], 50.0)
+# Chamfer forward (VALU-bound: used with --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ...)
+from genre_shapehd_amd.toolbox.nndistance._ext import my_lib  # noqa: E402
+xa = torch.rand((B, 2048, 3), device=dev)
+xb = torch.rand((B, 2048, 3), device=dev)
+d1 = torch.empty((B, 2048), device=dev); d2 = torch.empty_like(d1)
+i1 = torch.empty((B, 2048), device=dev, dtype=torch.int32); i2 = torch.empty_like(i1)
+for _ in range(3):
+    my_lib.nnd_forward_cuda(xa, xb, d1, d2, i1, i2)
 torch.cuda.synchronize()

@@ -36,6 +36,19 @@ def test_forward_exact_backward_close(b, n, m, genre, oracle, dev):
     assert np.abs(bb.grad.cpu().numpy() - gx2o).max() <= 1e-5
 
 
+@pytest.mark.parametrize("b,n,m,slices", [(512, 128, 128, 8), (1024, 128, 100, 4), (4096, 128, 128, 2), (64, 2048, 2048, 4)])
+def test_every_slice_count(b, n, m, slices, genre, oracle, dev):
+    """the launcher gives a workgroup 16, 8, 4 or 2 waves depending on how many workgroups the batch makes
+    (nnd.hip, genre_nnd_forward); all of them must agree bit for bit with the serial scan, ties included"""
+    x1, x2 = inputs.clouds(b, n, m, seed1=b + 1, seed2=b + 2)
+    x1[::3] = np.round(x1[::3] * 4) / 4                    # a third of the batches on a coarse lattice: exact ties
+    x2[::3] = np.round(x2[::3] * 4) / 4
+    d1o, d2o, i1o, i2o = oracle.nnd_forward(x1, x2)
+    d1, d2, i1, i2 = genre.nndistance_w_idx(t(x1, dev), t(x2, dev))
+    assert np.array_equal(i1.cpu().numpy(), i1o) and np.array_equal(i2.cpu().numpy(), i2o)
+    assert np.array_equal(d1.cpu().numpy(), d1o) and np.array_equal(d2.cpu().numpy(), d2o)
+
+
 def test_ties_first_minimum_wins(genre, oracle, dev):
     """integer lattice clouds are full of exact ties: the lowest index must win (my_lib.c:20)"""
     rng = np.random.default_rng(5)
