@@ -39,6 +39,17 @@ BYTES_CP_BWD_FUSED = 4 * 128 * 128 * 256 * 4              # p, s, grad in + grad
 BYTES_RENDER_FUSED = 128 ** 3 * 4 + 128 * 128 * 4         # vox in + map out           =  8 454 144
 
 
+# profiles/r01f_pmc_hbm_traffic.txt, bytes per launch at batch 32 (kernel groups as in kernel_table)
+PMC_TRAFFIC_SOURCE = "profiles/r01f_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+PMC_TRAFFIC_B32 = {
+    "render_bwd_fused": 918.0e6 + 1292.1e6 + 96.1e6,     # scan_bwd + bwd_brick + zero_shared_bricks
+    "render_fwd_fused": 1104.0e6 + 367.3e6,              # sample_brick + scan_fwd
+    "calc_prob_fwd": 1073.8e6,
+    "calc_prob_bwd_fused": 2147.6e6,
+    "cam_bp_fwd": 537.8e6 + 43.1e6 + 111.3e6,            # fill + scatter + normalise
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,6 +277,10 @@ def main():
         in_step = [k for k in rows if not (fused and k.startswith("calc_prob")) and k != "nnd_fwd"]
         dom_name = max(in_step, key=lambda k: rows[k]["us"])
         dom = rows[dom_name]
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately and corrected as
+        # MI355X_MICROARCH.md prescribes); rocprofv3 cannot run inside this process, so the figures of the committed
+        # passes are quoted, and only for the configuration they were measured on (batch 32, fused renderer)
+        traffic = PMC_TRAFFIC_B32.get(dom_name) if (B == 32 and fused) else None
         m2_us = rows["cam_bp_fwd"]["us"] + rows["calc_prob_fwd"]["us"]
         m2_bytes = rows["cam_bp_fwd"]["bytes"] + rows["calc_prob_fwd"]["bytes"]
         out = {
@@ -280,7 +295,8 @@ def main():
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom_name + " (" + dom["kernels"] + ")",
                          "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": None,
+                         "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": PMC_TRAFFIC_SOURCE if traffic else None,
                          "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["us"]},
             "m2": {"what": "cam_bp fwd + calc_prob fwd, algorithmic bytes / time, batch %d" % B,
                    "achieved": m2_bytes / m2_us / 1e3, "unit": "GB/s", "frac": m2_bytes / m2_us / 1e3 / HBM_PEAK_GBS,
