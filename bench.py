@@ -73,8 +73,9 @@ class HotPath(torch.nn.Module):
 
     def forward(self, depth):
         proj = self.cam(depth)                                        # fl=418.3, cam_dist=2.2, 1-128*tdf
-        sph = self.render(proj, pre_scale=50.0)                       # == render(clamp(proj*50, 1e-5, 1-1e-5)), :124
-        return self.G.sph_pad(sph, 16)
+        # == sph_pad(render(clamp(proj*50, 1e-5, 1-1e-5)), 16)  (:124-126); the fused renderer folds both in, the
+        # reference-op-sequence mode runs them as separate torch ops
+        return self.render(proj, pre_scale=50.0, pad=16)
 
 
 def event_time_us(fn, iters, warm):

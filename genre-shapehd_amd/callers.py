@@ -77,8 +77,9 @@ class GenReGeometry(nn.Module):
     def depth_to_spherical(self, pred_abs_depth):
         """depth_pred_with_sph_inpaint.py:120-129 -> (out_1['proj_depth'], out_1['pred_sph_partial'])"""
         proj = self.proj_depth(pred_abs_depth)                           # 1 - 128*tdf, shift folded into the op
-        sph_in = self.render_spherical(proj, pre_scale=50.0)             # == render(clamp(proj*50, 1e-5, 1-1e-5))
-        return proj * 50, sph_pad(sph_in, self.margin)
+        # == sph_pad(render(clamp(proj*50, 1e-5, 1-1e-5)), margin): clamp and padding both folded into the renderer
+        sph_in = self.render_spherical(proj, pre_scale=50.0, pad=self.margin)
+        return proj * 50, sph_in
 
     def refiner_input(self, pred_sph_full, proj_depth):
         """genre_full_model.py:122-127,134-143 -> (refine_input [N,2,R,R,R], cnt)"""

@@ -53,7 +53,50 @@ struct RenderDims {
     double step;                                 // 1/(ZR-1)
     float lo, hi;                                // clamp bounds of spherical_proj.py:66
     float pre_scale;                             // != 0: the volume is clamp(vox * pre_scale, lo, hi), formed on the
-};                                               //       fly (the caller's `clamp(proj * 50, 1e-5, 1 - 1e-5)` folded in)
+                                                 //       fly (the caller's `clamp(proj * 50, 1e-5, 1 - 1e-5)` folded in)
+    int pad;                                     // > 0: the map is written / read as sph_pad(map, pad) would lay it out
+};
+
+// sph_pad (spherical_proj.py:21-28) as a fan-out of map pixel (i, j): replicate padding repeats the first / last
+// row pad more times (:23); the left margin is then overwritten by the last pad interior columns and the right
+// margin by the first pad ones (:25-26, azimuth wraps around), rows included.  Output rows r_lo .. r_lo+r_n-1,
+// column c0 and (if >= 0) c1.  Needs 2*pad <= R.
+__device__ __forceinline__ void pad_span(int R, int pm, int i, int j, int &r_lo, int &r_n, int &c0, int &c1)
+{
+    r_lo = (i == 0) ? 0 : i + pm;
+    r_n = ((i == R - 1) ? R - 1 + 2 * pm : i + pm) - r_lo + 1;
+    c0 = j + pm;
+    c1 = (j >= R - pm) ? j - (R - pm) : (j < pm ? j + R + pm : -1);
+}
+
+// lane-parallel store of one ray's value to all its padded positions (value is wave-uniform)
+__device__ __forceinline__ void store_map(const RenderDims &D, float *oimg, const View4 &out, int q, int lane, float v)
+{
+    const int i = q / D.R, j = q % D.R;
+    if (D.pad == 0) {
+        if (lane == 0) oimg[i * out.s2 + j * out.s3] = v;
+        return;
+    }
+    int r_lo, r_n, c0, c1;
+    pad_span(D.R, D.pad, i, j, r_lo, r_n, c0, c1);
+    const int cnt = r_n * (c1 >= 0 ? 2 : 1);
+    for (int t = lane; t < cnt; t += 64) oimg[(r_lo + t % r_n) * out.s2 + (t < r_n ? c0 : c1) * out.s3] = v;
+}
+
+// gradient of one ray's value: sum over its padded positions
+__device__ __forceinline__ float load_map_grad(const RenderDims &D, const float *gimg, const View4 &gout, int q)
+{
+    const int i = q / D.R, j = q % D.R;
+    if (D.pad == 0) return gimg[i * gout.s2 + j * gout.s3];
+    int r_lo, r_n, c0, c1;
+    pad_span(D.R, D.pad, i, j, r_lo, r_n, c0, c1);
+    float g = 0.f;
+    for (int r = 0; r < r_n; r++) {
+        g += gimg[(r_lo + r) * gout.s2 + c0 * gout.s3];
+        if (c1 >= 0) g += gimg[(r_lo + r) * gout.s2 + c1 * gout.s3];
+    }
+    return g;
+}
 
 // sample k of the ray with doubled direction 2*dir (fp64): spherical_proj.py:50-56
 __device__ __forceinline__ void sample_pos(const RenderDims &D, double dx2, double dy2, double dz2, int k,
@@ -595,12 +638,12 @@ __global__ __launch_bounds__(kBlock) void render_scan_fwd_kernel(RenderDims D, c
             double carry = 1.0;
             clamp4(D, va, kb, p, pass);
             float total = wave_sum_f32((float)expect4w(p, w4, carry)) + (float)carry;     // + prod(1-p)  (:69-71)
-            if (lane == 0) oimg[(q / D.R) * out.s2 + (q % D.R) * out.s3] = total;
+            store_map(D, oimg, out, q, lane, total);
             if (hasb) {
                 carry = 1.0;
                 clamp4(D, vb, kb, p, pass);
                 total = wave_sum_f32((float)expect4w(p, w4, carry)) + (float)carry;
-                if (lane == 0) oimg[(qb / D.R) * out.s2 + (qb % D.R) * out.s3] = total;
+                store_map(D, oimg, out, qb, lane, total);
             }
         }
     }
@@ -627,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
     for (int qbase = w0; qbase < rr; qbase += 64 * nw) {
         const int myq = qbase + lane * nw;
         const int mykin = myq < rr ? kin[myq] : D.ZR;
-        const float myg = myq < rr ? gimg[(myq / D.R) * gout.s2 + (myq % D.R) * gout.s3] : 0.f;
+        const float myg = myq < rr ? load_map_grad(D, gimg, gout, myq) : 0.f;
         for (int it = 0; it < 64; it += 2) {
             const int q = qbase + it * nw;
             if (q >= rr) break;
@@ -818,12 +861,16 @@ int check_render(const char *op, const genre_tensor *vox, const genre_tensor *di
                  const genre_tensor *map, RenderDims &D)
 {
     GENRE_REQUIRE(is_f32(vox, 5), "%s: vox must be a 5-D fp32 tensor [N,NC,X,Y,Z]", op);
-    GENRE_REQUIRE(is_f32(map, 4) && map->size[0] == vox->size[0] && map->size[1] == vox->size[1] &&
-                      map->size[2] == map->size[3],
-                  "%s: the spherical map must be a 4-D fp32 tensor [N,NC,R,R]", op);
+    GENRE_REQUIRE(dirs && dirs->ndim == 3 && dirs->size[0] >= 0, "%s: dirs must be a 3-D tensor", op);
     D.N = (int)vox->size[0]; D.NC = (int)vox->size[1];
     D.X = (int)vox->size[2]; D.Y = (int)vox->size[3]; D.Z = (int)vox->size[4];
-    D.R = (int)map->size[2];
+    D.R = (int)dirs->size[0];
+    // the map is [N,NC,R,R], or [N,NC,R+2p,R+2p] laid out as sph_pad(map, p) (spherical_proj.py:21-28)
+    GENRE_REQUIRE(is_f32(map, 4) && map->size[0] == vox->size[0] && map->size[1] == vox->size[1] &&
+                      map->size[2] == map->size[3] && map->size[2] >= D.R && ((map->size[2] - D.R) & 1) == 0 &&
+                      (map->size[2] - D.R) <= D.R,
+                  "%s: the spherical map must be a 4-D fp32 tensor [N,NC,R+2p,R+2p] with 0 <= 2p <= R = %d", op, D.R);
+    D.pad = (int)(map->size[2] - D.R) / 2;
     int64_t span = 1;
     for (int i = 2; i < 5; i++) {
         GENRE_REQUIRE(vox->stride[i] >= 0, "%s: negative vox strides are not supported", op);
@@ -919,6 +966,7 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
         GENRE_LAUNCH_CHECK("render_spherical forward (scan)");
         return 1;
     }
+    GENRE_REQUIRE(D.pad == 0, "%s: the padded map layout needs the brick path (pass the tables)", op);
     render_fwd_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(
         D, view5(vox), (const double *)dirs->data, (const float *)depth_weight->data, view4(out));
     GENRE_LAUNCH_CHECK("render_spherical forward");
@@ -965,6 +1013,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                 view4(grad_out), (float *)dp_scratch->data, dpmax);
             GENRE_LAUNCH_CHECK("render_spherical backward (scan)");
         } else if (rays > 0) {                       // recompute the samples from vox
+            GENRE_REQUIRE(D.pad == 0, "%s: the padded map layout needs the forward's v_scratch", op);
             render_bwd_dp_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(
                 D, view5(vox), (const double *)dirs->data, (const float *)depth_weight->data, view4(grad_out),
                 (float *)dp_scratch->data, dpmax);
@@ -991,6 +1040,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
     zero_vec4_kernel<<<(int)zb, kBlock, 0, st>>>((float4 *)grad_vox->data, nv / 4);
     GENRE_LAUNCH_CHECK("render_spherical backward (zero)");
     if (rays == 0) return 1;
+    GENRE_REQUIRE(D.pad == 0, "%s: the padded map layout needs the brick path", op);
     render_bwd_atomic_kernel<<<grid_for_rays(rays), kBlock, 0, st>>>(D, view5(vox), (const double *)dirs->data,
                                                                     (const float *)depth_weight->data,
                                                                     view4(grad_out), view5(grad_vox));

@@ -120,16 +120,19 @@ def tables_for(vox_shape, device, dirs64, z_res):
 
 
 class RenderSphericalFused(Function):
-    """apply(vox [N,NC,X,Y,Z], dirs64 [R,R,3] float64, depth_weight [ZR], pre_scale=0.0) -> [N,NC,R,R];
-    pre_scale != 0 renders clamp(vox * pre_scale, 1e-5, 1 - 1e-5) without materialising it"""
+    """apply(vox [N,NC,X,Y,Z], dirs64 [R,R,3] float64, depth_weight [ZR], pre_scale=0.0, pad=0) -> [N,NC,R+2*pad,R+2*pad];
+    pre_scale != 0 renders clamp(vox * pre_scale, 1e-5, 1 - 1e-5) without materialising it; pad > 0 lays the map
+    out as sph_pad(map, pad) (spherical_proj.py:21-28) straight from the scan kernel"""
 
     @staticmethod
-    def forward(ctx, vox, dirs64, depth_weight, pre_scale=0.0):
+    def forward(ctx, vox, dirs64, depth_weight, pre_scale=0.0, pad=0):
         assert vox.dim() == 5 and vox.is_cuda and vox.dtype == torch.float32
         assert dirs64.dtype == torch.float64 and dirs64.dim() == 3 and dirs64.is_contiguous()
         lib = _loader().render_lib
         res, z_res = dirs64.shape[0], depth_weight.shape[0]
-        out = torch.empty((vox.shape[0], vox.shape[1], res, res), dtype=vox.dtype, device=vox.device)
+        pad = int(pad)
+        assert 0 <= 2 * pad <= res
+        out = torch.empty((vox.shape[0], vox.shape[1], res + 2 * pad, res + 2 * pad), dtype=vox.dtype, device=vox.device)
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
         rays = vox.shape[0] * vox.shape[1] * res * res
         v = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
@@ -150,4 +153,4 @@ class RenderSphericalFused(Function):
         scratch = torch.empty((v.numel() + 4,), dtype=torch.float32, device=vox.device)
         lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,
                                       scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"], ctx.pre_scale)
-        return grad_vox, None, None, None
+        return grad_vox, None, None, None, None

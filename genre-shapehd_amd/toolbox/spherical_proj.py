@@ -74,14 +74,17 @@ class render_spherical(torch.nn.Module):
         return (_fused_render.available() and vox.is_cuda and vox.dtype == torch.float32
                 and self.z_res <= 256 and self.z_res % 4 == 0 and self.sph_res * self.sph_res < (1 << 24))
 
-    def forward(self, vox, pre_scale=None):
-        """vox [N,C,X,Y,Z] -> [N,C,res,res].  Extension: `pre_scale=s` renders
+    def forward(self, vox, pre_scale=None, pad=0):
+        """vox [N,C,X,Y,Z] -> [N,C,res,res].  Extensions: `pre_scale=s` renders
         clamp(vox * s, 1e-5, 1 - 1e-5) -- the expression GenRe feeds this module
-        (depth_pred_with_sph_inpaint.py:124, s = 50) -- without materialising it on the fused path."""
-        if self._use_fused(vox):
+        (depth_pred_with_sph_inpaint.py:124, s = 50) -- without materialising it on the fused path;
+        `pad=m` returns sph_pad(map, m) (:126), written directly by the fused kernel."""
+        if self._use_fused(vox) and 0 <= 2 * int(pad) <= self.sph_res:
             from . import _fused_render
             return _fused_render.RenderSphericalFused.apply(vox, self._dirs64, self.depth_weight,
-                                                            0.0 if pre_scale is None else float(pre_scale))
+                                                            0.0 if pre_scale is None else float(pre_scale), int(pad))
+        if pad:
+            return sph_pad(self.forward(vox, pre_scale), int(pad))
         if pre_scale is not None:
             vox = torch.clamp(vox * pre_scale, 1e-5, 1 - 1e-5)
         grid = self.grid.expand(vox.shape[0], -1, -1, -1, -1)

@@ -173,7 +173,7 @@ int genre_nnd_backward(const genre_tensor *xyz1, const genre_tensor *xyz2,
  * render_spherical.forward (spherical_proj.py:62-72: expand, permute,
  * grid_sample [0.4.1 semantics == align_corners=True, zeros padding], clamp to
  * [1e-5, 1-1e-5], CalcStopProb, matmul(depth_weight), prod(1-p), add).
- * vox [N,NC,X,Y,Z] (any non-negative strides) -> out [N,NC,R,R].
+ * vox [N,NC,X,Y,Z] (any non-negative strides) -> out [N,NC,R,R] (or padded, see below).
  *   dirs         : the float64 [R,R,3] unit-direction table of spherical_proj.py:43-49,
  *                  passed as its raw storage viewed as fp32 [R,R,6] (contiguous);
  *                  sample k of ray (i,j) sits at float((2*dirs[i,j]) * (1 - k/(ZR-1))),
@@ -193,6 +193,10 @@ int genre_nnd_backward(const genre_tensor *xyz1, const genre_tensor *xyz2,
  * `torch.clamp(proj * 50, 1e-5, 1 - 1e-5)` of depth_pred_with_sph_inpaint.py:124 folded
  * in (two full-volume elementwise passes less each way); backward then returns the
  * gradient w.r.t. the un-scaled, un-clamped vox.
+ * Padded map (brick path only): `out` may be [N,NC,R+2p,R+2p] with 0 <= 2p <= R (R is taken
+ * from dirs); it is then written as sph_pad(map, p) of spherical_proj.py:21-28 lays it out
+ * (first/last row replicated, azimuth columns wrapped around) -- the `sph_pad(sph_in, margin)`
+ * of depth_pred_with_sph_inpaint.py:126 folded in; backward accepts grad_out of that shape.
  * Reference builder of the tables: genre-shapehd_amd/toolbox/_fused_render.py. */
 int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *dirs,
                                    const genre_tensor *depth_weight, const genre_tensor *out,

@@ -124,3 +124,26 @@ def test_render_odd_geometries(res, sph_res, z_res, genre, oracle, dev):
         assert (outs[fused][0] - ref.detach()).abs().max().item() <= TOL, (fused, res)
         d = (outs[fused][1] - vc.grad).abs() / (1 + vc.grad.abs())
         assert d.max().item() <= 2e-5, (fused, res, d.max().item())
+
+
+@pytest.mark.parametrize("pad", [1, 16, 64])
+def test_fused_pad_matches_sph_pad(pad, genre, dev):
+    """render(vox, pad=m) == sph_pad(render(vox), m) (spherical_proj.py:21-28,:126): values bit-equal (the same
+    numbers, fanned out), gradient equal up to the order of the <= 2(m+1) additions per map pixel"""
+    rng = np.random.default_rng(5)
+    vox = torch.from_numpy(rng.uniform(0.0, 0.04, (2, 1, 128, 128, 128)).astype(np.float32)).to(dev)
+    mod = genre.render_spherical().to(dev)
+    a = vox.clone().requires_grad_(True)
+    b = vox.clone().requires_grad_(True)
+    out_f = mod(a, pad=pad)
+    out_r = genre.sph_pad(mod(b), pad)
+    assert out_f.shape == out_r.shape == (2, 1, 128 + 2 * pad, 128 + 2 * pad)
+    assert torch.equal(out_f, out_r)
+    g = torch.from_numpy(rng.standard_normal(tuple(out_f.shape)).astype(np.float32)).to(dev)
+    out_f.backward(g)
+    out_r.backward(g)
+    scale = b.grad.abs().max().item()
+    assert (a.grad - b.grad).abs().max().item() <= 1e-5 * max(1.0, scale)
+    # and against the reference's op sequence (unfused module + torch sph_pad)
+    ref = genre.render_spherical(fused=False).to(dev)
+    assert (genre.sph_pad(ref(vox), pad) - out_f).abs().max().item() <= 1e-5
