@@ -151,6 +151,20 @@ def kernel_table(G, dev, B):
     rows["nnd_fwd"] = dict(us=t, bytes=B * n * (2 * 12 + 2 * 8), kernels="nnd_forward_kernel", TFLOPs=flops / t / 1e6,
                            frac_fp32_valu=flops / t / 1e6 / 157.3, pairs=2 * B * n * n)
     rows["nnd_fwd"]["GBs"] = rows["nnd_fwd"]["bytes"] / t / 1e3
+    # configs[0] on the GPU: one 2048 x 2048 pair, replayed from a HIP graph (launch cost excluded)
+    a1, b1 = a[:1].contiguous(), b[:1].contiguous()
+    o = [torch.empty((1, n), device=dev) for _ in range(2)] + [torch.empty((1, n), device=dev, dtype=torch.int32) for _ in range(2)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        my_lib.nnd_forward_cuda(a1, b1, o[0], o[1], o[2], o[3])
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(20):
+            my_lib.nnd_forward_cuda(a1, b1, o[0], o[1], o[2], o[3])
+    rows["nnd_fwd"]["cfg0_us"] = event_time_us(graph.replay, 20, 3) / 20
     return rows
 
 
@@ -227,8 +241,42 @@ def cpu_baseline(budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 64:
             break
-    return dict(value=n / el, unit="shapes/s", cores=1, kind=backend.kind,
-                sample="%d depth maps fwd+bwd through the same chain in %.1f s, 1 thread" % (n, el))
+    res = dict(value=n / el, unit="shapes/s", cores=1, kind=backend.kind,
+               sample="%d depth maps fwd+bwd through the same chain in %.1f s, 1 thread" % (n, el))
+    # the same chain on several host cores at once (one image per thread, intra-op threads stay at 1), so that the
+    # host figure is not artificially weak; bounded to 16 threads / ~8 s
+    try:
+        import concurrent.futures as cf
+        cores = max(1, min(os.cpu_count() or 1, 16))
+        if cores > 1:
+            hps = [HotPathCPU(backend) for _ in range(cores)]
+            deadline = time.perf_counter() + min(8.0, budget_s)
+
+            def work(i):
+                k = 0
+                while True:
+                    hps[i].forward_backward(torch.from_numpy(depths[(i + k) % 4:(i + k) % 4 + 1]), g)
+                    k += 1
+                    if time.perf_counter() >= deadline:
+                        return k
+            t1 = time.perf_counter()
+            with cf.ThreadPoolExecutor(cores) as ex:
+                total = sum(ex.map(work, range(cores)))
+            res["all_cores"] = dict(value=total / (time.perf_counter() - t1), unit="shapes/s", cores=cores,
+                                    sample="%d depth maps over %d threads" % (total, cores))
+    except Exception as e:      # pragma: no cover -- never fatal for the bench line
+        res["all_cores"] = dict(value=None, error=str(e)[:200])
+    # configs[0]: Chamfer on two 2048-point clouds, the reference's CPU path (my_lib.c nnsearch x2), 1 thread
+    try:
+        x1, x2 = inputs.clouds(1, 2048, 2048, seed1=0, seed2=1)
+        backend.nnd_forward(x1, x2)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            backend.nnd_forward(x1, x2)
+        res["nnd_cfg0_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+    except Exception as e:      # pragma: no cover
+        res["nnd_cfg0_ms"] = None
+    return res
 
 
 def main():
@@ -305,7 +353,10 @@ def main():
             "kernels": {k: {"us": round(v["us"], 2), "GBs": round(v["GBs"], 1)} for k, v in rows.items()},
             "nnd": {"what": "Chamfer forward, both directions, %d x 2048 x 2048; 8 fp32 flops per pair, no fma" % B,
                     "TFLOPs": rows["nnd_fwd"]["TFLOPs"], "peak": 157.3, "frac": rows["nnd_fwd"]["frac_fp32_valu"],
-                    "pairs_per_s": rows["nnd_fwd"]["pairs"] / rows["nnd_fwd"]["us"] * 1e6},
+                    "pairs_per_s": rows["nnd_fwd"]["pairs"] / rows["nnd_fwd"]["us"] * 1e6,
+                    "cfg0_us": rows["nnd_fwd"]["cfg0_us"],
+                    "cfg0_note": "configs[0] cloud pair (1 x 2048 x 2048) on the GPU, HIP-graph replay; the reference's "
+                                 "CPU path for the same pair is cpu_baseline.nnd_cfg0_ms"},
             "batch1": batch1_graph(G, dev),
         }
         if not args.no_cpu_baseline:
