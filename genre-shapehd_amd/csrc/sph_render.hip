@@ -678,8 +678,9 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
             const bool hasb = qb < rr;
             const int itb = hasb ? it + 1 : it, q2 = hasb ? qb : q;
             float va[4], vb[4];
-            load_v4(vimg + (int64_t)q * D.ZR, kb, __builtin_amdgcn_readlane(mykin, it), D.ZR, va);
-            load_v4(vimg + (int64_t)q2 * D.ZR, kb, __builtin_amdgcn_readlane(mykin, itb), D.ZR, vb);
+            const int kin_a = __builtin_amdgcn_readlane(mykin, it), kin_b = __builtin_amdgcn_readlane(mykin, itb);
+            load_v4(vimg + (int64_t)q * D.ZR, kb, kin_a, D.ZR, va);
+            load_v4(vimg + (int64_t)q2 * D.ZR, kb, kin_b, D.ZR, vb);
             const float ga = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(myg), it));
             const float gb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(myg), itb));
             float p[4], dp[4];
@@ -687,12 +688,13 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
             dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
             if (ga != 0.0f) { clamp4(D, va, kb, p, pass); dp4w(p, pass, w4, ga, dp); }
             wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
-            store_dp(D, dimg + (int64_t)q * D.ZR + kb, lane, dp);
+            // samples before kin lie outside the volume: no brick list names them, so their dL/dp is never read
+            if (kb + 3 >= kin_a) store_dp(D, dimg + (int64_t)q * D.ZR + kb, lane, dp);
             if (hasb) {
                 dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
                 if (gb != 0.0f) { clamp4(D, vb, kb, p, pass); dp4w(p, pass, w4, gb, dp); }
                 wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
-                store_dp(D, dimg + (int64_t)qb * D.ZR + kb, lane, dp);
+                if (kb + 3 >= kin_b) store_dp(D, dimg + (int64_t)qb * D.ZR + kb, lane, dp);
             }
         }
     }
