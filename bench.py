@@ -216,9 +216,48 @@ def batch1_graph(G, dev):
                 for _ in range(reps):
                     out = chain(d)
             res["chain_fwd_us_per_image"] = event_time_us(g2.replay, 20, 3) / reps
+            # the same forward chain at batch 8 (SURVEY 8d M1 quotes batch 1 and batch 8), eager launches
+            d8 = torch.from_numpy(inputs.batch_depth(8)).to(dev)
+            for _ in range(3):
+                chain(d8)
+            res["chain_fwd_b8_us_per_image"] = event_time_us(lambda: chain(d8), 20, 3) / 8
     except Exception as e:      # pragma: no cover
         res["chain_fwd_us_per_image"] = None
         res["chain_fwd_error"] = str(e)[:200]
+    try:        # all of GenRe's geometry between its networks, forward, batch 1, from a HIP graph:
+        # get_abs_depth -> cam_bp -> x50/clamp -> render_spherical -> sph_pad  [net2]  crop/1-x -> spherical
+        # back-projection -> refiner input [1,2,128^3]   (depth_pred_with_sph_inpaint.py:120-142,
+        # genre_full_model.py:122-143); the spherical map net2 would return is stood in by its input
+        from genre_shapehd_amd.callers import GenReGeometry
+        geo = GenReGeometry().to(dev)
+        rng = np.random.default_rng(3)
+        pred = torch.from_numpy(rng.uniform(20, 80, (1, 1, 256, 256)).astype(np.float32)).to(dev)
+        sil = torch.zeros((1, 1, 256, 256), device=dev)
+        sil[:, :, 64:192, 64:192] = 100.0
+        mm = torch.tensor([[1.8, 2.6]], device=dev)
+
+        def geometry():
+            dd = geo.get_abs_depth(pred, mm, sil)
+            proj50, sph_in = geo.depth_to_spherical(dd)
+            return geo.refiner_input(sph_in, proj50)
+
+        with torch.no_grad():
+            for _ in range(3):
+                geometry()
+            torch.cuda.synchronize()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                geometry()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g3 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g3):
+                for _ in range(reps):
+                    keep = geometry()
+            res["genre_geometry_fwd_us_per_image"] = event_time_us(g3.replay, 20, 3) / reps
+    except Exception as e:      # pragma: no cover
+        res["genre_geometry_fwd_us_per_image"] = None
+        res["genre_geometry_error"] = str(e)[:200]
     return res
 
 

@@ -189,6 +189,20 @@ class _RenderLib:
                      dp_scratch, brick_table, chunk_list, v_scratch, kin, scalars=(C.c_float(pre_scale),))
 
 
+class _GlueLib:
+    """GenRe caller glue folded into single passes (extension)"""
+
+    @staticmethod
+    def abs_depth_forward(pred_depth, depth_minmax, silhou, out, scale_25d=100.0):
+        """depth_pred_with_sph_inpaint.py:131-142 (get_abs_depth) in one pass"""
+        return _call("genre_abs_depth_forward", pred_depth, depth_minmax, silhou, out, scalars=(C.c_float(scale_25d),))
+
+    @staticmethod
+    def abs_depth_backward(grad_out, depth_minmax, silhou, grad_pred, scale_25d=100.0):
+        return _call("genre_abs_depth_backward", grad_out, depth_minmax, silhou, grad_pred,
+                     scalars=(C.c_float(scale_25d),))
+
+
 class _MyLib:
     """stands in for nndistance/_ext/my_lib (my_lib.h:3-5, my_lib_cuda.h:1-4).
     The reference's CPU entry points exist here only to fail loudly."""
@@ -213,3 +227,4 @@ cam_bp_lib = _CamBpLib()
 calc_prob_lib = _CalcProbLib()
 my_lib = _MyLib()
 render_lib = _RenderLib()
+glue_lib = _GlueLib()

@@ -7,6 +7,7 @@ refiner input [N,2,128^3] is written once.  The networks themselves (net1, net2,
 torch.nn and stay with the caller.
 
     geo = GenReGeometry().cuda()
+    pred_abs_depth = geo.get_abs_depth(pred['depth'], pred['depth_minmax'], input_struct.silhou)   # :131-142
     proj_depth, sph_in = geo.depth_to_spherical(pred_abs_depth)       # :120-126  -> net2
     refine_input, cnt  = geo.refiner_input(pred_sph_full, proj_depth) # :122-127,134-143 -> Unet_3D
 """
@@ -15,11 +16,42 @@ from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+from .toolbox.cam_bp.cam_bp._ext import cam_bp_lib, _loader
 from .toolbox.cam_bp.cam_bp.modules.camera_backprojection_module import Camera_back_projection_layer
 from .toolbox.spherical_proj import gen_sph_grid, render_spherical, sph_pad
 
 LO, HI = 1e-5, 1 - 1e-5
+
+
+class AbsDepth(Function):
+    """(pred_depth [N,1,H,W], depth_minmax [N,2], silhou [N,1,H,W], scale_25d) -> abs depth [N,1,W,H], i.e.
+    depth_pred_with_sph_inpaint.py:131-142:
+
+        d = to_abs_depth(1 - pred_depth / scale, depth_minmax.detach());  d[silhou.detach() / scale < 0.5] = 0
+        d = flip(d.permute(0, 1, 3, 2), [2])
+
+    one native pass instead of the reference's six elementwise / copy kernels; gradient w.r.t. pred_depth only
+    (the reference detaches the other two, :135,137)."""
+
+    @staticmethod
+    def forward(ctx, pred_depth, depth_minmax, silhou, scale_25d=100.0):
+        assert pred_depth.dim() == 4 and pred_depth.is_cuda and pred_depth.dtype == torch.float32
+        n, c, h, w = pred_depth.shape
+        out = torch.empty((n, c, w, h), dtype=pred_depth.dtype, device=pred_depth.device)
+        mm = depth_minmax.detach().reshape(n, 2)
+        _loader().glue_lib.abs_depth_forward(pred_depth, mm, silhou.detach(), out, float(scale_25d))
+        ctx.save_for_backward(mm, silhou.detach())
+        ctx.scale = float(scale_25d)
+        ctx.shape = pred_depth.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        mm, silhou = ctx.saved_tensors
+        grad_pred = torch.empty(ctx.shape, dtype=grad_out.dtype, device=grad_out.device)
+        _loader().glue_lib.abs_depth_backward(grad_out, mm, silhou, grad_pred, ctx.scale)
+        return grad_pred, None, None, None
 
 
 class RefinerInput(Function):
@@ -73,6 +105,10 @@ class GenReGeometry(nn.Module):
         self.proj_depth = Camera_back_projection_layer(res)
         self.render_spherical = render_spherical()
         self.register_buffer('grid', gen_sph_grid(res))                  # genre_full_model.py:108
+
+    def get_abs_depth(self, pred_depth, depth_minmax, silhou, scale_25d=100.0):
+        """depth_pred_with_sph_inpaint.py:131-142 (scale_25d: marrnetbase.py:17) -> depth map for proj_depth"""
+        return AbsDepth.apply(pred_depth, depth_minmax, silhou, scale_25d)
 
     def depth_to_spherical(self, pred_abs_depth):
         """depth_pred_with_sph_inpaint.py:120-129 -> (out_1['proj_depth'], out_1['pred_sph_partial'])"""

@@ -129,6 +129,26 @@ int genre_spherical_back_proj_backward_shifted(const genre_tensor *depth, const 
 
 /* ---- calc_prob : toolbox/calc_prob/calc_prob/src/calc_prob.h:1-2 ---------- */
 
+/* Extension: the glue of models/depth_pred_with_sph_inpaint.py:131-142 (`get_abs_depth`) in one pass --
+ *   abs = (1 - pred_depth / scale_25d) * (dmax - dmin + 1e-4) + dmin      marrnetbase.py:138-151
+ *   abs[silhou / scale_25d < 0.5] = 0                                      :138-139
+ *   out = flip(abs.permute(0,1,3,2), [2])  ==  out[n,c,i,j] = abs[n,c,j,W-1-i]        :140-141
+ * pred_depth, silhou [N,NC,H,W] (any strides); depth_minmax [N,2] = (min, max) per sample (:145-149);
+ * out [N,NC,W,H], fully written: the depth map genre_back_projection_forward consumes.
+ * Replaces six elementwise / copy kernels of the reference's PyTorch glue.  Un-fused fp32
+ * arithmetic in the reference's order (true division by scale_25d): bit-identical to the
+ * same lines run on CPU torch. */
+int genre_abs_depth_forward(const genre_tensor *pred_depth, const genre_tensor *depth_minmax,
+                            const genre_tensor *silhou, const genre_tensor *out, float scale_25d,
+                            void *stream);
+
+/* Adjoint of the above w.r.t. pred_depth (depth_minmax and silhou are detached in the
+ * reference, :135,137): grad_pred[n,c,h,w] = masked ? 0 : (-(g * (dmax - dmin + 1e-4))) / scale_25d
+ * with g = grad_out[n,c,W-1-w,h].  grad_pred [N,NC,H,W] fully written. */
+int genre_abs_depth_backward(const genre_tensor *grad_out, const genre_tensor *depth_minmax,
+                             const genre_tensor *silhou, const genre_tensor *grad_pred, float scale_25d,
+                             void *stream);
+
 /* Replaces calc_prob_forward (calc_prob.c:9-17 -> calc_prob_kernel.cu:191-226,
  * kernel :113-143).  prob_in, prob_out [N,NC,X,Y,Z]; rays run along Z:
  *   out[z] = in[z] * prod_{k<z} (1 - in[k])                                   */

@@ -161,6 +161,20 @@ class GenReGlueCPU:
         self.margin = margin
         self.grid = torch.from_numpy(unit_dirs(128).reshape(1, 1, 128, 128, 3)).float()
 
+    @staticmethod
+    def get_abs_depth(pred_depth, depth_minmax, silhou, scale_25d=100):
+        """depth_pred_with_sph_inpaint.py:131-142 with marrnetbase.py:138-151 inlined (postprocess = x / scale_25d,
+        to_abs_depth = rel * (max - min + 1e-4) + min), on CPU torch"""
+        pred = pred_depth / scale_25d                                  # postprocess (:133)
+        mm = depth_minmax.detach()                                     # :134
+        depth_min = mm[:, 0].view(-1, 1, 1, 1)
+        depth_max = mm[:, 1].view(-1, 1, 1, 1)
+        abs_depth = (1 - pred) * (depth_max - depth_min + 1e-4) + depth_min      # :135, marrnetbase.py:150
+        sil = (silhou / scale_25d).detach()                            # :136
+        abs_depth[sil < 0.5] = 0                                       # :137
+        abs_depth = abs_depth.permute(0, 1, 3, 2)                      # :138
+        return torch.flip(abs_depth, [2])                              # :139
+
     def depth_to_spherical(self, depth):
         n = depth.shape[0]
         tdf = self.hot.cam(depth, torch.full((n, 1), self.hot.fl), torch.full((n, 1), self.hot.cam_dist), 128)

@@ -54,3 +54,32 @@ def test_depth_to_spherical(genre, oracle, dev):
     assert sph.shape == (2, 1, 160, 160)
     assert (pd.cpu() - ref_pd).abs().max().item() <= 50 * 128 * TOL
     assert (sph.cpu() - ref_sph).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 256, 256), (3, 40, 72), (1, 33, 17)])
+def test_get_abs_depth_matches_reference_lines(n, h, w, genre, dev):
+    """GenReGeometry.get_abs_depth == depth_pred_with_sph_inpaint.py:131-142 run on CPU torch: plain fp32
+    elementwise arithmetic in the same order (true division) -> bit-identical values; gradient w.r.t. the
+    predicted depth to 1 ulp-level (autograd's division by a scalar may be a reciprocal multiply)"""
+    from genre_shapehd_amd.callers import GenReGeometry
+    from oracle.torch_oracle import GenReGlueCPU
+    rng = np.random.default_rng(11)
+    pred = torch.from_numpy(rng.uniform(0, 100, (n, 1, h, w)).astype(np.float32))
+    sil = torch.from_numpy((rng.uniform(0, 100, (n, 1, h, w))).astype(np.float32))
+    sil[:, :, : h // 3] = 0.0                                              # background rows
+    mm = torch.from_numpy(np.stack([rng.uniform(1.5, 1.9, n), rng.uniform(2.4, 2.9, n)], 1).astype(np.float32))
+    a = pred.clone().requires_grad_(True)
+    ref = GenReGlueCPU.get_abs_depth(a, mm, sil)
+    geo = GenReGeometry().to(dev)
+    b = pred.to(dev).requires_grad_(True)
+    out = geo.get_abs_depth(b, mm.to(dev), sil.to(dev))
+    assert out.shape == ref.shape == (n, 1, w, h)
+    assert torch.equal(out.cpu(), ref.detach())
+    g = torch.from_numpy(rng.standard_normal((n, 1, w, h)).astype(np.float32))
+    ref.backward(g)
+    out.backward(g.to(dev))
+    assert (b.grad.cpu() - a.grad).abs().max().item() <= 2e-7 * max(1.0, a.grad.abs().max().item())
+    # strided inputs (a channel slice) go through the same kernel
+    wide = torch.stack([pred, pred + 1], 1).reshape(n, 2, h, w).to(dev)
+    out2 = geo.get_abs_depth(wide[:, 0:1], mm.to(dev), sil.to(dev))
+    assert torch.equal(out2, out.detach())
