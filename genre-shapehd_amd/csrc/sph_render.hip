@@ -343,7 +343,8 @@ __device__ __forceinline__ void publish_max(float wmax, int lane, unsigned *dpma
 __device__ __forceinline__ void store_dp(const RenderDims &D, float *dst, int lane, const float (&dp)[4])
 {
     if ((D.ZR & 3) == 0) {
-        if (lane * 4 < D.ZR) *reinterpret_cast<float4 *>(dst) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        if (lane * 4 < D.ZR) __builtin_nontemporal_store((v4f){dp[0], dp[1], dp[2], dp[3]}, reinterpret_cast<v4f *>(dst));
     } else {
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
 #pragma unroll
                 for (int i = 0; i < 8; i++)
                     acc += tp[g * kTile3 + ((i & 1) ? kTile * kTile : 0) + ((i & 2) ? kTile : 0) + ((i & 4) ? 1 : 0)] * w[i];
-                vq[g * img_stride] = acc;
+                vq[g * img_stride] = acc;                   // plain store: L2 merges the partial lines (nontemporal: +60 us)
             }
         }
     }
