@@ -109,7 +109,7 @@ def kernel_table(G, dev, B):
     iters = max(20, 400 // B)
     rows = {}
     t = event_time_us(lambda: cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt), iters, 5)
-    rows["cam_bp_fwd"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="fill2_vec4+scatter+normalise")
+    rows["cam_bp_fwd"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="fill2_vec4+scatter_tile+normalise_tile")
     t = event_time_us(lambda: calc_prob_lib.calc_prob_forward(p, s), iters, 5)
     rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel")
     t = event_time_us(lambda: calc_prob_lib.calc_prob_backward_fused(p, s, g, o), iters, 5)

@@ -7,7 +7,8 @@
 // voxel and n-fastest (uncoalesced) indexing.  Here a forward is
 //   (1) one float4 streaming fill of tdf and cnt (the only full-volume pass;
 //       16 B/lane stores, the algorithmic minimum of 2 x 4 B per voxel),
-//   (2) the scatter, one lane per pixel, hardware fp32 atomics at L2,
+//   (2) the scatter: a wave per 8x8 pixel tile, pixels of one voxel merged with
+//       DPP moves, then hardware fp32 atomics at L2 (one pair per voxel and tile),
 //   (3) a per-PIXEL normalise that touches only the voxels that were hit
 //       (<= H*W of them) instead of re-streaming the whole volume.
 // (3) needs to know whether a voxel still holds a raw sum or was already
@@ -114,82 +115,197 @@ __global__ __launch_bounds__(kBlock) void fill2_strided_kernel(Dims D, View5 a, 
     }
 }
 
-// ---- (2) scatter --------------------------------------------------------------
-template <bool SPH>
-__device__ __forceinline__ void scatter_pixel(const Dims &D, const View4 &depth, const View2 &camdist, const View2 &fl,
-                                              const View5 &grid, const View5 &vox, const View5 &cnt, float empty_val,
-                                              float fill_val, int64_t idx)
+// ---- (2) scatter and (3) normalise: neighbouring pixels are combined before they touch memory ---------
+// The scatter is bound by the rate of global float atomics (~15-18 G/s measured): a 256^2 image puts ~2x2
+// pixels into every surface voxel, i.e. four atomic pairs per voxel.  Here a wave owns an 8x8 pixel tile
+// (lane = y*8 + x) and pixels that landed in the same voxel are merged with DPP moves first -- (x,x+1) pairs
+// at even x, then at odd x, then (y,y+1) pairs at even y (all inside one 16-lane DPP row) -- so a voxel usually
+// costs ONE atomic pair.  The survivor ("leader") carries the count and the sum of the absorbed distances.
+// Single-hit voxels are untouched by this (bit-exact as before); for multi-hit voxels only the summation
+// order changes, which the reference's atomics do not define either.
+constexpr int kRowShl1 = 0x101, kRowShl8 = 0x108, kRowShr1c = 0x111, kRowShr8 = 0x118;
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
 {
-    int n, c, h, w;
-    decode_pixel(D, idx, n, c, h, w);
-    float d_raw, gx, gy, gz, u_h, u_w, f;
-    if (!pixel_point<SPH>(D, depth, camdist, fl, grid, n, c, h, w, d_raw, gx, gy, gz, u_h, u_w, f)) return;
-    const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
-    if (!in_grid(D, ix, iy, iz)) return;                             // :252
-    const float dist = norm3(gx - centre_f(ix, D.X), gy - centre_f(iy, D.Y), gz - centre_f(iz, D.Z));
-    float *pc = cnt.p + n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4;
-    float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
-    // Negated accumulation (see file header).  The reference starts every sum at the prefill e = 1/res
-    // (0 on the spherical path) and subtracts it again in K2 (:304): the first point contributes
-    // t = fl(e + dist) - e (exact).  The first arriver reproduces that rounding and cancels whatever
-    // the fill pass wrote; later arrivers just add, as the reference's atomics do.
-    const float t = (dist + empty_val) - empty_val;
-    if (fill_val == 0.0f) {
-        // nothing to cancel (spherical path, and the camera path with the shift folded in): no need to
-        // know who is first, so both atomics are fire-and-forget (no return value, no dependent latency)
-        unsafeAtomicAdd(pc, 1.0f);                                   // :274
-        unsafeAtomicAdd(pv, -t);                                     // :273
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+
+// one merge step: lanes selected by `takes` absorb the lane SHL positions above them when both hold the same key;
+// the absorbed lane (selected by `gives`, looking SHR positions down) retires
+template <int SHL, int SHR>
+__device__ __forceinline__ void merge_step(bool takes, bool gives, int &key, float &rest, float &n, float dist)
+{
+    const int up_key = dpp_i<SHL>(key);
+    const float up_sum = dpp_f<SHL>(dist + rest), up_n = dpp_f<SHL>(n);
+    const int down_key = dpp_i<SHR>(key);
+    const bool absorb = takes && key >= 0 && up_key == key;
+    const bool retire = gives && key >= 0 && down_key == key;
+    if (absorb) { rest += up_sum; n += up_n; }
+    if (retire) key = -1;
+}
+
+// pixel (tile, lane): image, row, column; false outside the image
+__device__ __forceinline__ bool tile_coords(const Dims &D, int64_t tile, int lane, int &n, int &c, int &h, int &w)
+{
+    const int tw = (D.W + 7) >> 3, th = (D.H + 7) >> 3;
+    const int tx = (int)(tile % tw); tile /= tw;
+    const int ty = (int)(tile % th); tile /= th;
+    c = (int)(tile % D.NC);
+    n = (int)(tile / D.NC);
+    h = ty * 8 + (lane >> 3); w = tx * 8 + (lane & 7);
+    return h < D.H && w < D.W;
+}
+
+// voxel of a pixel whose depth (and, spherical path, direction) has been fetched: key = linear voxel index
+// inside the image, or -1.  Same arithmetic as pixel_point.
+template <bool SPH>
+__device__ __forceinline__ int pixel_voxel(const Dims &D, bool valid, float d_raw, float g0, float g1, float g2, float f,
+                                           float cam_dist, int h, int w, int &ix, int &iy, int &iz, float &dist)
+{
+    dist = 0.f; ix = iy = iz = 0;
+    if (!valid || d_raw < 0.0f) return -1;                           // :225 / :501
+    float gx, gy, gz;
+    if (SPH) {
+        gx = g0 * d_raw; gy = g1 * d_raw; gz = g2 * d_raw;           // :506-508
     } else {
-        const float old = unsafeAtomicAdd(pc, 1.0f);                 // hardware global_atomic_add_f32, returning
-        unsafeAtomicAdd(pv, (old == 0.0f) ? -(t + fill_val) : -dist);
+        const float u_h = (float)h - ((float)D.H - 1.0f) / 2.0f;    // :231-242
+        const float u_w = (float)w - ((float)D.W - 1.0f) / 2.0f;
+        const float cos_theta = f / norm3(u_h, u_w, f);
+        const float d = d_raw * cos_theta;
+        gy = -d * u_w / f;
+        gz = -d * u_h / f;
+        gx = d - cam_dist;
+    }
+    ix = vox_index(gx, D.X); iy = vox_index(gy, D.Y); iz = vox_index(gz, D.Z);
+    if (!in_grid(D, ix, iy, iz)) return -1;                          // :252
+    dist = norm3(gx - centre_f(ix, D.X), gy - centre_f(iy, D.Y), gz - centre_f(iz, D.Z));
+    return (ix * D.Y + iy) * D.Z + iz;
+}
+
+__device__ __forceinline__ void merge_tile(int lane, int &key, float &rest, float &n, float dist)
+{
+    const int x = lane & 7, y = lane >> 3;
+    merge_step<kRowShl1, kRowShr1c>((x & 1) == 0, (x & 1) == 1, key, rest, n, dist);
+    merge_step<kRowShl1, kRowShr1c>((x & 1) == 1 && x < 7, (x & 1) == 0 && x > 0, key, rest, n, dist);
+    merge_step<kRowShl8, kRowShr8>((y & 1) == 0, (y & 1) == 1, key, rest, n, dist);
+}
+
+// A wave walks its tiles two at a time with the loads of both in flight (depth first, then -- normalise --
+// the sum / count gathers): at batch 32 a wave sees four tiles, and one dependent latency chain per tile was
+// most of the kernel.
+constexpr int kTilesInFlight = 2;
+
+struct TileLanes {
+    int n[kTilesInFlight], c[kTilesInFlight], ix[kTilesInFlight], iy[kTilesInFlight], iz[kTilesInFlight], key[kTilesInFlight];
+    float dist[kTilesInFlight], rest[kTilesInFlight], num[kTilesInFlight];
+};
+
+template <bool SPH>
+__device__ __forceinline__ void load_tiles(const Dims &D, const View4 &depth, const View2 &camdist, const View2 &fl,
+                                           const View5 &grid, int64_t tile0, int64_t stride, int64_t tiles, int lane,
+                                           TileLanes &T)
+{
+    int h[kTilesInFlight], w[kTilesInFlight];
+    bool valid[kTilesInFlight];
+    float d_raw[kTilesInFlight], g0[kTilesInFlight], g1[kTilesInFlight], g2[kTilesInFlight], f[kTilesInFlight],
+        cd[kTilesInFlight];
+#pragma unroll
+    for (int u = 0; u < kTilesInFlight; u++) {
+        const int64_t tile = tile0 + u * stride;
+        const bool in_image = tile_coords(D, tile < tiles ? tile : 0, lane, T.n[u], T.c[u], h[u], w[u]);
+        valid[u] = tile < tiles && in_image;
+        d_raw[u] = -1.f; g0[u] = g1[u] = g2[u] = f[u] = cd[u] = 0.f;
+        if (valid[u]) {
+            d_raw[u] = depth.p[T.n[u] * depth.s0 + T.c[u] * depth.s1 + h[u] * depth.s2 + w[u] * depth.s3];
+            if (SPH) {
+                const float *gp = grid.p + T.n[u] * grid.s0 + T.c[u] * grid.s1 + h[u] * grid.s2 + w[u] * grid.s3;
+                g0[u] = gp[0]; g1[u] = gp[grid.s4]; g2[u] = gp[2 * grid.s4];
+            } else {
+                f[u] = fl.p[T.n[u] * fl.s0 + T.c[u] * fl.s1];
+                cd[u] = camdist.p[T.n[u] * camdist.s0 + T.c[u] * camdist.s1];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kTilesInFlight; u++) {
+        T.key[u] = pixel_voxel<SPH>(D, valid[u], d_raw[u], g0[u], g1[u], g2[u], f[u], cd[u], h[u], w[u], T.ix[u], T.iy[u],
+                                    T.iz[u], T.dist[u]);
+        T.rest[u] = 0.f; T.num[u] = 1.f;
+        merge_tile(lane, T.key[u], T.rest[u], T.num[u], T.dist[u]);
     }
 }
 
 template <bool SPH>
-__global__ __launch_bounds__(kBlock) void scatter_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
-                                                          View5 grid, View5 vox, View5 cnt, float empty_val,
-                                                          float fill_val)
+__global__ __launch_bounds__(kBlock) void scatter_tile_kernel(Dims D, View4 depth, View2 camdist, View2 fl, View5 grid,
+                                                               View5 vox, View5 cnt, float empty_val, float fill_val)
 {
-    const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
-    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * kBlock)
-        scatter_pixel<SPH>(D, depth, camdist, fl, grid, vox, cnt, empty_val, fill_val, idx);
-}
-
-// ---- (3) normalise, per pixel ---------------------------------------------------
-template <bool SPH>
-__device__ __forceinline__ void normalise_pixel(const Dims &D, const View4 &depth, const View2 &camdist,
-                                                const View2 &fl, const View5 &grid, const View5 &vox,
-                                                const View5 &cnt, float post_scale, float post_bias, int post_mode,
-                                                int64_t idx)
-{
-    int n, c, h, w;
-    decode_pixel(D, idx, n, c, h, w);
-    float d_raw, gx, gy, gz, u_h, u_w, f;
-    if (!pixel_point<SPH>(D, depth, camdist, fl, grid, n, c, h, w, d_raw, gx, gy, gz, u_h, u_w, f)) return;
-    const int ix = vox_index(gx, D.X), iy = vox_index(gy, D.Y), iz = vox_index(gz, D.Z);
-    if (!in_grid(D, ix, iy, iz)) return;
-    float *pv = vox.p + n * vox.s0 + c * vox.s1 + ix * vox.s2 + iy * vox.s3 + iz * vox.s4;
-    const float s = *pv;
-    if (s < 0.0f) {                                                   // still a raw (negated) sum
-        const float k = cnt.p[n * cnt.s0 + c * cnt.s1 + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4];
-        // :304 (mean distance); post = identity (scale 1, bias 0), the camera layer's shift 1 - res*tdf
-        // (mode 0 with scale -res, bias 1), or GenRe's spherical glue (-tdf + 1/res)*res (mode 1,
-        // genre_full_model.py:141: post_bias holds 1/res, post_scale holds res)
-        const float mean = (0.0f - s) / k;
-        *pv = post_mode == 1 ? (-mean + post_bias) * post_scale : post_bias + post_scale * mean;
+    const int lane = threadIdx.x & 63;
+    const int64_t tiles = (int64_t)D.N * D.NC * ((D.H + 7) >> 3) * ((D.W + 7) >> 3);
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); tile < tiles;
+         tile += kTilesInFlight * stride) {
+        TileLanes T;
+        load_tiles<SPH>(D, depth, camdist, fl, grid, tile, stride, tiles, lane, T);
+#pragma unroll
+        for (int u = 0; u < kTilesInFlight; u++) {
+            if (T.key[u] < 0) continue;
+            float *pc = cnt.p + T.n[u] * cnt.s0 + T.c[u] * cnt.s1 + T.ix[u] * cnt.s2 + T.iy[u] * cnt.s3 + T.iz[u] * cnt.s4;
+            float *pv = vox.p + T.n[u] * vox.s0 + T.c[u] * vox.s1 + T.ix[u] * vox.s2 + T.iy[u] * vox.s3 + T.iz[u] * vox.s4;
+            // Negated accumulation (see file header).  The reference starts every sum at the prefill e = 1/res
+            // (0 on the spherical path) and subtracts it again in K2 (:304): the first point contributes
+            // t = fl(e + dist) - e (exact).  The first arriver -- detected by the count's atomic return value --
+            // reproduces that rounding and cancels whatever the fill pass wrote; later arrivers just add, as the
+            // reference's atomics do.  When there is nothing to cancel (spherical path, and the camera path with
+            // the shift folded in) nobody needs to know who is first: both atomics are fire-and-forget.
+            const float t = (T.dist[u] + empty_val) - empty_val;
+            if (fill_val == 0.0f) {
+                unsafeAtomicAdd(pc, T.num[u]);                           // :274
+                unsafeAtomicAdd(pv, -(t + T.rest[u]));                   // :273
+            } else {
+                const float old = unsafeAtomicAdd(pc, T.num[u]);
+                unsafeAtomicAdd(pv, (old == 0.0f) ? -((t + fill_val) + T.rest[u]) : -(T.dist[u] + T.rest[u]));
+            }
+        }
     }
 }
 
 template <bool SPH>
-__global__ __launch_bounds__(kBlock) void normalise_kernel(Dims D, View4 depth, View2 camdist, View2 fl,
-                                                            View5 grid, View5 vox, View5 cnt, float post_scale,
-                                                            float post_bias, int post_mode)
+__global__ __launch_bounds__(kBlock) void normalise_tile_kernel(Dims D, View4 depth, View2 camdist, View2 fl, View5 grid,
+                                                                 View5 vox, View5 cnt, float post_scale, float post_bias,
+                                                                 int post_mode)
 {
-    const int64_t total = (int64_t)D.N * D.NC * D.H * D.W;
-    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * kBlock)
-        normalise_pixel<SPH>(D, depth, camdist, fl, grid, vox, cnt, post_scale, post_bias, post_mode, idx);
+    const int lane = threadIdx.x & 63;
+    const int64_t tiles = (int64_t)D.N * D.NC * ((D.H + 7) >> 3) * ((D.W + 7) >> 3);
+    const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); tile < tiles;
+         tile += kTilesInFlight * stride) {
+        TileLanes T;
+        load_tiles<SPH>(D, depth, camdist, fl, grid, tile, stride, tiles, lane, T);   // one lane per voxel and tile works
+        float s[kTilesInFlight], k[kTilesInFlight];
+        float *pv[kTilesInFlight];
+#pragma unroll
+        for (int u = 0; u < kTilesInFlight; u++) {
+            pv[u] = vox.p + T.n[u] * vox.s0 + T.c[u] * vox.s1 + T.ix[u] * vox.s2 + T.iy[u] * vox.s3 + T.iz[u] * vox.s4;
+            s[u] = 0.f; k[u] = 1.f;
+            if (T.key[u] >= 0) {
+                s[u] = *pv[u];
+                k[u] = cnt.p[T.n[u] * cnt.s0 + T.c[u] * cnt.s1 + T.ix[u] * cnt.s2 + T.iy[u] * cnt.s3 + T.iz[u] * cnt.s4];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kTilesInFlight; u++) {
+            if (T.key[u] >= 0 && s[u] < 0.0f) {                           // still a raw (negated) sum
+                // :304 (mean distance); post = identity (scale 1, bias 0), the camera layer's shift 1 - res*tdf
+                // (mode 0 with scale -res, bias 1), or GenRe's spherical glue (-tdf + 1/res)*res (mode 1,
+                // genre_full_model.py:141: post_bias holds 1/res, post_scale holds res)
+                const float mean = (0.0f - s[u]) / k[u];
+                *pv[u] = post_mode == 1 ? (-mean + post_bias) * post_scale : post_bias + post_scale * mean;
+            }
+        }
+    }
 }
 
 // ---- camera forward, single-launch GATHER formulation --------------------------------------------
@@ -721,11 +837,13 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
     const int64_t npix = (int64_t)D.N * D.NC * D.H * D.W;
     if (!launch_fill2(D, voxel, fill_val, cnt, 0.0f, st)) return 0;
     if (npix == 0 || (int64_t)D.X * D.Y * D.Z == 0) return 1;
-    const int g = grid_for(npix);
-    scatter_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), empty_val, fill_val);
+    const int64_t tiles = (int64_t)D.N * D.NC * ((D.H + 7) / 8) * ((D.W + 7) / 8);
+    const int g = grid_for(tiles * 64);
+    scatter_tile_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), empty_val,
+                                                   fill_val);
     GENRE_LAUNCH_CHECK("projection forward");
-    normalise_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), post_scale,
-                                                post_bias, post_mode);
+    normalise_tile_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt),
+                                                     post_scale, post_bias, post_mode);
     GENRE_LAUNCH_CHECK("safe divide");
     return 1;
 }
