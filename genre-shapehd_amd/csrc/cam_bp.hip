@@ -147,16 +147,24 @@ __device__ __forceinline__ void merge_step(bool takes, bool gives, int &key, flo
     if (retire) key = -1;
 }
 
-// pixel (tile, lane): image, row, column; false outside the image
-__device__ __forceinline__ bool tile_coords(const Dims &D, int64_t tile, int lane, int &n, int &c, int &h, int &w)
+// pixel (tile, lane): image, row, column; false outside the image.  `tile` is wave-uniform and fits 32 bits
+// (host-checked), so the decode runs on the scalar unit.
+__device__ __forceinline__ bool tile_coords(const Dims &D, int tile, int lane, int &n, int &c, int &h, int &w)
 {
     const int tw = (D.W + 7) >> 3, th = (D.H + 7) >> 3;
-    const int tx = (int)(tile % tw); tile /= tw;
-    const int ty = (int)(tile % th); tile /= th;
-    c = (int)(tile % D.NC);
-    n = (int)(tile / D.NC);
+    const int tx = tile % tw; tile /= tw;
+    const int ty = tile % th; tile /= th;
+    c = tile % D.NC;
+    n = tile / D.NC;
     h = ty * 8 + (lane >> 3); w = tx * 8 + (lane & 7);
     return h < D.H && w < D.W;
+}
+
+// element offset of voxel (ix,iy,iz) inside one image: 32-bit (the host checks that an image's volume spans
+// fewer than 2^31 elements), so the per-lane part of the address is three 32-bit multiply-adds
+__device__ __forceinline__ int vox_off(const View5 &v, int ix, int iy, int iz)
+{
+    return ix * (int)v.s2 + iy * (int)v.s3 + iz * (int)v.s4;
 }
 
 // voxel of a pixel whose depth (and, spherical path, direction) has been fetched: key = linear voxel index
@@ -205,8 +213,7 @@ struct TileLanes {
 
 template <bool SPH>
 __device__ __forceinline__ void load_tiles(const Dims &D, const View4 &depth, const View2 &camdist, const View2 &fl,
-                                           const View5 &grid, int64_t tile0, int64_t stride, int64_t tiles, int lane,
-                                           TileLanes &T)
+                                           const View5 &grid, int tile0, int stride, int tiles, int lane, TileLanes &T)
 {
     int h[kTilesInFlight], w[kTilesInFlight];
     bool valid[kTilesInFlight];
@@ -214,14 +221,14 @@ __device__ __forceinline__ void load_tiles(const Dims &D, const View4 &depth, co
         cd[kTilesInFlight];
 #pragma unroll
     for (int u = 0; u < kTilesInFlight; u++) {
-        const int64_t tile = tile0 + u * stride;
+        const int tile = tile0 + u * stride;
         const bool in_image = tile_coords(D, tile < tiles ? tile : 0, lane, T.n[u], T.c[u], h[u], w[u]);
         valid[u] = tile < tiles && in_image;
         d_raw[u] = -1.f; g0[u] = g1[u] = g2[u] = f[u] = cd[u] = 0.f;
         if (valid[u]) {
-            d_raw[u] = depth.p[T.n[u] * depth.s0 + T.c[u] * depth.s1 + h[u] * depth.s2 + w[u] * depth.s3];
+            d_raw[u] = depth.p[(T.n[u] * depth.s0 + T.c[u] * depth.s1) + (h[u] * (int)depth.s2 + w[u] * (int)depth.s3)];
             if (SPH) {
-                const float *gp = grid.p + T.n[u] * grid.s0 + T.c[u] * grid.s1 + h[u] * grid.s2 + w[u] * grid.s3;
+                const float *gp = grid.p + (T.n[u] * grid.s0 + T.c[u] * grid.s1) + (h[u] * (int)grid.s2 + w[u] * (int)grid.s3);
                 g0[u] = gp[0]; g1[u] = gp[grid.s4]; g2[u] = gp[2 * grid.s4];
             } else {
                 f[u] = fl.p[T.n[u] * fl.s0 + T.c[u] * fl.s1];
@@ -243,17 +250,17 @@ __global__ __launch_bounds__(kBlock) void scatter_tile_kernel(Dims D, View4 dept
                                                                View5 vox, View5 cnt, float empty_val, float fill_val)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t tiles = (int64_t)D.N * D.NC * ((D.H + 7) >> 3) * ((D.W + 7) >> 3);
-    const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
-    for (int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); tile < tiles;
+    const int tiles = D.N * D.NC * ((D.H + 7) >> 3) * ((D.W + 7) >> 3);
+    const int stride = gridDim.x * (kBlock / 64);
+    for (int tile = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); tile < tiles;
          tile += kTilesInFlight * stride) {
         TileLanes T;
         load_tiles<SPH>(D, depth, camdist, fl, grid, tile, stride, tiles, lane, T);
 #pragma unroll
         for (int u = 0; u < kTilesInFlight; u++) {
             if (T.key[u] < 0) continue;
-            float *pc = cnt.p + T.n[u] * cnt.s0 + T.c[u] * cnt.s1 + T.ix[u] * cnt.s2 + T.iy[u] * cnt.s3 + T.iz[u] * cnt.s4;
-            float *pv = vox.p + T.n[u] * vox.s0 + T.c[u] * vox.s1 + T.ix[u] * vox.s2 + T.iy[u] * vox.s3 + T.iz[u] * vox.s4;
+            float *pc = cnt.p + (T.n[u] * cnt.s0 + T.c[u] * cnt.s1) + vox_off(cnt, T.ix[u], T.iy[u], T.iz[u]);
+            float *pv = vox.p + (T.n[u] * vox.s0 + T.c[u] * vox.s1) + vox_off(vox, T.ix[u], T.iy[u], T.iz[u]);
             // Negated accumulation (see file header).  The reference starts every sum at the prefill e = 1/res
             // (0 on the spherical path) and subtracts it again in K2 (:304): the first point contributes
             // t = fl(e + dist) - e (exact).  The first arriver -- detected by the count's atomic return value --
@@ -278,9 +285,9 @@ __global__ __launch_bounds__(kBlock) void normalise_tile_kernel(Dims D, View4 de
                                                                  int post_mode)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t tiles = (int64_t)D.N * D.NC * ((D.H + 7) >> 3) * ((D.W + 7) >> 3);
-    const int64_t stride = (int64_t)gridDim.x * (kBlock / 64);
-    for (int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); tile < tiles;
+    const int tiles = D.N * D.NC * ((D.H + 7) >> 3) * ((D.W + 7) >> 3);
+    const int stride = gridDim.x * (kBlock / 64);
+    for (int tile = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); tile < tiles;
          tile += kTilesInFlight * stride) {
         TileLanes T;
         load_tiles<SPH>(D, depth, camdist, fl, grid, tile, stride, tiles, lane, T);   // one lane per voxel and tile works
@@ -288,11 +295,11 @@ __global__ __launch_bounds__(kBlock) void normalise_tile_kernel(Dims D, View4 de
         float *pv[kTilesInFlight];
 #pragma unroll
         for (int u = 0; u < kTilesInFlight; u++) {
-            pv[u] = vox.p + T.n[u] * vox.s0 + T.c[u] * vox.s1 + T.ix[u] * vox.s2 + T.iy[u] * vox.s3 + T.iz[u] * vox.s4;
+            pv[u] = vox.p + (T.n[u] * vox.s0 + T.c[u] * vox.s1) + vox_off(vox, T.ix[u], T.iy[u], T.iz[u]);
             s[u] = 0.f; k[u] = 1.f;
             if (T.key[u] >= 0) {
                 s[u] = *pv[u];
-                k[u] = cnt.p[T.n[u] * cnt.s0 + T.c[u] * cnt.s1 + T.ix[u] * cnt.s2 + T.iy[u] * cnt.s3 + T.iz[u] * cnt.s4];
+                k[u] = cnt.p[(T.n[u] * cnt.s0 + T.c[u] * cnt.s1) + vox_off(cnt, T.ix[u], T.iy[u], T.iz[u])];
             }
         }
 #pragma unroll
@@ -838,6 +845,14 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
     if (!launch_fill2(D, voxel, fill_val, cnt, 0.0f, st)) return 0;
     if (npix == 0 || (int64_t)D.X * D.Y * D.Z == 0) return 1;
     const int64_t tiles = (int64_t)D.N * D.NC * ((D.H + 7) / 8) * ((D.W + 7) / 8);
+    auto span32 = [](const genre_tensor *t, int first) {          // per-image extent in elements < 2^31 ?
+        int64_t span = 1;
+        for (int i = first; i < t->ndim; i++) span += (t->size[i] - 1) * (t->stride[i] < 0 ? -t->stride[i] : t->stride[i]);
+        return span < ((int64_t)1 << 31);
+    };
+    GENRE_REQUIRE(tiles < ((int64_t)1 << 30) && span32(voxel, 2) && span32(cnt, 2) && span32(depth, 2) &&
+                      (!SPH || span32(grid, 2)),
+                  "%s: one image (map or volume) must span fewer than 2^31 elements", op);
     const int g = grid_for(tiles * 64);
     scatter_tile_kernel<SPH><<<g, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, vgrid, view5(voxel), view5(cnt), empty_val,
                                                    fill_val);
