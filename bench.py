@@ -130,7 +130,7 @@ def kernel_table(G, dev, B):
         t = event_time_us(lambda: render_lib.render_spherical_forward(
             proj, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0), iters, 5)
         rows["render_fwd_fused"] = dict(us=t, bytes=B * BYTES_RENDER_FUSED,
-                                        kernels="render_sample_brick_kernel+render_scan_fwd_kernel")
+                                        kernels="render_sample_brick_group_kernel+render_scan_fwd_kernel")
         t = event_time_us(lambda: render_lib.render_spherical_backward(
             proj, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"], vbuf, T["kin"], 50.0),
             iters, 5)

@@ -386,97 +386,12 @@ __global__ __launch_bounds__(kBlock) void render_bwd_dp_kernel(RenderDims D, Vie
 // sample appears once, under the brick that holds its base corner.  The workgroup stages the brick plus a one-voxel halo
 // (18^3 floats, zeros outside the volume) with coalesced row reads -- each voxel leaves HBM/L2 once per
 // row instead of once per tap -- then evaluates its samples with 8 LDS reads each and writes the raw
-// value v[ray, k] (16 consecutive floats per chunk).
+// value v[ray, k].
 constexpr int kTile = kBrick + 2;
-__global__ __launch_bounds__(kBlock) void render_sample_brick_kernel(RenderDims D, View5 vox,
-                                                                      const double *__restrict__ dirs,
-                                                                      const int *__restrict__ fwd_table,
-                                                                      const int *__restrict__ fwd_list,
-                                                                      float *__restrict__ vbuf)
-{
-    __shared__ float tile[kTile * kTile * kTile];
-    const int img = blockIdx.y;
-    const int brick = fwd_table[blockIdx.x * 4 + 0];
-    const int begin = fwd_table[blockIdx.x * 4 + 1], end = fwd_table[blockIdx.x * 4 + 2];
-    const int nby = (D.Y + kBrick - 1) / kBrick, nbz = (D.Z + kBrick - 1) / kBrick;
-    const int ox = (brick / (nby * nbz)) * kBrick - 1, oy = ((brick / nbz) % nby) * kBrick - 1,
-              oz = (brick % nbz) * kBrick - 1;                            // tile origin (incl. halo)
-    const float *__restrict__ base = vox.p + (img / D.NC) * vox.s0 + (img % D.NC) * vox.s1;
-    // all of a thread's tile elements are requested before the first one is used: written as a plain loop the
-    // compiler waits for every load in turn (23 exposed latencies per workgroup).  Element t = thread + i*256
-    // is walked incrementally -- 256 = 14*kTile + 4 -- so the loop has no division and no address multiply
-    // (runtime strides make those quarter-rate v_mul_lo_u32: they were ~30 % of this kernel's issue time).
-    constexpr int kPerThread = (kTile * kTile * kTile + kBlock - 1) / kBlock;
-    static_assert(kBlock < kTile * kTile && kBlock / kTile == 14 && kBlock % kTile == 4, "tile walk constants");
-    float vals[kPerThread];
-    {
-        int lz = (int)threadIdx.x % kTile, ly = (int)threadIdx.x / kTile;
-        int x = ox, y = oy + ly, z = oz + lz;
-        int off = x * D.sx + y * D.sy + z * D.sz;
-        const int step = 14 * D.sy + 4 * D.sz, wrap_z = D.sy - kTile * D.sz, wrap_y = D.sx - kTile * D.sy;
-        unsigned inside = 0;                        // bit i: element i lies in the volume
-#pragma unroll
-        for (int i = 0; i < kPerThread; i++) {
-            vals[i] = 0.f;
-            if ((int)threadIdx.x + i * kBlock < kTile * kTile * kTile && (unsigned)x < (unsigned)D.X &&
-                (unsigned)y < (unsigned)D.Y && (unsigned)z < (unsigned)D.Z) {
-                vals[i] = base[off];
-                inside |= 1u << i;
-            }
-            lz += 4; z += 4; ly += 14; y += 14; off += step;
-            if (lz >= kTile) { lz -= kTile; z -= kTile; ly += 1; y += 1; off += wrap_z; }
-            if (ly >= kTile) { ly -= kTile; y -= kTile; x += 1; off += wrap_y; }
-        }
-        if (D.pre_scale != 0.0f) {                  // clamp(x * pre_scale)  (depth_pred_with_sph_inpaint.py:124);
-#pragma unroll                                      // halo cells outside the volume stay 0 (grid_sample zero padding)
-            for (int i = 0; i < kPerThread; i++)
-                if (inside & (1u << i)) vals[i] = fminf(fmaxf(vals[i] * D.pre_scale, D.lo), D.hi);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < kPerThread; i++) {
-        const int t = threadIdx.x + i * kBlock;
-        if (t < kTile * kTile * kTile) tile[t] = vals[i];
-    }
-    __syncthreads();
-    float *__restrict__ vi = vbuf + (int64_t)img * D.R * D.R * D.ZR;
-    // one lane per listed sample (entries are sorted by ray, then sample: neighbouring lanes mostly share the
-    // ray, so the direction loads coalesce to a few addresses and the v stores to 64-byte runs)
-    for (int e0 = begin + threadIdx.x; e0 < end; e0 += 4 * kBlock) {
-        unsigned ent[4];
-        double d2[4][3];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = e0 + u * kBlock;
-            ent[u] = (unsigned)fwd_list[e < end ? e : e0];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int q = (int)(ent[u] >> 8);
-            d2[u][0] = dirs[q * 3 + 0]; d2[u][1] = dirs[q * 3 + 1]; d2[u][2] = dirs[q * 3 + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (e0 + u * kBlock >= end) break;
-            const int q = (int)(ent[u] >> 8), k = (int)(ent[u] & 255u);
-            float gx, gy, gz;
-            sample_pos(D, d2[u][0] * 2, d2[u][1] * 2, d2[u][2] * 2, k, gx, gy, gz);
-            Cell c;
-            locate(D, gx, gy, gz, c);
-            const float *tp = tile + ((c.x0 - ox) * kTile + (c.y0 - oy)) * kTile + (c.z0 - oz);
-            float acc = 0.f;                                              // ATen corner order, zeros outside
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                acc += tp[((i & 1) ? kTile * kTile : 0) + ((i & 2) ? kTile : 0) + ((i & 4) ? 1 : 0)] * corner_w(c, i);
-            vi[(int64_t)q * D.ZR + k] = acc;
-        }
-    }
-}
 
-// ---- brick path for batches: G images per workgroup ---------------------------------------------------
 // Which cell a listed sample falls in and its eight trilinear weights depend on the geometry only, not on the
 // image -- and that arithmetic (fp64 position, floor/convert, weight products: ~80 of the ~100 VALU instructions
-// per sample, most of them 4-cycle forms) is what bounds render_sample_brick_kernel.  For a batch, a workgroup
+// per sample, most of them 4-cycle forms) dominated a one-image-per-workgroup sampler.  For a batch, a workgroup
 // therefore keeps the tiles of G images resident in LDS, walks the brick's sample list ONCE and evaluates every
 // sample on all resident tiles: the geometry is paid once per G images, the per-image part is 8 LDS reads +
 // 8 multiply-adds + one store.
@@ -955,14 +870,12 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
         GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R,
                       "%s: kin must be int32 [R*R]", op);
         const int imgs = D.N * D.NC;
-        if (imgs >= 2) {        // batches: kGroup images share one walk over the sample list
-            if (!launch_sample_group<kGroup, kGroupBlock>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, st))
-                return 0;
-        } else {
-            render_sample_brick_kernel<<<dim3(rows, imgs), kBlock, 0, st>>>(
-                D, view5(vox), (const double *)dirs->data, (const int *)fwd_table->data,
-                (const int *)fwd_chunks->data, (float *)v_scratch->data);
-        }
+        // batches: kGroup images share one walk over the sample list; a lone image gets the same kernel with G = 1
+        // (512 threads per workgroup: 38.9 us for the batch-1 forward chain against 42.1 with 256, 42.2 with 1024)
+        const int ok = imgs >= 2
+            ? launch_sample_group<kGroup, kGroupBlock>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, st)
+            : launch_sample_group<1, 512>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, st);
+        if (!ok) return 0;
         GENRE_LAUNCH_CHECK("render_spherical forward (bricks)");
         render_scan_fwd_kernel<<<scan_grid(D), kBlock, 0, st>>>(
             D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data, view4(out));
