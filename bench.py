@@ -39,14 +39,14 @@ BYTES_CP_BWD_FUSED = 4 * 128 * 128 * 256 * 4              # p, s, grad in + grad
 BYTES_RENDER_FUSED = 128 ** 3 * 4 + 128 * 128 * 4         # vox in + map out           =  8 454 144
 
 
-# profiles/r01f_pmc_hbm_traffic.txt, bytes per launch at batch 32 (kernel groups as in kernel_table)
-PMC_TRAFFIC_SOURCE = "profiles/r01f_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+# profiles/r01g_pmc_hbm_traffic.txt, bytes per launch at batch 32 (kernel groups as in kernel_table)
+PMC_TRAFFIC_SOURCE = "profiles/r01g_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 PMC_TRAFFIC_B32 = {
-    "render_bwd_fused": 918.0e6 + 1292.1e6 + 96.1e6,     # scan_bwd + bwd_brick + zero_shared_bricks
-    "render_fwd_fused": 1104.0e6 + 367.3e6,              # sample_brick + scan_fwd
+    "render_bwd_fused": 710.1e6 + 1296.3e6 + 96.2e6,     # scan_bwd + bwd_brick + zero_shared_bricks
+    "render_fwd_fused": 1017.7e6 + 367.5e6,              # sample_brick_group + scan_fwd
     "calc_prob_fwd": 1073.8e6,
-    "calc_prob_bwd_fused": 2147.6e6,
-    "cam_bp_fwd": 537.8e6 + 43.1e6 + 111.3e6,            # fill + scatter + normalise
+    "calc_prob_bwd_fused": 2147.7e6,
+    "cam_bp_fwd": 538.9e6 + 24.3e6 + 50.5e6,             # fill + scatter_tile + normalise_tile
 }
 
 
