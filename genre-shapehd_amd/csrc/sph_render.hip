@@ -437,8 +437,11 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
 #pragma unroll
         for (int i = 0; i < kPer; i++) {
             vals[i] = 0.f;
-            if ((int)threadIdx.x + i * NT < kTile3 && (unsigned)x < (unsigned)D.X && (unsigned)y < (unsigned)D.Y &&
-                (unsigned)z < (unsigned)D.Z) {
+            // The LOW halo planes (x == ox, y == oy, z == oz) are never fetched: a sample is listed under the brick of
+            // its base corner, so inside the volume it reads tile indices 1..17 only; index 0 is reached only by base
+            // corner -1, i.e. outside the volume, where grid_sample's zero padding applies.  That also makes every
+            // z-row start on a 64-byte boundary (17 floats = 2 sectors instead of 18 floats straddling 3).
+            if ((int)threadIdx.x + i * NT < kTile3 && x > ox && y > oy && z > oz && x < D.X && y < D.Y && z < D.Z) {
                 vals[i] = base[off];
                 inside |= 1u << i;
             }
