@@ -70,6 +70,24 @@ def test_validation_errors_do_not_launch(genre):
     rc = lib.genre_nnd_forward(C.byref(xyz), C.byref(xyz), C.byref(d1), C.byref(d1), C.byref(d1),
                                C.byref(i1), None)          # idx1 passed as fp32
     assert rc == 0 and b"idx1" in lib.genre_last_error()
+    # glue and renderer extensions
+    m, mm = desc((2, 1, 8, 6)), desc((2, 2))
+    lib.genre_abs_depth_forward.argtypes = lib.genre_abs_depth_backward.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    rc = lib.genre_abs_depth_forward(C.byref(m), C.byref(mm), C.byref(m), C.byref(m), 100.0, None)   # out not transposed
+    assert rc == 0 and b"transposed" in lib.genre_last_error()
+    rc = lib.genre_abs_depth_forward(C.byref(m), C.byref(desc((2, 3))), C.byref(m), C.byref(desc((2, 1, 6, 8))), 100.0, None)
+    assert rc == 0 and b"depth_minmax" in lib.genre_last_error()
+    rc = lib.genre_abs_depth_forward(C.byref(m), C.byref(mm), C.byref(m), C.byref(desc((2, 1, 6, 8))), 0.0, None)
+    assert rc == 0 and b"scale_25d" in lib.genre_last_error()
+    lib.genre_render_spherical_forward.argtypes = [C.c_void_p] * 8 + [C.c_float, C.c_void_p]
+    dirs, dw = desc((8, 8, 6)), desc((16,))
+    rc = lib.genre_render_spherical_forward(C.byref(vox), C.byref(dirs), C.byref(dw), C.byref(desc((1, 1, 11, 11))),
+                                            None, None, None, None, 0.0, None)          # odd padding
+    assert rc == 0 and b"R+2p" in lib.genre_last_error()
+    rc = lib.genre_render_spherical_forward(C.byref(vox), C.byref(dirs), C.byref(dw), C.byref(desc((1, 1, 12, 12))),
+                                            None, None, None, None, 0.0, None)          # padded map without the tables
+    assert rc == 0 and b"brick path" in lib.genre_last_error()
     # empty problems succeed without launching anything
     e = desc((0, 1, 8, 8))
     ev = desc((0, 1, 4, 4, 4))
