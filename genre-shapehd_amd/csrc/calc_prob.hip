@@ -25,6 +25,7 @@
 // prefix; any strides are accepted (a generic one-sample-per-lane kernel covers
 // layouts the float4 path cannot).
 #include "common.hpp"
+#include <cstdlib>
 #include "wave_scan.hpp"
 
 #pragma clang fp contract(off)
@@ -244,7 +245,10 @@ RayDims ray_dims(const genre_tensor *t)
 inline int grid_for_rays(int64_t rays)
 {
     int64_t b = (rays + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t cap = (int64_t)kCUs * 8 * 4;      // 8 resident blocks per CU x 4 rounds
+    // one ray per wave up to 2^20 workgroups: measured at batch 32 (524 288 rays) forward 199 / 181 / 172 / 165 us
+    // for 2 k / 8 k / 32 k / 131 k workgroups -- short-lived waves walking the tensor front to back beat long-lived
+    // grid-striding ones on this memory system (same finding as cam_bp's fill, tools/fill_bench.hip)
+    const int64_t cap = (int64_t)1 << 20;
     if (b > cap) b = cap;
     return (int)(b < 1 ? 1 : b);
 }
