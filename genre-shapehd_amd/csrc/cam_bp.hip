@@ -749,7 +749,7 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
         fill2_vec4_kernel<<<grid_for(total / 4, 1 << 20), kBlock, 0, st>>>((float4 *)a->data, va, (float4 *)b->data, vb,
                                                                   total / 4);
     } else {
-        fill2_strided_kernel<<<grid_for(total), kBlock, 0, st>>>(D, view5(a), va, view5(b), vb);
+        fill2_strided_kernel<<<grid_for(total, 1 << 20), kBlock, 0, st>>>(D, view5(a), va, view5(b), vb);
     }
     GENRE_LAUNCH_CHECK("fill");
     return 1;
@@ -956,7 +956,7 @@ extern "C" int genre_get_surface_mask(const genre_tensor *depth, const genre_ten
         return 0;
     const int64_t total = (int64_t)D.N * D.NC * D.X * D.Y * D.Z;
     if (total == 0) return 1;
-    surface_mask_kernel<<<grid_for(total), kBlock, 0, (hipStream_t)stream>>>(D, view4(depth), view2(camdist),
+    surface_mask_kernel<<<grid_for(total, 1 << 20), kBlock, 0, (hipStream_t)stream>>>(D, view4(depth), view2(camdist),
                                                                               view2(fl), view5(cnt), view5(mask));
     GENRE_LAUNCH_CHECK("surface mask");
     return 1;

@@ -959,7 +959,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
     GENRE_REQUIRE(is_contiguous(grad_vox) && aligned16(grad_vox->data) && nv % 4 == 0,
                   "%s: (atomic fallback) grad_vox must be contiguous, 16-byte aligned, numel %% 4 == 0", op);
     int64_t zb = (nv / 4 + kBlock - 1) / kBlock;
-    if (zb > kCUs * 8) zb = kCUs * 8;
+    if (zb > (1 << 20)) zb = 1 << 20;                    // one float4 per thread (see cam_bp's fill)
     zero_vec4_kernel<<<(int)zb, kBlock, 0, st>>>((float4 *)grad_vox->data, nv / 4);
     GENRE_LAUNCH_CHECK("render_spherical backward (zero)");
     if (rays == 0) return 1;
