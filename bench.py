@@ -65,10 +65,10 @@ def parse():
 class HotPath(torch.nn.Module):
     """configs[1] with the product ops (depth_pred_with_sph_inpaint.py:120-126)."""
 
-    def __init__(self, G, fused):
+    def __init__(self, G, fused, batch_minor=False):
         super().__init__()
         self.G = G
-        self.cam = G.Camera_back_projection_layer()
+        self.cam = G.Camera_back_projection_layer(batch_minor=batch_minor)
         self.render = G.render_spherical(fused=fused)
 
     def forward(self, depth):
@@ -115,7 +115,8 @@ def kernel_table(G, dev, B):
     t = event_time_us(lambda: calc_prob_lib.calc_prob_backward_fused(p, s, g, o), iters, 5)
     rows["calc_prob_bwd_fused"] = dict(us=t, bytes=B * BYTES_CP_BWD_FUSED, kernels="stop_bwd_vec4_kernel<fused>")
     from genre_shapehd_amd.toolbox import _fused_render
-    if _fused_render.available():
+    fused_ok = _fused_render.available()
+    if fused_ok:
         render_lib = _fused_render._loader().render_lib
         mod = G.render_spherical(fused=True).to(dev)
         vox = torch.clamp((1 - 128 * tdf) * 50, 1e-5, 1 - 1e-5)          # the volume the step really renders
@@ -138,6 +139,14 @@ def kernel_table(G, dev, B):
                                         kernels="render_scan_bwd_kernel+render_bwd_brick_kernel")
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3
+    # forward-only chain (inference) at this batch size, standard layout and batch-minor layout
+    if fused_ok:
+        with torch.no_grad():
+            for name, bm in (("chain_fwd", False), ("chain_fwd_batch_minor", True)):
+                net = HotPath(G, True, batch_minor=bm).to(dev)
+                t = event_time_us(lambda: net(d), iters, 3)
+                rows[name] = dict(us=t, bytes=B * (BYTES_CAM_FWD + BYTES_RENDER_FUSED), GBs=B * (BYTES_CAM_FWD + BYTES_RENDER_FUSED) / t / 1e3,
+                                  kernels="cam_bp forward (shifted) + fused render forward (+pad)")
     # Chamfer forward, both directions, B x 2048 x 2048 (configs[0]'s cloud size): fp32-VALU bound, 8 flops per
     # pair (3 sub, 3 mul, 2 add -- no fma: the distance must round like the reference's expression)
     from genre_shapehd_amd.toolbox.nndistance._ext import my_lib
@@ -362,7 +371,7 @@ def main():
     if rank == 0:
         rows = kernel_table(G, dev, B)
         # dominant hand-written kernel of the step = the one moving the most algorithmic bytes
-        in_step = [k for k in rows if not (fused and k.startswith("calc_prob")) and k != "nnd_fwd"]
+        in_step = [k for k in rows if not (fused and k.startswith("calc_prob")) and k != "nnd_fwd" and not k.startswith("chain_")]
         dom_name = max(in_step, key=lambda k: rows[k]["us"])
         dom = rows[dom_name]
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately and corrected as
@@ -396,6 +405,10 @@ def main():
                     "cfg0_us": rows["nnd_fwd"]["cfg0_us"],
                     "cfg0_note": "configs[0] cloud pair (1 x 2048 x 2048) on the GPU, HIP-graph replay; the reference's "
                                  "CPU path for the same pair is cpu_baseline.nnd_cfg0_ms"},
+            "forward_only": {"what": "configs[1] forward chain (no grad), batch %d, eager launches" % B,
+                             "standard_layout_us": rows.get("chain_fwd", {}).get("us"),
+                             "batch_minor_layout_us": rows.get("chain_fwd_batch_minor", {}).get("us"),
+                             "shapes_per_s": (B / rows["chain_fwd_batch_minor"]["us"] * 1e6) if "chain_fwd_batch_minor" in rows else None},
             "batch1": batch1_graph(G, dev),
         }
         if not args.no_cpu_baseline:

@@ -189,6 +189,14 @@ class _RenderLib:
                      dp_scratch, brick_table, chunk_list, v_scratch, kin, scalars=(C.c_float(pre_scale),))
 
 
+    @staticmethod
+    def render_spherical_backward_gather(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox, dp_scratch, csr_rows,
+                                         csr_entries, csr_shared, v_scratch, kin, pre_scale=0.0):
+        """backward for batch-minor volumes: reverse scan + per-voxel gather (tables: build_voxel_csr)"""
+        return _call("genre_render_spherical_backward_gather", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
+                     dp_scratch, csr_rows, csr_entries, csr_shared, v_scratch, kin, scalars=(C.c_float(pre_scale),))
+
+
 class _GlueLib:
     """GenRe caller glue folded into single passes (extension)"""
 

@@ -98,11 +98,13 @@ class RefinerInput(Function):
 
 
 class GenReGeometry(nn.Module):
-    def __init__(self, padding_margin=16, res=128):
+    def __init__(self, padding_margin=16, res=128, batch_minor=False):
+        """batch_minor: inference batches of >= 16 images keep the projected volume image-minor in memory, the
+        layout in which the fused renderer's forward is fastest (see Camera_back_projection_layer)"""
         super().__init__()
         self.margin = padding_margin
         self.res = res
-        self.proj_depth = Camera_back_projection_layer(res)
+        self.proj_depth = Camera_back_projection_layer(res, batch_minor=batch_minor)
         self.render_spherical = render_spherical()
         self.register_buffer('grid', gen_sph_grid(res))                  # genre_full_model.py:108
 

@@ -743,7 +743,7 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
 {
     const int64_t total = (int64_t)D.N * D.NC * D.X * D.Y * D.Z;
     if (total == 0) return 1;
-    if (is_contiguous(a) && is_contiguous(b) && (total % 4) == 0 && aligned16(a->data) && aligned16(b->data)) {
+    if (is_dense(a) && is_dense(b) && (total % 4) == 0 && aligned16(a->data) && aligned16(b->data)) {
         // one float4 pair per thread where possible: tools/fill_bench.hip measures 2 x 268 MB at 126 us with 2048
         // grid-striding workgroups, 94 us with 16 384 and 81 us (6.6 TB/s) with 65 536 and more
         fill2_vec4_kernel<<<grid_for(total / 4, 1 << 20), kBlock, 0, st>>>((float4 *)a->data, va, (float4 *)b->data, vb,

@@ -52,6 +52,24 @@ inline bool is_contiguous(const genre_tensor *t)
     }
     return true;
 }
+// dense: the elements occupy one gap-free block of memory in SOME dimension order (a permuted contiguous tensor,
+// e.g. the batch-minor volumes of toolbox/_fused_render.py: empty_batch_minor) -- fills may treat it as flat
+inline bool is_dense(const genre_tensor *t)
+{
+    int order[5], n = 0;
+    for (int i = 0; i < t->ndim; i++)
+        if (t->size[i] != 1) order[n++] = i;
+    for (int i = 1; i < n; i++)                                          // insertion sort by stride
+        for (int j = i; j > 0 && t->stride[order[j]] < t->stride[order[j - 1]]; j--) {
+            const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp;
+        }
+    int64_t expect = 1;
+    for (int i = 0; i < n; i++) {
+        if (t->stride[order[i]] != expect) return false;
+        expect *= t->size[order[i]];
+    }
+    return true;
+}
 inline bool same_shape(const genre_tensor *a, const genre_tensor *b)
 {
     if (a->ndim != b->ndim) return false;

@@ -622,6 +622,337 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
     publish_max(wmax, lane, dpmax_bits);
 }
 
+// ==== batch-minor path =================================================================================
+// When the volume is laid out with the IMAGE index fastest in memory (stride[0] == 1: element (n,x,y,z) at
+// ((x*Y + y)*Z + z)*N + n -- any [N,1,X,Y,Z] tensor with such strides, e.g. what Camera_back_projection_layer
+// allocates with batch_minor=True), the 32 lanes of a half-wave can be 32 IMAGES of one sample:
+//   * a trilinear corner is one 128-byte line for all 32 images -- no LDS tiles, no staging, full-line v stores;
+//   * the geometry of a sample is computed once per 32 images (by one lane, handed over through LDS);
+//   * the per-ray scans need no cross-lane operation at all: a lane walks ITS ray's 256 samples serially
+//     (~10 instructions per sample per 64 image-rays instead of ~110 per ray for the DPP tree scans);
+//   * the backward becomes a deterministic gather: every voxel sums its (sample, weight) list in a fixed order
+//     (tables by toolbox/_fused_render.py: build_voxel_csr), each dL/dp line read serves 32 images.
+// Scratch layouts here: v[(q*ZR + k)*N + n], dL/dp likewise.
+constexpr int kBmLanes = 32;                        // images per half-wave
+constexpr int kBmRec = 12;                          // LDS record per sample: offset, mask, entry, pad, 8 weights (3 x b128)
+
+template <bool PS>
+__global__ __launch_bounds__(kBlock) void render_sample_bm_kernel(RenderDims D, View5 vox,
+                                                                   const double *__restrict__ dirs,
+                                                                   const int *__restrict__ fwd_list, int n_entries,
+                                                                   float *__restrict__ vbm)
+{
+    __shared__ __attribute__((aligned(16))) int rec[kWavesPerBlock][64 * kBmRec];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin, and the list is sorted by brick, so XCD x
+    // takes the x-th CONTIGUOUS eighth of the list -- the voxel lines its waves share then meet in ITS L2
+    // (with the plain order every XCD streamed the whole volume through its own L2: 50 % L2 misses)
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int chunk = blk * kWavesPerBlock + wv;
+    const int e0 = chunk * 64;
+    if (e0 >= n_entries) return;
+    int *my = rec[wv];
+    bool chunk_fast;
+    {   // phase A: lane l works out the geometry of entry e0 + l
+        const int e = e0 + lane;
+        unsigned ent = 0xffffffffu;
+        int off = 0, mask = 0;
+        float w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (e < n_entries) {
+            ent = (unsigned)fwd_list[e];
+            const int q = (int)(ent >> 8), k = (int)(ent & 255u);
+            float gx, gy, gz;
+            sample_pos(D, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, k, gx, gy, gz);
+            Cell c;
+            locate(D, gx, gy, gz, c);
+            off = c.x0 * D.sx + c.y0 * D.sy + c.z0 * D.sz;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int x = c.x0 + (i & 1), y = c.y0 + ((i >> 1) & 1), z = c.z0 + ((i >> 2) & 1);
+                if (x >= 0 && x < D.X && y >= 0 && y < D.Y && z >= 0 && z < D.Z) mask |= 1 << i;
+                w[i] = corner_w(c, i);
+            }
+        }
+        chunk_fast = __builtin_amdgcn_ballot_w64(mask == 0xff) == ~0ull;   // 64 interior samples: the pipelined loop
+        int4 *dst = reinterpret_cast<int4 *>(my + lane * kBmRec);
+        dst[0] = make_int4(off, mask, (int)ent, 0);
+        dst[1] = make_int4(__float_as_int(w[0]), __float_as_int(w[1]), __float_as_int(w[2]), __float_as_int(w[3]));
+        dst[2] = make_int4(__float_as_int(w[4]), __float_as_int(w[5]), __float_as_int(w[6]), __float_as_int(w[7]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // LDS of one wave is processed in issue order
+    // phase B: half-wave h evaluates entry s + h for 32 images at a time.  Interior samples (all eight corners
+    // inside the volume -- nearly all of them) take a branch-free path chosen per wave: 32-bit offsets from the
+    // uniform base pointer, clamp as multiply + median, one fma per corner (the reference's CUDA build contracts
+    // `out += val * weight` too).
+    const int half = lane >> 5, li = lane & 31;
+    const int imgs = D.N * D.NC;
+    const int coff[8] = {0, D.sx, D.sy, D.sx + D.sy, D.sz, D.sx + D.sz, D.sy + D.sz, D.sx + D.sy + D.sz};
+    // byte offsets from the uniform base as 32-bit unsigned values (the host checks the volume spans < 4 GiB): the
+    // loads then take the SGPR-base + VGPR-offset form, one v_add_u32 per corner instead of a 64-bit address
+    const char *__restrict__ vbytes = reinterpret_cast<const char *>(vox.p);
+    for (int g0 = 0; g0 < imgs; g0 += kBmLanes) {
+        const int img = g0 + li;
+        const bool img_on = img < imgs;
+        const int ioff = img_on ? (img / D.NC) * (int)vox.s0 + (img % D.NC) * (int)vox.s1 : 0;     // once per 32 entries
+        if (chunk_fast) {
+            // all 64 samples interior: software-pipelined -- the eight lines of the NEXT sample are requested before
+            // the current one is evaluated (a wave is otherwise one exposed L2 round trip per sample: the kernel
+            // ran at 56 % VALU, latency-bound at full occupancy)
+            int4 h0 = reinterpret_cast<const int4 *>(my + half * kBmRec)[0];
+            float tv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                tv[i] = *reinterpret_cast<const float *>(vbytes + (((unsigned)(ioff + h0.x) + (unsigned)coff[i]) << 2));
+            for (int s0 = 0; s0 < 64; s0 += 2) {
+                const int4 *r = reinterpret_cast<const int4 *>(my + (s0 + half) * kBmRec);
+                const int4 w03 = r[1], w47 = r[2];
+                const unsigned ent = (unsigned)h0.z;
+                float cur[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) cur[i] = tv[i];
+                if (s0 + 2 < 64) {
+                    h0 = reinterpret_cast<const int4 *>(my + (s0 + 2 + half) * kBmRec)[0];
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        tv[i] = *reinterpret_cast<const float *>(vbytes + (((unsigned)(ioff + h0.x) + (unsigned)coff[i]) << 2));
+                }
+                const float w[8] = {__int_as_float(w03.x), __int_as_float(w03.y), __int_as_float(w03.z), __int_as_float(w03.w),
+                                    __int_as_float(w47.x), __int_as_float(w47.y), __int_as_float(w47.z), __int_as_float(w47.w)};
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float t = PS ? __builtin_amdgcn_fmed3f(cur[i] * D.pre_scale, D.lo, D.hi) : cur[i];
+                    acc = __builtin_fmaf(t, w[i], acc);
+                }
+                if (img_on) vbm[(unsigned)(((ent >> 8) * (unsigned)D.ZR + (ent & 255u)) * (unsigned)imgs + (unsigned)img)] = acc;
+            }
+            continue;
+        }
+        for (int s0 = 0; s0 < 64; s0 += 2) {
+            const int4 *r = reinterpret_cast<const int4 *>(my + (s0 + half) * kBmRec);
+            const int4 h0 = r[0], w03 = r[1], w47 = r[2];
+            const unsigned ent = (unsigned)h0.z;
+            const int off = h0.x, mask = h0.y;
+            const float w[8] = {__int_as_float(w03.x), __int_as_float(w03.y), __int_as_float(w03.z), __int_as_float(w03.w),
+                                __int_as_float(w47.x), __int_as_float(w47.y), __int_as_float(w47.z), __int_as_float(w47.w)};
+            const bool valid = ent != 0xffffffffu;
+            const bool fast = __builtin_amdgcn_ballot_w64(!valid || mask != 0xff) == 0ull;      // wave-uniform
+            const bool on = valid && img_on;
+            const int idx = on ? ioff + off : 0;
+            float acc = 0.f;                                          // ATen corner order
+            if (fast) {
+                float tv[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++)                           // eight lines requested together
+                    tv[i] = *reinterpret_cast<const float *>(vbytes + (((unsigned)idx + (on ? (unsigned)coff[i] : 0u)) << 2));
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float t = PS ? __builtin_amdgcn_fmed3f(tv[i] * D.pre_scale, D.lo, D.hi) : tv[i];
+                    acc = __builtin_fmaf(t, w[i], acc);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (on && (mask & (1 << i))) {                    // zeros outside the volume stay zeros
+                        float t = vox.p[idx + coff[i]];
+                        if (PS) t = __builtin_amdgcn_fmed3f(t * D.pre_scale, D.lo, D.hi);
+                        acc = __builtin_fmaf(t, w[i], acc);
+                    }
+                }
+            }
+            // v index fits 32 bits (host-checked): (ray * ZR + k) * images + image
+            if (on) vbm[(unsigned)(((ent >> 8) * (unsigned)D.ZR + (ent & 255u)) * (unsigned)imgs + (unsigned)img)] = acc;
+        }
+    }
+}
+
+// forward scan, batch-minor: one lane = one (ray, image); serial over the samples in fp64
+// Anchor of the backward scan, 16 bytes per (ray, image): the transmittance T (double) before sample k_f (int), where
+// k_f = ZR when the product never dropped below 1e-290 (then T = prod(1-p)), else the first sample before which it did:
+// behind k_f every dL/dp term is below fp32 resolution, in front of it T_k is recovered by dividing back from the anchor.
+struct BmAnchor { double T; int kf; int pad; };
+
+__global__ __launch_bounds__(kBlock) void render_scan_fwd_bm_kernel(RenderDims D, const float *__restrict__ vbm,
+                                                                     const int *__restrict__ kin,
+                                                                     const float *__restrict__ dw, View4 out,
+                                                                     BmAnchor *__restrict__ anchor)
+{
+    const int imgs = D.N * D.NC, rr = D.R * D.R;
+    const int ipad = (imgs + kBmLanes - 1) / kBmLanes * kBmLanes;      // lanes per ray, multiple of 32
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int q = (int)(t / ipad), img = (int)(t % ipad);
+    if (q >= rr || img >= imgs) return;
+    const int k_in = kin[q];
+    const double lo = (double)D.lo;
+    double T = 1.0, acc = 0.0, Tf = 0.0;
+    int kf = D.ZR;
+    for (int k = 0; k < k_in && k < D.ZR; k++) {                       // outside the volume: v = 0 -> p = lo
+        acc += (lo * T) * (double)dw[k];
+        T *= 1.0 - lo;
+    }
+    const float *__restrict__ vr = vbm + ((int64_t)q * D.ZR) * imgs + img;
+    int k = k_in;
+    for (; k + 8 <= D.ZR; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = vr[(int64_t)(k + u) * imgs];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (T < 1e-290 && kf == D.ZR) { kf = k + u; Tf = T; }
+            const double p = (double)fminf(fmaxf(v[u], D.lo), D.hi);  // :66
+            acc += (p * T) * (double)dw[k + u];                       // stop probability x depth weight  (:67-68)
+            T *= 1.0 - p;
+        }
+    }
+    for (; k < D.ZR; k++) {
+        if (T < 1e-290 && kf == D.ZR) { kf = k; Tf = T; }
+        const double p = (double)fminf(fmaxf(vr[(int64_t)k * imgs], D.lo), D.hi);
+        acc += (p * T) * (double)dw[k];
+        T *= 1.0 - p;
+    }
+    if (anchor) {
+        BmAnchor a;
+        a.T = kf == D.ZR ? T : Tf; a.kf = kf; a.pad = 0;
+        anchor[(int64_t)q * imgs + img] = a;
+    }
+    const float total = (float)acc + (float)T;                          // + prod(1-p)  (:69-71), rounded as the tree scan
+    float *oimg = out.p + (img / D.NC) * out.s0 + (img % D.NC) * out.s1;
+    const int i = q / D.R, j = q % D.R;
+    if (D.pad == 0) {
+        oimg[i * out.s2 + j * out.s3] = total;
+    } else {
+        int r_lo, r_n, c0, c1;
+        pad_span(D.R, D.pad, i, j, r_lo, r_n, c0, c1);
+        for (int r = 0; r < r_n; r++) {
+            oimg[(r_lo + r) * out.s2 + c0 * out.s3] = total;
+            if (c1 >= 0) oimg[(r_lo + r) * out.s2 + c1 * out.s3] = total;
+        }
+    }
+}
+
+// backward scan, batch-minor: one lane = one (ray, image), ONE reverse pass over the samples.  T_k (transmittance
+// before sample k) is divided back from the anchor the forward scan left, A_k (the suffix sum of stop probability x
+// depth weight, plus prod(1-p)) is accumulated tail-first; both in fp64.  dL/dp is written for the in-volume samples
+// k_in .. ZR-1, the only ones the gather reads.
+__global__ __launch_bounds__(kBlock) void render_scan_bwd_bm_kernel(RenderDims D, const float *__restrict__ vbm,
+                                                                     const int *__restrict__ kin,
+                                                                     const float *__restrict__ dw, View4 gout,
+                                                                     const BmAnchor *__restrict__ anchor,
+                                                                     float *__restrict__ dpbm)
+{
+    const int imgs = D.N * D.NC, rr = D.R * D.R;
+    const int ipad = (imgs + kBmLanes - 1) / kBmLanes * kBmLanes;
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int q = (int)(t / ipad), img = (int)(t % ipad);
+    if (q >= rr || img >= imgs) return;
+    const int k_in = kin[q];
+    const float g = load_map_grad(D, gout.p + (img / D.NC) * gout.s0 + (img % D.NC) * gout.s1, gout, q);
+    const BmAnchor a = anchor[(int64_t)q * imgs + img];
+    const double gd = (double)g;
+    const int64_t row0 = ((int64_t)q * D.ZR) * imgs + img;
+    const float *__restrict__ vr = vbm + row0;
+    float *__restrict__ dr = dpbm + row0;
+    // behind the anchor (k >= kf) T_k < 1e-290 and so is A_k: dL/dp underflows fp32
+    for (int k = D.ZR - 1; k >= a.kf && k >= k_in; k--) dr[(int64_t)k * imgs] = 0.f;
+    double T = a.T;                                                      // T_{kf}
+    double A = a.kf == D.ZR ? a.T : 0.0;                                 // A_{kf-1}: prod(1-p) if nothing underflowed
+    int k = (a.kf < D.ZR ? a.kf : D.ZR) - 1;
+    for (; k - 3 >= k_in; k -= 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = vr[(int64_t)(k - u) * imgs];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool pass = v[u] >= D.lo && v[u] <= D.hi;             // torch.clamp backward mask
+            const double p = (double)fminf(fmaxf(v[u], D.lo), D.hi);
+            const double qk = 1.0 - p;
+            double r = __builtin_amdgcn_rcp(qk);                         // v_rcp_f64 + one Newton step
+            r = r * (2.0 - qk * r);
+            T *= r;                                                      // T_k = T_{k+1} / (1 - p_k)
+            const double tw = T * (double)dw[k - u];
+            dr[(int64_t)(k - u) * imgs] = pass ? (float)(gd * (tw - A * r)) : 0.f;
+            A += p * tw;                                                 // A_{k-1} = A_k + s_k w_k
+        }
+    }
+    for (; k >= k_in; k--) {
+        const float v = vr[(int64_t)k * imgs];
+        const bool pass = v >= D.lo && v <= D.hi;
+        const double p = (double)fminf(fmaxf(v, D.lo), D.hi);
+        const double qk = 1.0 - p;
+        double r = __builtin_amdgcn_rcp(qk);
+        r = r * (2.0 - qk * r);
+        T *= r;
+        const double tw = T * (double)dw[k];
+        dr[(int64_t)k * imgs] = pass ? (float)(gd * (tw - A * r)) : 0.f;
+        A += p * tw;
+    }
+}
+
+// backward gather, batch-minor: a half-wave owns a voxel row (csr_rows) and 32 images; it walks the row's
+// (sample, weight) pairs in table order -- a fixed summation order -- reading one 128-byte dL/dp line per pair.
+// Measured at batch 32: 1.0-1.2 ms, against 0.76 ms for the brick-owned LDS accumulation of the standard layout:
+// the dL/dp lines of a voxel's pairs have little cache locality (63 % L2 misses, ~1.8 GB from HBM), whatever the
+// row order (raster, 4x4x8 ... 16^3 blocks) and with four rows per half-wave in lock step (slower still).  It is
+// what makes the batch-minor path differentiable, not a reason to train in that layout.
+constexpr int kRowsPerHalf = 1;
+
+__global__ __launch_bounds__(kBlock) void render_bwd_gather_bm_kernel(RenderDims D, const float *__restrict__ dpbm,
+                                                                       const int4 *__restrict__ rows, int n_rows,
+                                                                       const int2 *__restrict__ entries, View5 vox,
+                                                                       View5 gvox)
+{
+    const int imgs = D.N * D.NC;
+    // XCD-aware order (see render_sample_bm_kernel): each XCD takes a contiguous eighth of the rows
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int row = blk * (kBlock / kBmLanes) + (threadIdx.x >> 5);
+    if (row >= n_rows) return;
+    const int li = threadIdx.x & 31;
+    const int4 rw = rows[row];
+    const int voxel = rw.x, begin = rw.y, end = rw.z, shared = rw.w;
+    const int z = voxel % D.Z, y = (voxel / D.Z) % D.Y, x = voxel / (D.Z * D.Y);
+    for (int g0 = 0; g0 < imgs; g0 += kBmLanes) {
+        const int img = g0 + li;
+        if (img >= imgs) break;
+        float acc = 0.f;
+        int e = begin;
+        for (; e + 4 <= end; e += 4) {
+            int2 en[4];
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) en[u] = entries[e + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) d[u] = dpbm[(unsigned)en[u].x * (unsigned)imgs + (unsigned)img];
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc = __builtin_fmaf(__int_as_float(en[u].y), d[u], acc);
+        }
+        for (; e < end; e++) {
+            const int2 en = entries[e];
+            acc = __builtin_fmaf(__int_as_float(en.y), dpbm[(unsigned)en.x * (unsigned)imgs + (unsigned)img], acc);
+        }
+        const int n = img / D.NC, c = img % D.NC;
+        if (D.pre_scale != 0.0f) {                           // adjoint of clamp(x * pre_scale, lo, hi)
+            const float tv = vox.p[n * vox.s0 + c * vox.s1 + x * D.sx + y * D.sy + z * D.sz] * D.pre_scale;
+            acc = (tv >= D.lo && tv <= D.hi) ? acc * D.pre_scale : 0.0f;
+        }
+        float *dst = gvox.p + n * gvox.s0 + c * gvox.s1 + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
+        if (!shared) *dst = acc;
+        else if (acc != 0.0f) unsafeAtomicAdd(dst, acc);
+    }
+}
+
+__global__ void zero_voxels_bm_kernel(RenderDims D, const int *__restrict__ voxels, int n, View5 gvox)
+{
+    const int imgs = D.N * D.NC;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = (int)(t / imgs), img = (int)(t % imgs);
+    if (v >= n) return;
+    const int voxel = voxels[v];
+    const int z = voxel % D.Z, y = (voxel / D.Z) % D.Y, x = voxel / (D.Z * D.Y);
+    gvox.p[(img / D.NC) * gvox.s0 + (img % D.NC) * gvox.s1 + x * gvox.s2 + y * gvox.s3 + z * gvox.s4] = 0.f;
+}
+
 // ---- backward pass B: brick-owned accumulation ----------------------------------------------------
 // brick_table [rows,4] = (brick id, begin, end, mode) into chunk_list, heaviest first; mode 0: the
 // row covers the whole brick (plain stores); mode 1: the brick's list is split over several rows
@@ -877,6 +1208,36 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
         GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R,
                       "%s: kin must be int32 [R*R]", op);
         const int imgs = D.N * D.NC;
+        // batch-minor volume (image index fastest in memory) with enough images to fill half-waves
+        int64_t vspan = 1;
+        for (int i = 0; i < 5; i++) vspan += (vox->size[i] - 1) * vox->stride[i];
+        // (the caller must apply the same test to know the layout of v_scratch: toolbox/_fused_render.py: is_batch_minor)
+        if (imgs >= 16 && D.NC == 1 && vox->stride[0] == 1 && vspan < ((int64_t)1 << 30) &&
+            rays * D.ZR < ((int64_t)1 << 31)) {
+            const int n_entries = (int)fwd_chunks->size[0];
+            if (n_entries > 0) {
+                const int gb = ((n_entries + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock) + 7) / 8 * 8;   // multiple of 8 XCDs
+                if (pre_scale != 0.0f)
+                    render_sample_bm_kernel<true><<<gb, kBlock, 0, st>>>(D, view5(vox), (const double *)dirs->data,
+                                                                       (const int *)fwd_chunks->data, n_entries,
+                                                                       (float *)v_scratch->data);
+                else
+                    render_sample_bm_kernel<false><<<gb, kBlock, 0, st>>>(D, view5(vox), (const double *)dirs->data,
+                                                                        (const int *)fwd_chunks->data, n_entries,
+                                                                        (float *)v_scratch->data);
+                GENRE_LAUNCH_CHECK("render_spherical forward (batch-minor sampler)");
+            }
+            const int64_t lanes = (int64_t)D.R * D.R * ((imgs + kBmLanes - 1) / kBmLanes * kBmLanes);
+            // the backward scan's anchors live behind the samples when the caller made room for them
+            // (4 more floats per ray and image; 16-byte aligned because rays*ZR is a multiple of 4)
+            BmAnchor *anchor = v_scratch->size[0] >= rays * (D.ZR + 4)
+                                   ? reinterpret_cast<BmAnchor *>((float *)v_scratch->data + rays * D.ZR) : nullptr;
+            render_scan_fwd_bm_kernel<<<(int)((lanes + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+                D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data, view4(out),
+                anchor);
+            GENRE_LAUNCH_CHECK("render_spherical forward (batch-minor scan)");
+            return 1;
+        }
         // batches: kGroup images share one walk over the sample list; a lone image gets the same kernel with G = 1
         // (512 threads per workgroup: 38.9 us for the batch-1 forward chain against 42.1 with 256, 42.2 with 1024)
         const int ok = imgs >= 2
@@ -968,5 +1329,66 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                                                                     (const float *)depth_weight->data,
                                                                     view4(grad_out), view5(grad_vox));
     GENRE_LAUNCH_CHECK("render_spherical backward");
+    return 1;
+}
+
+extern "C" int genre_render_spherical_backward_gather(const genre_tensor *vox, const genre_tensor *dirs,
+                                                      const genre_tensor *depth_weight, const genre_tensor *grad_out,
+                                                      const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
+                                                      const genre_tensor *csr_rows, const genre_tensor *csr_entries,
+                                                      const genre_tensor *csr_shared, const genre_tensor *v_scratch,
+                                                      const genre_tensor *kin, float pre_scale, void *stream)
+{
+    const char *op = "render_spherical_backward_gather";
+    RenderDims D{};
+    if (!check_render(op, vox, dirs, depth_weight, grad_out, D)) return 0;
+    D.pre_scale = pre_scale;
+    GENRE_REQUIRE(is_f32(grad_vox, 5) && same_shape(grad_vox, vox), "%s: grad_vox must have the shape of vox", op);
+    GENRE_REQUIRE(D.ZR <= 256 && (D.ZR & 3) == 0, "%s: needs z_res <= 256 and z_res %% 4 == 0", op);
+    const int imgs = D.N * D.NC;
+    const int64_t rays = (int64_t)imgs * D.R * D.R;
+    const int64_t nvox = (int64_t)D.X * D.Y * D.Z;
+    if (numel(grad_vox) == 0) return 1;
+    GENRE_REQUIRE(rays * D.ZR < ((int64_t)1 << 31), "%s: rays * z_res must be < 2^31", op);
+    GENRE_REQUIRE(is_i32(csr_rows, 2) && csr_rows->size[1] == 4 && is_contiguous(csr_rows) && csr_rows->size[0] >= nvox &&
+                      csr_rows->size[0] < ((int64_t)1 << 30),
+                  "%s: csr_rows must be a contiguous int32 [rows >= X*Y*Z, 4] tensor", op);
+    GENRE_REQUIRE(is_i32(csr_entries, 2) && csr_entries->size[1] == 2 && is_contiguous(csr_entries) &&
+                      aligned16(csr_entries->data),
+                  "%s: csr_entries must be a contiguous, 16-byte aligned int32 [E, 2] tensor", op);
+    GENRE_REQUIRE(!csr_shared || (is_i32(csr_shared, 1) && is_contiguous(csr_shared)), "%s: csr_shared must be int32 [n]", op);
+    GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && v_scratch->size[0] >= rays * (D.ZR + 4) &&
+                      aligned16(v_scratch->data),
+                  "%s: v_scratch must be the forward's buffer of >= rays*(ZR+4) floats (samples + anchors)", op);
+    GENRE_REQUIRE(is_f32(dp_scratch, 1) && is_contiguous(dp_scratch) && dp_scratch->size[0] >= rays * D.ZR,
+                  "%s: dp_scratch must be a contiguous fp32 buffer of >= rays*ZR elements", op);
+    GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R, "%s: kin must be int32 [R*R]", op);
+    int64_t gspan = 1, vspan = 1;
+    for (int i = 0; i < 5; i++) {
+        GENRE_REQUIRE(grad_vox->stride[i] >= 0, "%s: negative grad_vox strides are not supported", op);
+        gspan += (grad_vox->size[i] - 1) * grad_vox->stride[i];
+        vspan += (vox->size[i] - 1) * vox->stride[i];
+    }
+    GENRE_REQUIRE(gspan < ((int64_t)1 << 31) && vspan < ((int64_t)1 << 31), "%s: volumes must span < 2^31 elements", op);
+    hipStream_t st = (hipStream_t)stream;
+    if (rays > 0) {
+        const int64_t lanes = (int64_t)D.R * D.R * ((imgs + kBmLanes - 1) / kBmLanes * kBmLanes);
+        render_scan_bwd_bm_kernel<<<(int)((lanes + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+            D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data, view4(grad_out),
+            reinterpret_cast<const BmAnchor *>((const float *)v_scratch->data + rays * D.ZR), (float *)dp_scratch->data);
+        GENRE_LAUNCH_CHECK("render_spherical backward (batch-minor scan)");
+    }
+    const int n_shared = csr_shared ? (int)csr_shared->size[0] : 0;
+    if (n_shared > 0) {
+        const int64_t t = (int64_t)n_shared * imgs;
+        zero_voxels_bm_kernel<<<(int)((t + 255) / 256), 256, 0, st>>>(D, (const int *)csr_shared->data, n_shared, view5(grad_vox));
+        GENRE_LAUNCH_CHECK("render_spherical backward (zero shared voxels)");
+    }
+    const int n_rows = (int)csr_rows->size[0];
+    const int per_block = kBlock / kBmLanes * kRowsPerHalf;
+    const int gb = ((n_rows + per_block - 1) / per_block + 7) / 8 * 8;
+    render_bwd_gather_bm_kernel<<<gb, kBlock, 0, st>>>(D, (const float *)dp_scratch->data, (const int4 *)csr_rows->data, n_rows,
+                                                      (const int2 *)csr_entries->data, view5(vox), view5(grad_vox));
+    GENRE_LAUNCH_CHECK("render_spherical backward (gather)");
     return 1;
 }

@@ -107,6 +107,79 @@ def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT_BWD, split_fwd=SPLIT_
     return dict(bwd_table=bwd_table, bwd_chunks=bwd_chunks, fwd_table=fwd_table, fwd_chunks=fwd_chunks, kin=kin)
 
 
+CSR_SPLIT = 512         # voxel rows of the gather backward above this many (sample, weight) pairs are split
+
+
+def build_voxel_csr(X, Y, Z, dirs64, z_res, split=CSR_SPLIT):
+    """Geometry-only tables of the batch-minor gather backward (csrc/sph_render.hip: render_bwd_gather_bm_kernel):
+    for every voxel the list of samples whose trilinear cell touches it, with the weight of that corner.
+
+      rows    int32 [n_rows,4] = (voxel = (x*Y + y)*Z + z, begin, end, shared); one row per voxel, in voxel order;
+              voxels with more than `split` pairs get several rows (shared = 1: accumulated with atomics onto a
+              pre-zeroed voxel)
+      entries int32 [E,2]      = (sample row q*z_res + k, weight as fp32 bits), per voxel sorted by sample
+      shared  int32 [n]        = the voxels that have split rows
+
+    Positions, cells and weights follow the kernels' fp64/fp32 sequence (sample_pos, locate, corner_w:
+    ATen's (wx*wy)*wz), so every weight is bit-identical to what the forward sampler multiplies with."""
+    R = dirs64.shape[0]
+    d2 = dirs64.reshape(-1, 3).astype(np.float64) * 2.0
+    step = 1.0 / (z_res - 1) if z_res > 1 else 0.0
+    alpha = np.arange(z_res, dtype=np.float64) * step
+    alpha[-1] = 1.0
+    a = 1.0 - alpha
+    one, two = np.float32(1), np.float32(2)
+    i0s, w0s, w1s = [], [], []
+    anyin = None
+    for ax, size in enumerate((X, Y, Z)):
+        g = (d2[:, None, ax] * a[None, :]).astype(np.float32)                # [R*R, ZR]
+        ix = ((g + one) / two) * np.float32(size - 1)
+        fx = np.floor(ix)
+        i0 = fx.astype(np.int32)
+        inside = (i0 >= -1) & (i0 < size)
+        anyin = inside if anyin is None else (anyin & inside)
+        i0s.append(i0); w1s.append(ix - fx); w0s.append((fx + one) - ix)
+    sid = np.arange(R * R * z_res, dtype=np.int64).reshape(R * R, z_res)
+    keys, wts = [], []
+    for c in range(8):
+        bx, by, bz = c & 1, (c >> 1) & 1, (c >> 2) & 1
+        x, y, z = i0s[0] + bx, i0s[1] + by, i0s[2] + bz
+        m = anyin & (x >= 0) & (x < X) & (y >= 0) & (y < Y) & (z >= 0) & (z < Z)
+        wx = (w1s[0] if bx else w0s[0])[m]
+        wy = (w1s[1] if by else w0s[1])[m]
+        wz = (w1s[2] if bz else w0s[2])[m]
+        w = (wx * wy) * wz                                                   # fp32, ATen order
+        vox = (x[m].astype(np.int64) * Y + y[m]) * Z + z[m]
+        keys.append((vox << 32) | sid[m])
+        wts.append(w.astype(np.float32))
+    keys = np.concatenate(keys)
+    wts = np.concatenate(wts)
+    order = np.argsort(keys, kind="stable")
+    keys, wts = keys[order], wts[order]
+    vox = (keys >> 32).astype(np.int64)
+    entries = np.empty((keys.shape[0], 2), np.int32)
+    entries[:, 0] = (keys & 0xFFFFFFFF).astype(np.int32)
+    entries[:, 1] = wts.view(np.int32)
+    nvox = X * Y * Z
+    begin = np.searchsorted(vox, np.arange(nvox), side="left").astype(np.int64)
+    end = np.searchsorted(vox, np.arange(nvox), side="right").astype(np.int64)
+    cnt = end - begin
+    big = np.nonzero(cnt > split)[0]
+    rows = np.stack([np.arange(nvox, dtype=np.int64), begin, end, np.zeros(nvox, np.int64)], 1)
+    if big.size:
+        keep = np.ones(nvox, bool)
+        keep[big] = False
+        extra = []
+        for v in big:
+            parts = -(-int(cnt[v]) // split)
+            size = -(-int(cnt[v]) // parts)
+            for s0 in range(int(begin[v]), int(end[v]), size):
+                extra.append((int(v), s0, min(s0 + size, int(end[v])), 1))
+        rows = np.concatenate([rows[keep], np.asarray(extra, np.int64).reshape(-1, 4)], 0)
+        rows = rows[np.argsort(rows[:, 0], kind="stable")]
+    return dict(csr_rows=rows.astype(np.int32), csr_entries=entries, csr_shared=big.astype(np.int32))
+
+
 def tables_for(vox_shape, device, dirs64, z_res):
     small = vox_shape[0] * vox_shape[1] < SMALL_BATCH
     key = (tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device), small)
@@ -117,6 +190,30 @@ def tables_for(vox_shape, device, dirs64, z_res):
         t = {k: torch.from_numpy(v).to(device) for k, v in np_t.items()}
         _TABLES[key] = t
     return t
+
+
+def csr_for(vox_shape, device, dirs64, z_res):
+    """per-voxel (sample, weight) tables of the batch-minor backward, built on first use and cached"""
+    key = ("csr", tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device))
+    t = _TABLES.get(key)
+    if t is None:
+        np_t = build_voxel_csr(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), z_res)
+        t = {k: torch.from_numpy(v).to(device) for k, v in np_t.items()}
+        _TABLES[key] = t
+    return t
+
+
+def is_batch_minor(vox):
+    """image index fastest in memory (the layout the batch-minor kernels of csrc/sph_render.hip want)"""
+    return (vox.dim() == 5 and vox.shape[1] == 1 and vox.shape[0] >= 16 and vox.stride(0) == 1
+            and vox.numel() < (1 << 30))
+
+
+def empty_batch_minor(shape, dtype, device):
+    """uninitialised [N,1,X,Y,Z] tensor whose memory order is (X, Y, Z, N)"""
+    n, c, x, y, z = shape
+    assert c == 1
+    return torch.empty_strided((n, c, x, y, z), (1, n * x * y * z, y * z * n, z * n, n), dtype=dtype, device=device)
 
 
 class RenderSphericalFused(Function):
@@ -135,7 +232,9 @@ class RenderSphericalFused(Function):
         out = torch.empty((vox.shape[0], vox.shape[1], res + 2 * pad, res + 2 * pad), dtype=vox.dtype, device=vox.device)
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
         rays = vox.shape[0] * vox.shape[1] * res * res
-        v = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
+        ctx.batch_minor = is_batch_minor(vox) and rays * z_res < (1 << 31)
+        # batch-minor volumes: room for the backward scan's anchors behind the samples (4 floats per ray and image)
+        v = torch.empty((rays * (z_res + 4) if ctx.batch_minor else rays * z_res,), dtype=torch.float32, device=vox.device)
         lib.render_spherical_forward(vox, dirs64.view(torch.float32), depth_weight, out,
                                      v, t["fwd_table"], t["fwd_chunks"], t["kin"], float(pre_scale))
         ctx.save_for_backward(vox, dirs64, depth_weight, v)
@@ -149,6 +248,16 @@ class RenderSphericalFused(Function):
         lib = _loader().render_lib
         z_res = depth_weight.shape[0]
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
+        if ctx.batch_minor:
+            c = csr_for(vox.shape, vox.device, dirs64, z_res)
+            grad_vox = empty_batch_minor(vox.shape, vox.dtype, vox.device)
+            rays = vox.shape[0] * vox.shape[1] * dirs64.shape[0] * dirs64.shape[0]
+            scratch = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
+            lib.render_spherical_backward_gather(vox, dirs64.view(torch.float32), depth_weight, grad_out.contiguous(),
+                                                 grad_vox, scratch, c["csr_rows"], c["csr_entries"],
+                                                 c["csr_shared"] if c["csr_shared"].numel() else None, v, t["kin"],
+                                                 ctx.pre_scale)
+            return grad_vox, None, None, None, None
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
         scratch = torch.empty((v.numel() + 4,), dtype=torch.float32, device=vox.device)
         lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,

@@ -52,14 +52,21 @@ class ShiftedCameraBackProjection(Function):
     values, one full-volume elementwise pass less in each direction.  Used by the layer."""
 
     @staticmethod
-    def forward(ctx, depth_t, fl, cam_dist, res=128):
+    def forward(ctx, depth_t, fl, cam_dist, res=128, batch_minor=False):
         assert depth_t.dim() == 4
         n, nc = depth_t.shape[0], depth_t.shape[1]
         assert fl.dim() == 2 and tuple(fl.shape) == (n, nc)
         assert cam_dist.dim() == 2 and tuple(cam_dist.shape) == (n, nc)
         assert depth_t.is_cuda and fl.is_cuda and cam_dist.is_cuda
-        out = torch.empty((n, nc, res, res, res), dtype=depth_t.dtype, device=depth_t.device)
-        cnt = torch.empty_like(out)
+        if batch_minor and nc == 1:
+            # same logical [n,1,res,res,res] tensors, image index fastest in memory: the layout the fused renderer's
+            # batch-minor kernels want (the native op is stride-generic, its fill treats any dense tensor as flat)
+            strides = (1, n * res ** 3, res * res * n, res * n, n)
+            out = torch.empty_strided((n, nc, res, res, res), strides, dtype=depth_t.dtype, device=depth_t.device)
+            cnt = torch.empty_strided((n, nc, res, res, res), strides, dtype=depth_t.dtype, device=depth_t.device)
+        else:
+            out = torch.empty((n, nc, res, res, res), dtype=depth_t.dtype, device=depth_t.device)
+            cnt = torch.empty_like(out)
         cam_bp_lib.back_projection_forward_shifted(depth_t, cam_dist, fl, out, cnt)
         ctx.save_for_backward(depth_t, fl, cam_dist, cnt)
         ctx.depth_shape = depth_t.shape
@@ -75,4 +82,4 @@ class ShiftedCameraBackProjection(Function):
         grad_camdist = torch.empty_like(grad_fl)
         cam_bp_lib.back_projection_backward_shifted(depth_t, fl, cam_dist, cnt, grad_output,
                                                     grad_depth, grad_camdist, grad_fl)
-        return grad_depth, grad_fl, grad_camdist, None
+        return grad_depth, grad_fl, grad_camdist, None, None

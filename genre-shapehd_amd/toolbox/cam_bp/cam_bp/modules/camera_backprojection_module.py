@@ -10,10 +10,14 @@ from ..functions.cam_back_projection import ShiftedCameraBackProjection
 
 
 class Camera_back_projection_layer(nn.Module):
-    def __init__(self, res=128):
+    def __init__(self, res=128, batch_minor=False):
+        """batch_minor (extension): batches of >= 16 single-channel maps get their volume laid out with the image
+        index fastest in memory (same logical shape and values; `.is_contiguous()` is False) -- the layout in which
+        render_spherical's fused forward is fastest.  Leave it off when training through the renderer."""
         super().__init__()
         assert res == 128
         self.res = 128
+        self.batch_minor = batch_minor
         self._consts = {}
 
     def _const(self, value, n, device):
@@ -33,7 +37,8 @@ class Camera_back_projection_layer(nn.Module):
         if type(cam_dist) == float:
             cam_dist = self._const(cam_dist, n, depth_t.device)
         if shift:       # 1 - res*tdf evaluated inside the native op (same values as shift_tdf(df))
-            return ShiftedCameraBackProjection.apply(depth_t, fl, cam_dist, self.res)
+            bm = self.batch_minor and n >= 16 and depth_t.size(1) == 1
+            return ShiftedCameraBackProjection.apply(depth_t, fl, cam_dist, self.res, bm)
         return CameraBackProjection.apply(depth_t, fl, cam_dist, self.res)
 
     @staticmethod

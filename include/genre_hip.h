@@ -245,6 +245,29 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
                                     const genre_tensor *v_scratch, const genre_tensor *kin,
                                     float pre_scale, void *stream);
 
+/* Batch-minor layout (extension).  When vox is laid out with the image index fastest in memory
+ * (stride[0] == 1 with NC == 1; element (n,x,y,z) at ((x*Y + y)*Z + z)*N + n) and holds >= 16 images,
+ * genre_render_spherical_forward (brick tables given) runs kernels in which a half-wave is 32 IMAGES
+ * of one sample / one ray: full-line loads and stores, per-lane serial scans.  v_scratch is then laid
+ * out [ray*ZR + k][image]; if it has room for 4 more floats per ray and image (>= rays*(ZR+4)) the
+ * forward also leaves the anchors this backward needs.  Results agree with the standard layout to
+ * fp32 rounding (the scan order differs), not bit for bit.
+ *
+ * genre_render_spherical_backward_gather is the backward for that layout: a reverse scan writes
+ * dL/dp [ray*ZR + k][image] into dp_scratch (>= rays*ZR floats), then every voxel of grad_vox
+ * (any strides; batch-minor is the fast case) gathers its (sample, weight) pairs in table order:
+ *   csr_rows    : int32 [n_rows,4] = (voxel (x*Y + y)*Z + z, begin, end, shared), voxel order, every
+ *                 voxel present; shared = 1 rows are split rows, accumulated with float atomics
+ *   csr_entries : int32 [E,2] = (sample row ray*ZR + k, weight as fp32 bits)
+ *   csr_shared  : int32 [n] voxels that have shared rows (zeroed first); may be NULL when n == 0
+ * Builder: genre-shapehd_amd/toolbox/_fused_render.py: build_voxel_csr. */
+int genre_render_spherical_backward_gather(const genre_tensor *vox, const genre_tensor *dirs,
+                                           const genre_tensor *depth_weight, const genre_tensor *grad_out,
+                                           const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
+                                           const genre_tensor *csr_rows, const genre_tensor *csr_entries,
+                                           const genre_tensor *csr_shared, const genre_tensor *v_scratch,
+                                           const genre_tensor *kin, float pre_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,3 +147,48 @@ def test_fused_pad_matches_sph_pad(pad, genre, dev):
     # and against the reference's op sequence (unfused module + torch sph_pad)
     ref = genre.render_spherical(fused=False).to(dev)
     assert (genre.sph_pad(ref(vox), pad) - out_f).abs().max().item() <= 1e-5
+
+
+def _batch_minor(t):
+    n, c, x, y, z = t.shape
+    out = torch.empty_strided((n, c, x, y, z), (1, n * x * y * z, y * z * n, z * n, n), dtype=t.dtype, device=t.device)
+    out.copy_(t)
+    return out
+
+
+@pytest.mark.parametrize("n,pre_scale,pad", [(32, None, 0), (32, 20.0, 16), (19, 20.0, 16)])
+def test_batch_minor_layout_matches_standard(n, pre_scale, pad, genre, dev):
+    """the same logical volume with the image index fastest in memory takes the batch-minor kernels (half-wave =
+    32 images of one sample, serial per-lane scans, gather backward): values agree with the standard path to fp32
+    rounding (the scan order differs), gradients to 1e-5 of their maximum"""
+    rng = np.random.default_rng(31)
+    vox = torch.from_numpy(rng.uniform(0.0, 0.05, (n, 1, 128, 128, 128)).astype(np.float32)).to(dev)
+    vox[:, :, 40:60, 50:70, 30:90] = 0.9                              # a solid block: transmittance underflows behind it
+    mod = genre.render_spherical().to(dev)
+    a = vox.clone().requires_grad_(True)
+    b = _batch_minor(vox).requires_grad_(True)
+    assert b.stride(0) == 1 and torch.equal(a, b)
+    out_a = mod(a, pre_scale=pre_scale, pad=pad)
+    out_b = mod(b, pre_scale=pre_scale, pad=pad)
+    assert out_a.shape == out_b.shape and out_b.is_contiguous()
+    assert (out_a - out_b).abs().max().item() <= 1e-6
+    g = torch.from_numpy(rng.standard_normal(tuple(out_a.shape)).astype(np.float32)).to(dev)
+    out_a.backward(g)
+    out_b.backward(g)
+    assert b.grad.stride(0) == 1                                       # the gradient comes back in the same layout
+    scale = a.grad.abs().max().item()
+    assert (a.grad - b.grad).abs().max().item() <= 1e-5 * max(1.0, scale)
+
+
+def test_camera_layer_batch_minor_option(genre, dev):
+    """Camera_back_projection_layer(batch_minor=True): same values, image-minor memory; the chain through the
+    renderer equals the standard-layout chain"""
+    d = torch.from_numpy(inputs.batch_depth(16)).to(dev)
+    std, bm = genre.Camera_back_projection_layer().to(dev), genre.Camera_back_projection_layer(batch_minor=True).to(dev)
+    ps, pb = std(d), bm(d)
+    assert pb.stride(0) == 1 and not pb.is_contiguous() and pb.shape == ps.shape
+    assert (ps - pb).abs().max().item() <= 1e-5                        # multi-hit voxels: float-atomic order
+    render = genre.render_spherical().to(dev)
+    with torch.no_grad():
+        assert (render(ps, pre_scale=50.0, pad=16) - render(pb, pre_scale=50.0, pad=16)).abs().max().item() <= 1e-5
+    assert bm(d[:4]).is_contiguous()                                    # small batches keep the standard layout
