@@ -1245,6 +1245,9 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
             : launch_sample_group<1, 512>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, st);
         if (!ok) return 0;
         GENRE_LAUNCH_CHECK("render_spherical forward (bricks)");
+        // (LDS-transposed per-lane serial scans for this layout -- 64 rays per wave, 16-sample tiles -- measured 136 us
+        // forward / 243 us backward against 124-150 / 196 for the tree scans below: the tile loads serialise with the
+        // recurrence; only the batch-minor layout, where lanes are images and loads need no transpose, profits)
         render_scan_fwd_kernel<<<scan_grid(D), kBlock, 0, st>>>(
             D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data, view4(out));
         GENRE_LAUNCH_CHECK("render_spherical forward (scan)");

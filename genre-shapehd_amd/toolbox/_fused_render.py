@@ -233,7 +233,7 @@ class RenderSphericalFused(Function):
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
         rays = vox.shape[0] * vox.shape[1] * res * res
         ctx.batch_minor = is_batch_minor(vox) and rays * z_res < (1 << 31)
-        # batch-minor volumes: room for the backward scan's anchors behind the samples (4 floats per ray and image)
+        # batch-minor volumes: 4 floats per ray and image behind the samples for the backward scan's anchors
         v = torch.empty((rays * (z_res + 4) if ctx.batch_minor else rays * z_res,), dtype=torch.float32, device=vox.device)
         lib.render_spherical_forward(vox, dirs64.view(torch.float32), depth_weight, out,
                                      v, t["fwd_table"], t["fwd_chunks"], t["kin"], float(pre_scale))
@@ -248,10 +248,10 @@ class RenderSphericalFused(Function):
         lib = _loader().render_lib
         z_res = depth_weight.shape[0]
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
+        rays = vox.shape[0] * vox.shape[1] * dirs64.shape[0] * dirs64.shape[0]
         if ctx.batch_minor:
             c = csr_for(vox.shape, vox.device, dirs64, z_res)
             grad_vox = empty_batch_minor(vox.shape, vox.dtype, vox.device)
-            rays = vox.shape[0] * vox.shape[1] * dirs64.shape[0] * dirs64.shape[0]
             scratch = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
             lib.render_spherical_backward_gather(vox, dirs64.view(torch.float32), depth_weight, grad_out.contiguous(),
                                                  grad_vox, scratch, c["csr_rows"], c["csr_entries"],
@@ -259,7 +259,7 @@ class RenderSphericalFused(Function):
                                                  ctx.pre_scale)
             return grad_vox, None, None, None, None
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
-        scratch = torch.empty((v.numel() + 4,), dtype=torch.float32, device=vox.device)
+        scratch = torch.empty((rays * z_res + 4,), dtype=torch.float32, device=vox.device)
         lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,
                                       scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"], ctx.pre_scale)
         return grad_vox, None, None, None, None
