@@ -156,7 +156,7 @@ def _batch_minor(t):
     return out
 
 
-@pytest.mark.parametrize("n,pre_scale,pad", [(32, None, 0), (32, 20.0, 16), (19, 20.0, 16)])
+@pytest.mark.parametrize("n,pre_scale,pad", [(32, None, 0), (32, 20.0, 16), (19, 20.0, 16), (40, None, 16)])
 def test_batch_minor_layout_matches_standard(n, pre_scale, pad, genre, dev):
     """the same logical volume with the image index fastest in memory takes the batch-minor kernels (half-wave =
     32 images of one sample, serial per-lane scans, gather backward): values agree with the standard path to fp32
