@@ -190,11 +190,11 @@ class _RenderLib:
 
 
     @staticmethod
-    def render_spherical_backward_gather(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox, dp_scratch, csr_rows,
-                                         csr_entries, csr_shared, v_scratch, kin, pre_scale=0.0):
-        """backward for batch-minor volumes: reverse scan + per-voxel gather (tables: build_voxel_csr)"""
-        return _call("genre_render_spherical_backward_gather", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                     dp_scratch, csr_rows, csr_entries, csr_shared, v_scratch, kin, scalars=(C.c_float(pre_scale),))
+    def render_spherical_backward_bm(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox, dp_scratch, sub_rows,
+                                     sub_list, v_scratch, kin, pre_scale=0.0):
+        """backward for batch-minor volumes: reverse scan + sub-brick-owned accumulation (build_subbrick_table)"""
+        return _call("genre_render_spherical_backward_bm", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
+                     dp_scratch, sub_rows, sub_list, v_scratch, kin, scalars=(C.c_float(pre_scale),))
 
 
 class _GlueLib:

@@ -630,8 +630,8 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
 //   * the geometry of a sample is computed once per 32 images (by one lane, handed over through LDS);
 //   * the per-ray scans need no cross-lane operation at all: a lane walks ITS ray's 256 samples serially
 //     (~10 instructions per sample per 64 image-rays instead of ~110 per ray for the DPP tree scans);
-//   * the backward becomes a deterministic gather: every voxel sums its (sample, weight) list in a fixed order
-//     (tables by toolbox/_fused_render.py: build_voxel_csr), each dL/dp line read serves 32 images.
+//   * the backward accumulates per 4^3 sub-brick in LDS with lanes = images: no atomics, a fixed summation order
+//     (lists by toolbox/_fused_render.py: build_subbrick_table).
 // Scratch layouts here: v[(q*ZR + k)*N + n], dL/dp likewise.
 constexpr int kBmLanes = 32;                        // images per half-wave
 constexpr int kBmRec = 12;                          // LDS record per sample: offset, mask, entry, pad, 8 weights (3 x b128)
@@ -889,68 +889,143 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_bm_kernel(RenderDims D
     }
 }
 
-// backward gather, batch-minor: a half-wave owns a voxel row (csr_rows) and 32 images; it walks the row's
-// (sample, weight) pairs in table order -- a fixed summation order -- reading one 128-byte dL/dp line per pair.
-// Measured at batch 32: 1.0-1.2 ms, against 0.76 ms for the brick-owned LDS accumulation of the standard layout:
-// the dL/dp lines of a voxel's pairs have little cache locality (63 % L2 misses, ~1.8 GB from HBM), whatever the
-// row order (raster, 4x4x8 ... 16^3 blocks) and with four rows per half-wave in lock step (slower still).  It is
-// what makes the batch-minor path differentiable, not a reason to train in that layout.
-constexpr int kRowsPerHalf = 1;
+// backward accumulation, batch-minor: a WAVE owns a 4^3-voxel sub-brick and keeps its gradients for 32 images in
+// 8 KB of LDS as plain fp32 [voxel][image].  Lanes are images, so the lanes of an instruction never touch the same
+// word; the two half-waves take the z0 and the z0+1 corner plane of the same sample -- different voxels -- and a wave
+// walks its list (sub_rows / sub_list: every sample with a corner in the sub-brick) in order: no atomics, a fixed
+// summation order.  Measured at batch 32: 1.1 ms -- slower than the 0.76 ms of the standard layout's brick kernel
+// (ablations: ~0.5 ms in the LDS read-modify-writes, ~0.3 ms in the dL/dp line reads), as was a per-voxel gather over
+// precomputed (sample, weight) lists (1.0-1.2 ms; 2.1 ms with 16 rows per half-wave, 1.8 ms with four in lock step,
+// no better with dL/dp stored in brick order).  It makes the batch-minor path differentiable; train in the standard
+// layout.
+constexpr int kSub = 2, kSubE = 1 << kSub, kSubV = kSubE * kSubE * kSubE;
 
-__global__ __launch_bounds__(kBlock) void render_bwd_gather_bm_kernel(RenderDims D, const float *__restrict__ dpbm,
-                                                                       const int4 *__restrict__ rows, int n_rows,
-                                                                       const int2 *__restrict__ entries, View5 vox,
-                                                                       View5 gvox)
+__global__ __launch_bounds__(kBlock) void render_bwd_sub_bm_kernel(RenderDims D, const double *__restrict__ dirs,
+                                                                    const float *__restrict__ dpbm,
+                                                                    const int4 *__restrict__ sub_rows, int n_rows,
+                                                                    const int *__restrict__ sub_list, View5 vox, View5 gvox,
+                                                                    int zero_only)
 {
-    const int imgs = D.N * D.NC;
-    // XCD-aware order (see render_sample_bm_kernel): each XCD takes a contiguous eighth of the rows
-    const int per_xcd = (gridDim.x + 7) >> 3;
-    const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int row = blk * (kBlock / kBmLanes) + (threadIdx.x >> 5);
+    __shared__ float accs[kWavesPerBlock][kSubV * kBmLanes];
+    __shared__ __attribute__((aligned(16))) int recs[kWavesPerBlock][64 * kBmRec];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = blockIdx.x * kWavesPerBlock + wv;
     if (row >= n_rows) return;
-    const int li = threadIdx.x & 31;
-    const int4 rw = rows[row];
-    const int voxel = rw.x, begin = rw.y, end = rw.z, shared = rw.w;
-    const int z = voxel % D.Z, y = (voxel / D.Z) % D.Y, x = voxel / (D.Z * D.Y);
+    const int4 rw = sub_rows[row];
+    const int sb = rw.x, begin = rw.y, end = rw.z, shared = rw.w;
+    const int nsy = (D.Y + kSubE - 1) >> kSub, nsz = (D.Z + kSubE - 1) >> kSub;
+    const int ox = (sb / (nsy * nsz)) << kSub, oy = ((sb / nsz) % nsy) << kSub, oz = (sb % nsz) << kSub;
+    const int half = lane >> 5, li = lane & 31;
+    const int imgs = D.N * D.NC;
+    float *acc = accs[wv];
+    int *my = recs[wv];
     for (int g0 = 0; g0 < imgs; g0 += kBmLanes) {
         const int img = g0 + li;
-        if (img >= imgs) break;
-        float acc = 0.f;
-        int e = begin;
-        for (; e + 4 <= end; e += 4) {
-            int2 en[4];
-            float d[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) en[u] = entries[e + u];
-#pragma unroll
-            for (int u = 0; u < 4; u++) d[u] = dpbm[(unsigned)en[u].x * (unsigned)imgs + (unsigned)img];
-#pragma unroll
-            for (int u = 0; u < 4; u++) acc = __builtin_fmaf(__int_as_float(en[u].y), d[u], acc);
+        const bool img_on = img < imgs;
+        const int n = img_on ? img / D.NC : 0, c_ = img_on ? img % D.NC : 0;
+        if (zero_only) {                                               // pre-pass: shared sub-bricks start from zero
+            if (shared && img_on)
+                for (int v = half; v < kSubV; v += 2) {
+                    const int x = ox + (v >> (2 * kSub)), y = oy + ((v >> kSub) & (kSubE - 1)), z = oz + (v & (kSubE - 1));
+                    if (x < D.X && y < D.Y && z < D.Z) gvox.p[n * gvox.s0 + c_ * gvox.s1 + x * gvox.s2 + y * gvox.s3 + z * gvox.s4] = 0.f;
+                }
+            continue;
         }
-        for (; e < end; e++) {
-            const int2 en = entries[e];
-            acc = __builtin_fmaf(__int_as_float(en.y), dpbm[(unsigned)en.x * (unsigned)imgs + (unsigned)img], acc);
+#pragma unroll
+        for (int t = 0; t < kSubV * kBmLanes / 64; t++) acc[t * 64 + lane] = 0.f;
+        for (int e0 = begin; e0 < end; e0 += 64) {
+            {   // phase A: lane l works out the geometry of entry e0 + l (see render_sample_bm_kernel)
+                const int e = e0 + lane;
+                unsigned ent = 0xffffffffu;
+                int lidx = 0, mask = 0;
+                float w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (e < end) {
+                    ent = (unsigned)sub_list[e];
+                    const int q = (int)(ent >> 8), k = (int)(ent & 255u);
+                    float gx, gy, gz;
+                    sample_pos(D, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, k, gx, gy, gz);
+                    Cell c;
+                    locate(D, gx, gy, gz, c);
+                    const int lx = c.x0 - ox, ly = c.y0 - oy, lz = c.z0 - oz;
+                    lidx = (lx * kSubE + ly) * kSubE + lz;                // may be negative: only owned corners are used
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int x = lx + (i & 1), y = ly + ((i >> 1) & 1), z = lz + ((i >> 2) & 1);
+                        if ((unsigned)x < (unsigned)kSubE && (unsigned)y < (unsigned)kSubE && (unsigned)z < (unsigned)kSubE &&
+                            ox + x < D.X && oy + y < D.Y && oz + z < D.Z)
+                            mask |= 1 << i;
+                        w[i] = corner_w(c, i);
+                    }
+                }
+                int4 *dst = reinterpret_cast<int4 *>(my + lane * kBmRec);
+                dst[0] = make_int4(lidx, mask, (int)ent, 0);
+                dst[1] = make_int4(__float_as_int(w[0]), __float_as_int(w[1]), __float_as_int(w[2]), __float_as_int(w[3]));
+                dst[2] = make_int4(__float_as_int(w[4]), __float_as_int(w[5]), __float_as_int(w[6]), __float_as_int(w[7]));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const int cnt = end - e0 < 64 ? end - e0 : 64;
+            // phase B: one sample per step; half h adds the corners of plane z0 + h (weights 4h .. 4h+3)
+            float dnext = 0.f;
+            {
+                const unsigned ent0 = (unsigned)my[2];
+                dnext = img_on ? dpbm[((ent0 >> 8) * (unsigned)D.ZR + (ent0 & 255u)) * (unsigned)imgs + (unsigned)img] : 0.f;
+            }
+            for (int s0 = 0; s0 < cnt; s0++) {
+                const int4 *r = reinterpret_cast<const int4 *>(my + s0 * kBmRec);
+                const int4 h0 = r[0], wq = r[1 + half];
+                const float d = dnext;
+                if (s0 + 1 < cnt) {                                     // the next sample's line is requested now
+                    const unsigned en = (unsigned)my[(s0 + 1) * kBmRec + 2];
+                    dnext = img_on ? dpbm[((en >> 8) * (unsigned)D.ZR + (en & 255u)) * (unsigned)imgs + (unsigned)img] : 0.f;
+                }
+                const int mask = h0.y >> (4 * half);
+                const int base = h0.x + half;                           // + 1 in z for the upper plane
+                const float w4[4] = {__int_as_float(wq.x), __int_as_float(wq.y), __int_as_float(wq.z), __int_as_float(wq.w)};
+                // the four cells are distinct voxels: read them together, then write them together (written as four
+                // read-modify-writes the compiler must assume aliasing: four dependent LDS round trips per sample)
+                float cur[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int vi = base + ((i & 1) ? kSubE * kSubE : 0) + ((i & 2) ? kSubE : 0);
+                    cur[i] = (mask & (1 << i)) ? acc[vi * kBmLanes + li] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int vi = base + ((i & 1) ? kSubE * kSubE : 0) + ((i & 2) ? kSubE : 0);
+                    if (mask & (1 << i)) acc[vi * kBmLanes + li] = __builtin_fmaf(w4[i], d, cur[i]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        const int n = img / D.NC, c = img % D.NC;
-        if (D.pre_scale != 0.0f) {                           // adjoint of clamp(x * pre_scale, lo, hi)
-            const float tv = vox.p[n * vox.s0 + c * vox.s1 + x * D.sx + y * D.sy + z * D.sz] * D.pre_scale;
-            acc = (tv >= D.lo && tv <= D.hi) ? acc * D.pre_scale : 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (img_on) {
+            // flush: all clamp-mask lines of this half are requested before the first one is used (32 dependent
+            // round trips otherwise -- longer than the accumulation itself)
+            constexpr int kPer = kSubV / 2;
+            float tv[kPer];
+#pragma unroll
+            for (int t = 0; t < kPer; t++) {
+                const int v = 2 * t + half;
+                const int x = ox + (v >> (2 * kSub)), y = oy + ((v >> kSub) & (kSubE - 1)), z = oz + (v & (kSubE - 1));
+                tv[t] = 0.f;
+                if (D.pre_scale != 0.0f && x < D.X && y < D.Y && z < D.Z)
+                    tv[t] = vox.p[n * vox.s0 + c_ * vox.s1 + x * D.sx + y * D.sy + z * D.sz] * D.pre_scale;
+            }
+#pragma unroll
+            for (int t = 0; t < kPer; t++) {
+                const int v = 2 * t + half;
+                const int x = ox + (v >> (2 * kSub)), y = oy + ((v >> kSub) & (kSubE - 1)), z = oz + (v & (kSubE - 1));
+                if (x < D.X && y < D.Y && z < D.Z) {
+                    float a = acc[v * kBmLanes + li];
+                    if (D.pre_scale != 0.0f) a = (tv[t] >= D.lo && tv[t] <= D.hi) ? a * D.pre_scale : 0.0f;   // clamp adjoint
+                    float *dst = gvox.p + n * gvox.s0 + c_ * gvox.s1 + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
+                    if (!shared) *dst = a;
+                    else if (a != 0.0f) unsafeAtomicAdd(dst, a);
+                }
+            }
         }
-        float *dst = gvox.p + n * gvox.s0 + c * gvox.s1 + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
-        if (!shared) *dst = acc;
-        else if (acc != 0.0f) unsafeAtomicAdd(dst, acc);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-}
-
-__global__ void zero_voxels_bm_kernel(RenderDims D, const int *__restrict__ voxels, int n, View5 gvox)
-{
-    const int imgs = D.N * D.NC;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int v = (int)(t / imgs), img = (int)(t % imgs);
-    if (v >= n) return;
-    const int voxel = voxels[v];
-    const int z = voxel % D.Z, y = (voxel / D.Z) % D.Y, x = voxel / (D.Z * D.Y);
-    gvox.p[(img / D.NC) * gvox.s0 + (img % D.NC) * gvox.s1 + x * gvox.s2 + y * gvox.s3 + z * gvox.s4] = 0.f;
 }
 
 // ---- backward pass B: brick-owned accumulation ----------------------------------------------------
@@ -1335,14 +1410,14 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
     return 1;
 }
 
-extern "C" int genre_render_spherical_backward_gather(const genre_tensor *vox, const genre_tensor *dirs,
-                                                      const genre_tensor *depth_weight, const genre_tensor *grad_out,
-                                                      const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
-                                                      const genre_tensor *csr_rows, const genre_tensor *csr_entries,
-                                                      const genre_tensor *csr_shared, const genre_tensor *v_scratch,
-                                                      const genre_tensor *kin, float pre_scale, void *stream)
+extern "C" int genre_render_spherical_backward_bm(const genre_tensor *vox, const genre_tensor *dirs,
+                                                  const genre_tensor *depth_weight, const genre_tensor *grad_out,
+                                                  const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
+                                                  const genre_tensor *sub_rows, const genre_tensor *sub_list,
+                                                  const genre_tensor *v_scratch, const genre_tensor *kin,
+                                                  float pre_scale, void *stream)
 {
-    const char *op = "render_spherical_backward_gather";
+    const char *op = "render_spherical_backward_bm";
     RenderDims D{};
     if (!check_render(op, vox, dirs, depth_weight, grad_out, D)) return 0;
     D.pre_scale = pre_scale;
@@ -1350,16 +1425,13 @@ extern "C" int genre_render_spherical_backward_gather(const genre_tensor *vox, c
     GENRE_REQUIRE(D.ZR <= 256 && (D.ZR & 3) == 0, "%s: needs z_res <= 256 and z_res %% 4 == 0", op);
     const int imgs = D.N * D.NC;
     const int64_t rays = (int64_t)imgs * D.R * D.R;
-    const int64_t nvox = (int64_t)D.X * D.Y * D.Z;
     if (numel(grad_vox) == 0) return 1;
     GENRE_REQUIRE(rays * D.ZR < ((int64_t)1 << 31), "%s: rays * z_res must be < 2^31", op);
-    GENRE_REQUIRE(is_i32(csr_rows, 2) && csr_rows->size[1] == 4 && is_contiguous(csr_rows) && csr_rows->size[0] >= nvox &&
-                      csr_rows->size[0] < ((int64_t)1 << 30),
-                  "%s: csr_rows must be a contiguous int32 [rows >= X*Y*Z, 4] tensor", op);
-    GENRE_REQUIRE(is_i32(csr_entries, 2) && csr_entries->size[1] == 2 && is_contiguous(csr_entries) &&
-                      aligned16(csr_entries->data),
-                  "%s: csr_entries must be a contiguous, 16-byte aligned int32 [E, 2] tensor", op);
-    GENRE_REQUIRE(!csr_shared || (is_i32(csr_shared, 1) && is_contiguous(csr_shared)), "%s: csr_shared must be int32 [n]", op);
+    const int nsub = ((D.X + kSubE - 1) >> kSub) * ((D.Y + kSubE - 1) >> kSub) * ((D.Z + kSubE - 1) >> kSub);
+    GENRE_REQUIRE(is_i32(sub_rows, 2) && sub_rows->size[1] == 4 && is_contiguous(sub_rows) && sub_rows->size[0] >= nsub &&
+                      sub_rows->size[0] < ((int64_t)1 << 30) && aligned16(sub_rows->data),
+                  "%s: sub_rows must be a contiguous int32 [rows >= %d, 4] tensor", op, nsub);
+    GENRE_REQUIRE(is_i32(sub_list, 1) && is_contiguous(sub_list), "%s: sub_list must be int32 [S]", op);
     GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && v_scratch->size[0] >= rays * (D.ZR + 4) &&
                       aligned16(v_scratch->data),
                   "%s: v_scratch must be the forward's buffer of >= rays*(ZR+4) floats (samples + anchors)", op);
@@ -1381,17 +1453,17 @@ extern "C" int genre_render_spherical_backward_gather(const genre_tensor *vox, c
             reinterpret_cast<const BmAnchor *>((const float *)v_scratch->data + rays * D.ZR), (float *)dp_scratch->data);
         GENRE_LAUNCH_CHECK("render_spherical backward (batch-minor scan)");
     }
-    const int n_shared = csr_shared ? (int)csr_shared->size[0] : 0;
-    if (n_shared > 0) {
-        const int64_t t = (int64_t)n_shared * imgs;
-        zero_voxels_bm_kernel<<<(int)((t + 255) / 256), 256, 0, st>>>(D, (const int *)csr_shared->data, n_shared, view5(grad_vox));
-        GENRE_LAUNCH_CHECK("render_spherical backward (zero shared voxels)");
+    const int n_rows = (int)sub_rows->size[0];
+    const int gb = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (n_rows > nsub) {        // some sub-bricks are split over several rows: those accumulate with atomics
+        render_bwd_sub_bm_kernel<<<gb, kBlock, 0, st>>>(D, (const double *)dirs->data, (const float *)dp_scratch->data,
+                                                       (const int4 *)sub_rows->data, n_rows, (const int *)sub_list->data,
+                                                       view5(vox), view5(grad_vox), 1);
+        GENRE_LAUNCH_CHECK("render_spherical backward (zero shared sub-bricks)");
     }
-    const int n_rows = (int)csr_rows->size[0];
-    const int per_block = kBlock / kBmLanes * kRowsPerHalf;
-    const int gb = ((n_rows + per_block - 1) / per_block + 7) / 8 * 8;
-    render_bwd_gather_bm_kernel<<<gb, kBlock, 0, st>>>(D, (const float *)dp_scratch->data, (const int4 *)csr_rows->data, n_rows,
-                                                      (const int2 *)csr_entries->data, view5(vox), view5(grad_vox));
-    GENRE_LAUNCH_CHECK("render_spherical backward (gather)");
+    render_bwd_sub_bm_kernel<<<gb, kBlock, 0, st>>>(D, (const double *)dirs->data, (const float *)dp_scratch->data,
+                                                   (const int4 *)sub_rows->data, n_rows, (const int *)sub_list->data,
+                                                   view5(vox), view5(grad_vox), 0);
+    GENRE_LAUNCH_CHECK("render_spherical backward (sub-bricks)");
     return 1;
 }

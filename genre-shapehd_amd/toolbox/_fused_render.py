@@ -107,79 +107,6 @@ def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT_BWD, split_fwd=SPLIT_
     return dict(bwd_table=bwd_table, bwd_chunks=bwd_chunks, fwd_table=fwd_table, fwd_chunks=fwd_chunks, kin=kin)
 
 
-CSR_SPLIT = 512         # voxel rows of the gather backward above this many (sample, weight) pairs are split
-
-
-def build_voxel_csr(X, Y, Z, dirs64, z_res, split=CSR_SPLIT):
-    """Geometry-only tables of the batch-minor gather backward (csrc/sph_render.hip: render_bwd_gather_bm_kernel):
-    for every voxel the list of samples whose trilinear cell touches it, with the weight of that corner.
-
-      rows    int32 [n_rows,4] = (voxel = (x*Y + y)*Z + z, begin, end, shared); one row per voxel, in voxel order;
-              voxels with more than `split` pairs get several rows (shared = 1: accumulated with atomics onto a
-              pre-zeroed voxel)
-      entries int32 [E,2]      = (sample row q*z_res + k, weight as fp32 bits), per voxel sorted by sample
-      shared  int32 [n]        = the voxels that have split rows
-
-    Positions, cells and weights follow the kernels' fp64/fp32 sequence (sample_pos, locate, corner_w:
-    ATen's (wx*wy)*wz), so every weight is bit-identical to what the forward sampler multiplies with."""
-    R = dirs64.shape[0]
-    d2 = dirs64.reshape(-1, 3).astype(np.float64) * 2.0
-    step = 1.0 / (z_res - 1) if z_res > 1 else 0.0
-    alpha = np.arange(z_res, dtype=np.float64) * step
-    alpha[-1] = 1.0
-    a = 1.0 - alpha
-    one, two = np.float32(1), np.float32(2)
-    i0s, w0s, w1s = [], [], []
-    anyin = None
-    for ax, size in enumerate((X, Y, Z)):
-        g = (d2[:, None, ax] * a[None, :]).astype(np.float32)                # [R*R, ZR]
-        ix = ((g + one) / two) * np.float32(size - 1)
-        fx = np.floor(ix)
-        i0 = fx.astype(np.int32)
-        inside = (i0 >= -1) & (i0 < size)
-        anyin = inside if anyin is None else (anyin & inside)
-        i0s.append(i0); w1s.append(ix - fx); w0s.append((fx + one) - ix)
-    sid = np.arange(R * R * z_res, dtype=np.int64).reshape(R * R, z_res)
-    keys, wts = [], []
-    for c in range(8):
-        bx, by, bz = c & 1, (c >> 1) & 1, (c >> 2) & 1
-        x, y, z = i0s[0] + bx, i0s[1] + by, i0s[2] + bz
-        m = anyin & (x >= 0) & (x < X) & (y >= 0) & (y < Y) & (z >= 0) & (z < Z)
-        wx = (w1s[0] if bx else w0s[0])[m]
-        wy = (w1s[1] if by else w0s[1])[m]
-        wz = (w1s[2] if bz else w0s[2])[m]
-        w = (wx * wy) * wz                                                   # fp32, ATen order
-        vox = (x[m].astype(np.int64) * Y + y[m]) * Z + z[m]
-        keys.append((vox << 32) | sid[m])
-        wts.append(w.astype(np.float32))
-    keys = np.concatenate(keys)
-    wts = np.concatenate(wts)
-    order = np.argsort(keys, kind="stable")
-    keys, wts = keys[order], wts[order]
-    vox = (keys >> 32).astype(np.int64)
-    entries = np.empty((keys.shape[0], 2), np.int32)
-    entries[:, 0] = (keys & 0xFFFFFFFF).astype(np.int32)
-    entries[:, 1] = wts.view(np.int32)
-    nvox = X * Y * Z
-    begin = np.searchsorted(vox, np.arange(nvox), side="left").astype(np.int64)
-    end = np.searchsorted(vox, np.arange(nvox), side="right").astype(np.int64)
-    cnt = end - begin
-    big = np.nonzero(cnt > split)[0]
-    rows = np.stack([np.arange(nvox, dtype=np.int64), begin, end, np.zeros(nvox, np.int64)], 1)
-    if big.size:
-        keep = np.ones(nvox, bool)
-        keep[big] = False
-        extra = []
-        for v in big:
-            parts = -(-int(cnt[v]) // split)
-            size = -(-int(cnt[v]) // parts)
-            for s0 in range(int(begin[v]), int(end[v]), size):
-                extra.append((int(v), s0, min(s0 + size, int(end[v])), 1))
-        rows = np.concatenate([rows[keep], np.asarray(extra, np.int64).reshape(-1, 4)], 0)
-        rows = rows[np.argsort(rows[:, 0], kind="stable")]
-    return dict(csr_rows=rows.astype(np.int32), csr_entries=entries, csr_shared=big.astype(np.int32))
-
-
 def tables_for(vox_shape, device, dirs64, z_res):
     small = vox_shape[0] * vox_shape[1] < SMALL_BATCH
     key = (tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device), small)
@@ -192,12 +119,60 @@ def tables_for(vox_shape, device, dirs64, z_res):
     return t
 
 
-def csr_for(vox_shape, device, dirs64, z_res):
-    """per-voxel (sample, weight) tables of the batch-minor backward, built on first use and cached"""
-    key = ("csr", tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device))
+SUB = 2                 # log2 of the sub-brick edge of the batch-minor backward (4^3 voxels); matches kSub in sph_render.hip
+SUB_SPLIT = 512         # sub-brick rows above this many samples are split (atomic flush)
+
+
+def build_subbrick_table(X, Y, Z, dirs64, z_res, split=SUB_SPLIT):
+    """Geometry-only table of the batch-minor backward (csrc/sph_render.hip: render_bwd_sub_bm_kernel): for every
+    4^3-voxel sub-brick the samples with at least one trilinear corner inside it.
+
+      sub_rows  int32 [rows,4] = (sub-brick id (sx*nsy + sy)*nsz + sz, begin, end, shared), heaviest first; one row per
+                sub-brick, more when it holds over `split` samples (shared = 1: flushed with atomics onto zeroed voxels)
+      sub_list  int32 [S]      = (ray << 8) | k, per sub-brick sorted by (ray, k)
+
+    Same fp64/fp32 position arithmetic as the kernels (sample_pos, locate), so membership is exact."""
+    R = dirs64.shape[0]
+    assert z_res <= 256 and R * R < (1 << 24)
+    d2 = dirs64.reshape(-1, 3).astype(np.float64) * 2.0
+    step = 1.0 / (z_res - 1) if z_res > 1 else 0.0
+    alpha = np.arange(z_res, dtype=np.float64) * step
+    alpha[-1] = 1.0
+    a = 1.0 - alpha
+    one, two = np.float32(1), np.float32(2)
+    nsx, nsy, nsz = -(-X >> SUB), -(-Y >> SUB), -(-Z >> SUB)
+    axes = []
+    anyin = None
+    for ax, size in enumerate((X, Y, Z)):
+        g = (d2[:, None, ax] * a[None, :]).astype(np.float32)
+        i0 = np.floor(((g + one) / two) * np.float32(size - 1)).astype(np.int32)
+        inside = (i0 >= -1) & (i0 < size)
+        anyin = inside if anyin is None else (anyin & inside)
+        b0, v0 = i0 >> SUB, i0 >= 0
+        b1 = (i0 + 1) >> SUB
+        v1 = (i0 + 1 <= size - 1) & ((b1 != b0) | ~v0)
+        axes.append(((b0, v0), (b1, v1)))
+    sample_id = np.arange(R * R * z_res, dtype=np.int64).reshape(R * R, z_res)
+    keys = []
+    for cx in axes[0]:
+        for cy in axes[1]:
+            for cz in axes[2]:
+                m = anyin & cx[1] & cy[1] & cz[1]
+                if m.any():
+                    sb = (cx[0][m].astype(np.int64) * nsy + cy[0][m]) * nsz + cz[0][m]
+                    keys.append((sb << 32) | sample_id[m])
+    keys = np.sort(np.concatenate(keys)) if keys else np.zeros((0,), np.int64)
+    sid = keys & 0xFFFFFFFF
+    rows, words = _rows((keys >> 32).astype(np.int64), sid // z_res, sid % z_res, nsx * nsy * nsz, split, 1)
+    return dict(sub_rows=rows, sub_list=words)
+
+
+def sub_for(vox_shape, device, dirs64, z_res):
+    """sub-brick sample lists of the batch-minor backward, built on first use and cached"""
+    key = ("sub", tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device))
     t = _TABLES.get(key)
     if t is None:
-        np_t = build_voxel_csr(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), z_res)
+        np_t = build_subbrick_table(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), z_res)
         t = {k: torch.from_numpy(v).to(device) for k, v in np_t.items()}
         _TABLES[key] = t
     return t
@@ -250,13 +225,11 @@ class RenderSphericalFused(Function):
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
         rays = vox.shape[0] * vox.shape[1] * dirs64.shape[0] * dirs64.shape[0]
         if ctx.batch_minor:
-            c = csr_for(vox.shape, vox.device, dirs64, z_res)
+            c = sub_for(vox.shape, vox.device, dirs64, z_res)
             grad_vox = empty_batch_minor(vox.shape, vox.dtype, vox.device)
             scratch = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
-            lib.render_spherical_backward_gather(vox, dirs64.view(torch.float32), depth_weight, grad_out.contiguous(),
-                                                 grad_vox, scratch, c["csr_rows"], c["csr_entries"],
-                                                 c["csr_shared"] if c["csr_shared"].numel() else None, v, t["kin"],
-                                                 ctx.pre_scale)
+            lib.render_spherical_backward_bm(vox, dirs64.view(torch.float32), depth_weight, grad_out.contiguous(),
+                                             grad_vox, scratch, c["sub_rows"], c["sub_list"], v, t["kin"], ctx.pre_scale)
             return grad_vox, None, None, None, None
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
         scratch = torch.empty((rays * z_res + 4,), dtype=torch.float32, device=vox.device)

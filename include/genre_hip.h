@@ -250,23 +250,22 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  * genre_render_spherical_forward (brick tables given) runs kernels in which a half-wave is 32 IMAGES
  * of one sample / one ray: full-line loads and stores, per-lane serial scans.  v_scratch is then laid
  * out [ray*ZR + k][image]; if it has room for 4 more floats per ray and image (>= rays*(ZR+4)) the
- * forward also leaves the anchors this backward needs.  Results agree with the standard layout to
- * fp32 rounding (the scan order differs), not bit for bit.
- *
- * genre_render_spherical_backward_gather is the backward for that layout: a reverse scan writes
- * dL/dp [ray*ZR + k][image] into dp_scratch (>= rays*ZR floats), then every voxel of grad_vox
- * (any strides; batch-minor is the fast case) gathers its (sample, weight) pairs in table order:
- *   csr_rows    : int32 [n_rows,4] = (voxel (x*Y + y)*Z + z, begin, end, shared), voxel order, every
- *                 voxel present; shared = 1 rows are split rows, accumulated with float atomics
- *   csr_entries : int32 [E,2] = (sample row ray*ZR + k, weight as fp32 bits)
- *   csr_shared  : int32 [n] voxels that have shared rows (zeroed first); may be NULL when n == 0
- * Builder: genre-shapehd_amd/toolbox/_fused_render.py: build_voxel_csr. */
-int genre_render_spherical_backward_gather(const genre_tensor *vox, const genre_tensor *dirs,
-                                           const genre_tensor *depth_weight, const genre_tensor *grad_out,
-                                           const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
-                                           const genre_tensor *csr_rows, const genre_tensor *csr_entries,
-                                           const genre_tensor *csr_shared, const genre_tensor *v_scratch,
-                                           const genre_tensor *kin, float pre_scale, void *stream);
+ * forward also leaves the anchors the backward below needs.  Results agree with the standard layout to
+ * fp32 rounding (the scan order differs), not bit for bit. */
+
+/* Backward of the fused renderer for that layout: a reverse scan writes dL/dp [ray*ZR + k][image] into dp_scratch
+ * (>= rays*ZR floats; v_scratch must be the forward's buffer with its anchors), then a wave owns a 4^3-voxel sub-brick, keeps
+ * its gradients for 32 images in LDS (lanes = images, so no atomics) and walks the samples that touch it:
+ *   sub_rows : int32 [rows,4] = (sub-brick (sx*nsy + sy)*nsz + sz, begin, end, shared); every sub-brick present,
+ *              split rows (shared = 1) flush with float atomics onto voxels zeroed by a pre-pass
+ *   sub_list : int32 [S] = (ray << 8) | k, per sub-brick sorted by (ray, k)
+ * Builder: genre-shapehd_amd/toolbox/_fused_render.py: build_subbrick_table. */
+int genre_render_spherical_backward_bm(const genre_tensor *vox, const genre_tensor *dirs,
+                                       const genre_tensor *depth_weight, const genre_tensor *grad_out,
+                                       const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
+                                       const genre_tensor *sub_rows, const genre_tensor *sub_list,
+                                       const genre_tensor *v_scratch, const genre_tensor *kin, float pre_scale,
+                                       void *stream);
 
 #ifdef __cplusplus
 }
