@@ -8,32 +8,35 @@
 // forward here reads the 128^3 volume (8 MiB, L2/MALL resident) and writes the [R,R] map:
 // algorithmic traffic 8.45 MB per image.
 //
-// FORWARD  one wave renders one ray.  Lane l owns samples 4l..4l+3 (0.5 voxel apart, so a
-//   lane's taps and its neighbours' overlap in L1); the exclusive product scan of (1-p) and the
-//   depth expectation run in fp64 registers + 6 cross-lane steps, exactly like calc_prob.hip.
-//   Sample positions are regenerated in fp64 from the per-ray unit direction --
-//   grid[i,j,k] = float((2*dir_ij) * (1 - alpha_k)), the reference's own float64 expression
-//   (spherical_proj.py:50-56) -- bit-identical to its 48 MiB `grid` buffer without reading it.
-//   Trilinear taps follow ATen's grid_sampler_3d arithmetic (what PyTorch runs for the
-//   reference); samples with no corner inside the volume (about half of them) skip all loads.
+// Sample positions are regenerated in fp64 from the per-ray unit direction --
+// grid[i,j,k] = float((2*dir_ij) * (1 - alpha_k)), the reference's own float64 expression
+// (spherical_proj.py:50-56) -- bit-identical to its 48 MiB `grid` buffer without reading it.  Trilinear taps follow
+// ATen's grid_sampler_3d arithmetic (what PyTorch runs for the reference).  Which samples touch which 16^3 voxel
+// BRICK depends only on the geometry, so it comes from lists built once on the host (toolbox/_fused_render.py).
 //
-// BACKWARD two passes, no global atomics:
-//   A  (wave per ray) recomputes the ray, forms
+// FORWARD (brick path)  render_sample_brick_group_kernel: a workgroup stages the 18^3 tiles of one or two images in
+//   LDS and evaluates the brick's listed samples (one lane per sample, 8 LDS reads each), writing the raw values
+//   v[ray,k]; render_scan_fwd_kernel: a wave per ray, lane l owns samples 4l..4l+3, exclusive product scan of
+//   (1-p) and depth expectation in fp64 registers + 6 DPP steps (wave_scan.hpp), optional sph_pad fan-out.
+//
+// BACKWARD (brick path), no global atomics:
+//   A  render_scan_bwd_kernel (wave per ray) re-reads v and forms
 //        dL/dp_k = g * ( T_k w_k - (sum_{j>k} s_j w_j + prod_all(1-p)) / (1 - p_k) ),
-//      masks it with torch.clamp's rule (pass where lo <= v <= hi) and writes it to a
-//      [rays, ZR] scratch with one coalesced float4 per lane.
-//   B  (workgroup per 16^3 voxel BRICK) accumulates the trilinear adjoint of every sample that
-//      touches the brick into a 32 KiB LDS tile and writes each voxel of grad_vox exactly once
-//      with plain stores.  The tile is 64-bit FIXED POINT (ds_add_u64): measured on gfx950
-//      ds_add_f32 sustains 0.33 lane-ops/clk/CU, ds_add_u64 6-10 (tools/lds_atomic_bench.hip).
-//      The scale is 2^(44-e) with 2^e >= max|dL/dp| (found by pass A), leaving 18 bits of headroom
-//      for the up-to-2^17 contributions a central voxel receives: 44 bits below the largest term --
-//      finer than fp32 accumulation, and order-independent (deterministic).  Which samples touch which brick depends only
-//      on the geometry, so it comes from a precomputed list (built once on the host, see
-//      toolbox/_fused_render.py); bricks are scheduled heaviest first.
-//   The first version scattered dL/dp with 8 global fp32 atomics per sample: 1.3 ms/image,
-//   95 % of it atomic throughput (all 16 384 rays converge on the central voxels).  It is kept
-//   as the fallback when no brick tables are passed.
+//      masked with torch.clamp's rule (pass where lo <= v <= hi), into a [rays, ZR] scratch, plus max|dL/dp|.
+//   B  render_bwd_brick_kernel (workgroup per brick row) accumulates the trilinear adjoint of every listed sample
+//      into a 32 KiB LDS tile and writes each voxel of grad_vox exactly once with plain stores.  The tile is 64-bit
+//      FIXED POINT (ds_add_u64): measured on gfx950 ds_add_f32 sustains 0.33 lane-ops/clk/CU, ds_add_u64 6-10
+//      (tools/lds_atomic_bench.hip).  The scale is 2^(44-e) with 2^e >= max|dL/dp|, leaving 18 bits of headroom for the
+//      up-to-2^17 contributions a central voxel receives: 44 bits below the largest term -- finer than fp32
+//      accumulation, and order-independent (deterministic).  Bricks are scheduled heaviest first; the eight central
+//      ones are split over several rows (atomic flush onto pre-zeroed voxels).
+//
+// BATCH-MINOR volumes (image index fastest in memory) take a third set of kernels in which a half-wave is 32 images
+//   of one sample / one ray (see "batch-minor path" below): the fastest forward, a slower backward.
+//
+// FALLBACKS without the tables: render_fwd_kernel / render_bwd_dp_kernel (a wave renders one ray with gathers from
+//   global memory) and render_bwd_atomic_kernel (8 global fp32 atomics per sample: 1.3 ms/image, 95 % of it atomic
+//   throughput -- all 16 384 rays converge on the central voxels).
 #include "common.hpp"
 #include <cstdlib>
 #include "wave_scan.hpp"
