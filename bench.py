@@ -356,6 +356,7 @@ def main():
     def fence():
         dist_utils.fence(dist, torch.cuda.synchronize)
 
+    step()                                  # set-up pass: builds the geometry tables (host, ~2 s); never timed
     for _ in range(args.warmup):
         step()
     fence()
