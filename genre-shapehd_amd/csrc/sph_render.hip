@@ -491,7 +491,7 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
 #pragma unroll
             for (int i = 0; i < 8; i++) w[i] = corner_w(c, i);
             const float *tp = gtile + ((c.x0 - ox) * kTile + (c.y0 - oy)) * kTile + (c.z0 - oz);
-            float *__restrict__ vq = v0 + (int64_t)q * D.ZR + k;
+            float *__restrict__ vq = v0 + ((unsigned)q * (unsigned)D.ZR + (unsigned)k);
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 if (g >= ng) break;
@@ -1086,7 +1086,8 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
         for (int u = 0; u < 4; u++) {
             const bool ok = ent[u] != 0xffffffffu;
             const int q = ok ? (int)(ent[u] >> 8) : 0;
-            dp[u] = ok ? dpi[(int64_t)q * D.ZR + (ent[u] & 255u)] : 0.f;
+            // one image's samples fit 32 bits (R*R < 2^24, ZR <= 256): unsigned index from the image's base
+            dp[u] = ok ? dpi[(unsigned)q * (unsigned)D.ZR + (ent[u] & 255u)] : 0.f;
             d2[u][0] = dirs[q * 3 + 0]; d2[u][1] = dirs[q * 3 + 1]; d2[u][2] = dirs[q * 3 + 2];
         }
 #pragma unroll
