@@ -11,24 +11,31 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .._ext import calc_prob_lib
+from .._ext import calc_prob_lib as _native
+
+
+def _require_ray_volume(p):
+    # same three requirements the reference asserts (:12-14): [N, C, X, Y, Z] fp32 on the GPU
+    if p.dim() != 5 or p.dtype != torch.float32 or not p.is_cuda:
+        raise AssertionError("CalcStopProb expects a 5-D float32 GPU tensor, got %s %s on %s"
+                             % (tuple(p.shape), p.dtype, p.device))
 
 
 class CalcStopProb(Function):
+    """stop probability along the last (ray sample) dimension; differentiable once"""
+
     @staticmethod
     def forward(ctx, prob_in):
-        assert prob_in.dim() == 5
-        assert prob_in.dtype == torch.float32
-        assert prob_in.is_cuda
-        stop_prob = torch.empty_like(prob_in)
-        calc_prob_lib.calc_prob_forward(prob_in, stop_prob)
-        ctx.save_for_backward(prob_in, stop_prob)
-        return stop_prob
+        _require_ray_volume(prob_in)
+        stop = torch.empty_like(prob_in)
+        _native.calc_prob_forward(prob_in, stop)
+        ctx.save_for_backward(prob_in, stop)
+        return stop
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_in):
-        prob_in, stop_prob = ctx.saved_tensors
-        grad_out = torch.empty_like(prob_in)
-        calc_prob_lib.calc_prob_backward_fused(prob_in, stop_prob, grad_in, grad_out)
-        return grad_out
+    def backward(ctx, grad_stop):
+        p, stop = ctx.saved_tensors
+        grad_p = torch.empty_like(p)
+        _native.calc_prob_backward_fused(p, stop, grad_stop, grad_p)      # (stop * grad_stop) formed in the kernel
+        return grad_p

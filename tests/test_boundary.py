@@ -120,6 +120,9 @@ def test_reference_import_lines_work_unchanged(genre):
         "from toolbox.spherical_proj import render_spherical, sph_pad, gen_sph_grid\n"
         "from nndistance.modules.nnd import NNDModule\n"
         "from nndistance.functions.nnd import nndistance, nndistance_w_idx, nndistance_score\n"
+        "from nndistance.functions import nndistance as n2, nndistance_w_idx as n3, nndistance_score as n4\n"
+        "from toolbox.calc_prob.calc_prob.functions import CalcStopProb as c2\n"
+        "assert n2 is nndistance and c2 is CalcStopProb\n"
         "r = render_spherical()\n"
         "assert tuple(r.grid.shape) == (128, 128, 256, 3) and tuple(r.depth_weight.shape) == (256,)\n"
         "assert sorted(r.state_dict()) == ['depth_weight', 'grid']\n"
