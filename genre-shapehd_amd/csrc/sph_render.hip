@@ -1127,18 +1127,29 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
     const int n = img / D.NC, cc = img % D.NC;
     float *gbase = gvox.p + n * gvox.s0 + cc * gvox.s1;
     const float *vbase = vox.p + n * vox.s0 + cc * vox.s1;
-    for (int t = threadIdx.x; t < kBrick * kBrick * kBrick; t += kBlock) {
-        const int lz = t % kBrick, ly = (t / kBrick) % kBrick, lx = t / (kBrick * kBrick);
-        const int x = ox + lx, y = oy + ly, z = oz + lz;
-        if (x < D.X && y < D.Y && z < D.Z) {
+    // flush.  Element t = thread + 256 i is voxel (lx = i, ly = thread / 16, lz = thread % 16): the clamp-mask values of
+    // all 16 are requested before the first one is used (one exposed round trip instead of 16)
+    constexpr int kPerT = kBrick * kBrick * kBrick / kBlock;
+    const int ly = (int)threadIdx.x / kBrick, lz = (int)threadIdx.x % kBrick;
+    const int y = oy + ly, z = oz + lz;
+    const bool col_in = y < D.Y && z < D.Z;
+    float tvs[kPerT];
+#pragma unroll
+    for (int i = 0; i < kPerT; i++) {
+        tvs[i] = 0.f;
+        if (D.pre_scale != 0.0f && col_in && ox + i < D.X) tvs[i] = vbase[(ox + i) * D.sx + y * D.sy + z * D.sz] * D.pre_scale;
+    }
+#pragma unroll
+    for (int i = 0; i < kPerT; i++) {
+        const int x = ox + i;
+        if (col_in && x < D.X) {
+            const unsigned long long acc = tile[threadIdx.x + i * kBlock];
             float *dst = gbase + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
-            float val = (float)((double)(long long)tile[t] * inv_scale);
-            if (D.pre_scale != 0.0f) {                       // adjoint of clamp(x * pre_scale, lo, hi)
-                const float tv = vbase[x * D.sx + y * D.sy + z * D.sz] * D.pre_scale;
-                val = (tv >= D.lo && tv <= D.hi) ? val * D.pre_scale : 0.0f;
-            }
+            float val = (float)((double)(long long)acc * inv_scale);
+            if (D.pre_scale != 0.0f)                         // adjoint of clamp(x * pre_scale, lo, hi)
+                val = (tvs[i] >= D.lo && tvs[i] <= D.hi) ? val * D.pre_scale : 0.0f;
             if (!shared) *dst = val;
-            else if (tile[t] != 0ull) unsafeAtomicAdd(dst, val);
+            else if (acc != 0ull) unsafeAtomicAdd(dst, val);
         }
     }
 }
