@@ -466,21 +466,22 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
     __syncthreads();
     const int64_t img_stride = (int64_t)D.R * D.R * D.ZR;
     float *__restrict__ v0 = vbuf + (int64_t)img0 * img_stride;
-    for (int e0 = begin + threadIdx.x; e0 < end; e0 += 2 * NT) {
-        unsigned ent[2];
-        double d2[2][3];
+    constexpr int kFwdInFlight = 2;
+    for (int e0 = begin + threadIdx.x; e0 < end; e0 += kFwdInFlight * NT) {
+        unsigned ent[kFwdInFlight];
+        double d2[kFwdInFlight][3];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < kFwdInFlight; u++) {
             const int e = e0 + u * NT;
             ent[u] = (unsigned)fwd_list[e < end ? e : e0];
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < kFwdInFlight; u++) {
             const int q = (int)(ent[u] >> 8);
             d2[u][0] = dirs[q * 3 + 0]; d2[u][1] = dirs[q * 3 + 1]; d2[u][2] = dirs[q * 3 + 2];
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < kFwdInFlight; u++) {
             if (e0 + u * NT >= end) break;
             const int q = (int)(ent[u] >> 8), k = (int)(ent[u] & 255u);
             float gx, gy, gz;
@@ -1071,19 +1072,21 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
     for (int t = threadIdx.x; t < kBrick * kBrick * kBrick; t += kBlock) tile[t] = 0ull;
     __syncthreads();
     const float *__restrict__ dpi = dpbuf + (int64_t)img * D.R * D.R * D.ZR;
-    // One lane per listed sample, four samples per thread in flight: list words first (coalesced), then the
-    // dependent dL/dp loads of all four (64-byte runs: entries are sorted by ray, then sample), then the work.
-    for (int e0 = begin + threadIdx.x; e0 < end; e0 += 4 * kBlock) {
-        unsigned ent[4];
-        float dp[4];
+    // One lane per listed sample, eight samples per thread in flight (4: +15 us, 16: +100 us): list words first
+    // (coalesced), then the dependent dL/dp loads of all of them (64-byte runs: entries are sorted by ray, then
+    // sample), then the work.
+    constexpr int kInFlight = 8;
+    for (int e0 = begin + threadIdx.x; e0 < end; e0 += kInFlight * kBlock) {
+        unsigned ent[kInFlight];
+        float dp[kInFlight];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kInFlight; u++) {
             const int e = e0 + u * kBlock;
             ent[u] = e < end ? (unsigned)chunk_list[e] : 0xffffffffu;
         }
-        double d2[4][3];
+        double d2[kInFlight][3];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kInFlight; u++) {
             const bool ok = ent[u] != 0xffffffffu;
             const int q = ok ? (int)(ent[u] >> 8) : 0;
             // one image's samples fit 32 bits (R*R < 2^24, ZR <= 256): unsigned index from the image's base
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
             d2[u][0] = dirs[q * 3 + 0]; d2[u][1] = dirs[q * 3 + 1]; d2[u][2] = dirs[q * 3 + 2];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kInFlight; u++) {
             if (dp[u] == 0.0f) continue;
             const int k = (int)(ent[u] & 255u);
             float gx, gy, gz;
