@@ -372,7 +372,8 @@ def main():
     if rank == 0:
         rows = kernel_table(G, dev, B)
         # dominant hand-written kernel of the step = the one moving the most algorithmic bytes
-        in_step = [k for k in rows if not (fused and k.startswith("calc_prob")) and k != "nnd_fwd" and not k.startswith("chain_")]
+        # kernel groups that are part of the timed step in this mode (the fused renderer replaces calc_prob's kernels)
+        in_step = [k for k in rows if k == "cam_bp_fwd" or k.startswith("render_" if fused else "calc_prob")]
         dom_name = max(in_step, key=lambda k: rows[k]["us"])
         dom = rows[dom_name]
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately and corrected as
