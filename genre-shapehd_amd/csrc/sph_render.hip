@@ -80,10 +80,17 @@ __device__ __forceinline__ void store_map(const RenderDims &D, float *oimg, cons
         if (lane == 0) oimg[i * out.s2 + j * out.s3] = v;
         return;
     }
+    if (i > 0 && i < D.R - 1 && j >= D.pad && j < D.R - D.pad) {      // three quarters of the map: a single position
+        if (lane == 0) oimg[(i + D.pad) * out.s2 + (j + D.pad) * out.s3] = v;
+        return;
+    }
     int r_lo, r_n, c0, c1;
     pad_span(D.R, D.pad, i, j, r_lo, r_n, c0, c1);
     const int cnt = r_n * (c1 >= 0 ? 2 : 1);
-    for (int t = lane; t < cnt; t += 64) oimg[(r_lo + t % r_n) * out.s2 + (t < r_n ? c0 : c1) * out.s3] = v;
+    for (int t = lane; t < cnt; t += 64) {
+        const int second = t >= r_n;
+        oimg[(r_lo + (second ? t - r_n : t)) * out.s2 + (second ? c1 : c0) * out.s3] = v;
+    }
 }
 
 // gradient of one ray's value: sum over its padded positions
