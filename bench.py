@@ -126,7 +126,7 @@ def kernel_table(G, dev, B):
         gvox = torch.empty_like(vox)
         T = _fused_render.tables_for(vox.shape, dev, mod._dirs64, mod.z_res)
         vbuf = torch.empty((B * 128 * 128 * mod.z_res,), device=dev)
-        scratch = torch.empty((vbuf.numel() + 4,), device=dev)
+        scratch = torch.empty((vbuf.numel() + max(4, B),), device=dev)
         proj = 1 - 128 * tdf
         t = event_time_us(lambda: render_lib.render_spherical_forward(
             proj, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0), iters, 5)

@@ -38,7 +38,9 @@ def _load():
     if lib.genre_abi_version() != ABI_VERSION:
         raise ImportError("libgenre_hip.so ABI %d != expected %d -- rebuild" % (lib.genre_abi_version(), ABI_VERSION))
     T, V = C.POINTER(GenreTensor), C.c_void_p
-    scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float]}
+    scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float],
+               "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float],
+               "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float]}
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
                         ("genre_get_surface_mask", 5), ("genre_back_projection_forward_shifted", 5),
                         ("genre_back_projection_backward_shifted", 8), ("genre_spherical_back_proj_forward", 4),
@@ -46,10 +48,12 @@ def _load():
                         ("genre_spherical_back_proj_backward_shifted", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
-                        ("genre_render_spherical_forward", 8), ("genre_render_spherical_backward", 10)):
+                        ("genre_render_spherical_forward", 8), ("genre_render_spherical_backward", 10),
+                        ("genre_render_bm_forward", 11), ("genre_render_bm_backward", 14),
+                        ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4)):
         fn = getattr(lib, name, None)
         if fn is None:
-            continue
+            raise ImportError("libgenre_hip.so does not export %s -- rebuild (make -C genre-shapehd_amd/csrc)" % name)
         fn.argtypes = [T] * nargs + scalars.get(name, []) + [V]
         fn.restype = C.c_int
     return lib
@@ -190,11 +194,19 @@ class _RenderLib:
 
 
     @staticmethod
-    def render_spherical_backward_bm(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox, dp_scratch, sub_rows,
-                                     sub_list, v_scratch, kin, pre_scale=0.0):
-        """backward for batch-minor volumes: reverse scan + sub-brick-owned accumulation (build_subbrick_table)"""
-        return _call("genre_render_spherical_backward_bm", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                     dp_scratch, sub_rows, sub_list, v_scratch, kin, scalars=(C.c_float(pre_scale),))
+    def render_bm_forward(vox, out, segs, rec_f, fwd_rows, ray_ptr, ray_seg, ray_pre_as_f32, ps_scratch,
+                          p_stash=None, mask=None, pre_scale=0.0):
+        """batch-minor tile renderer (csrc/sph_render_bm.hip; tables: toolbox/_bm_tables.py).  p_stash (and mask when
+        pre_scale != 0) given: the state the backward needs is saved"""
+        return _call("genre_render_bm_forward", vox, out, segs, rec_f, fwd_rows, ray_ptr, ray_seg, ray_pre_as_f32,
+                     ps_scratch, p_stash, mask, scalars=(C.c_float(pre_scale),))
+
+    @staticmethod
+    def render_bm_backward(grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, ent, rec_b, bwd_rows,
+                           depth_weight, ps_scratch, tr_scratch, p_stash, mask=None, pre_scale=0.0):
+        return _call("genre_render_bm_backward", grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, ent,
+                     rec_b, bwd_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask,
+                     scalars=(C.c_float(pre_scale),))
 
 
 class _GlueLib:

@@ -31,8 +31,7 @@
 //      accumulation, and order-independent (deterministic).  Bricks are scheduled heaviest first; the eight central
 //      ones are split over several rows (atomic flush onto pre-zeroed voxels).
 //
-// BATCH-MINOR volumes (image index fastest in memory) take a third set of kernels in which a half-wave is 32 images
-//   of one sample / one ray (see "batch-minor path" below): the fastest forward, a slower backward.
+// BATCH-MINOR volumes (image index fastest in memory, batches of >= 16) have their own renderer: sph_render_bm.hip.
 //
 // FALLBACKS without the tables: render_fwd_kernel / render_bwd_dp_kernel (a wave renders one ray with gathers from
 //   global memory) and render_bwd_atomic_kernel (8 global fp32 atomics per sample: 1.3 ms/image, 95 % of it atomic
@@ -339,17 +338,22 @@ __device__ __forceinline__ void lane_dp(const RenderDims &D, const float *__rest
     dp4(D, p, pass, dw, g, lane, dp);
 }
 
-// publish a wave's max |dL/dp| (bit pattern of a non-negative float orders like the value).  One
-// same-address global atomic costs ~10 ns, so publish only when it would raise the maximum (the
-// racy pre-read is safe -- the value only grows).
-__device__ __forceinline__ void publish_max(float wmax, int lane, unsigned *dpmax_bits)
+// A wave's max |dL/dp| as a bit pattern: patterns of non-negative floats order like their values, and Inf / NaN
+// patterns sort above every finite one, so a non-finite gradient survives the maximum (the brick kernel then writes
+// NaN for that image instead of pushing garbage through the fixed-point conversion).  One same-address global atomic
+// costs ~10 ns, so publish only when it would raise the maximum (the racy pre-read is safe -- the value only grows).
+__device__ __forceinline__ unsigned abs_bits4(const float (&dp)[4])
+{
+    const unsigned a = __float_as_uint(dp[0]) & 0x7fffffffu, b = __float_as_uint(dp[1]) & 0x7fffffffu;
+    const unsigned c = __float_as_uint(dp[2]) & 0x7fffffffu, d = __float_as_uint(dp[3]) & 0x7fffffffu;
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ void publish_max(unsigned wmax, int lane, unsigned *dpmax_bits)
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-    if (lane == 0 && wmax > 0.f && isfinite(wmax)) {
-        const unsigned bits = __float_as_uint(wmax);
-        if (bits > __hip_atomic_load(dpmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dpmax_bits, bits);
-    }
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o, 64));
+    if (lane == 0 && wmax > 0u &&
+        wmax > __hip_atomic_load(dpmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dpmax_bits, wmax);
 }
 
 __device__ __forceinline__ void store_dp(const RenderDims &D, float *dst, int lane, const float (&dp)[4])
@@ -376,10 +380,15 @@ __global__ __launch_bounds__(kBlock) void render_bwd_dp_kernel(RenderDims D, Vie
     const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
     const int64_t rays = (int64_t)D.N * D.NC * D.R * D.R;
-    float wmax = 0.f;
+    unsigned wmax = 0u;
+    int64_t cur = -1;                                                    // image the running maximum belongs to
     for (int64_t r = wave0; r < rays; r += nwaves) {
         int64_t n; int c, q;
         ray_decode(D, r, n, c, q);
+        if (n * D.NC + c != cur) {
+            if (cur >= 0) publish_max(wmax, lane, dpmax_bits + cur);
+            cur = n * D.NC + c; wmax = 0u;
+        }
         const int i = q / D.R, j = q % D.R;
         const float g = gout.p[n * gout.s0 + c * gout.s1 + i * gout.s2 + j * gout.s3];
         float dp[4] = {0.f, 0.f, 0.f, 0.f};
@@ -387,10 +396,10 @@ __global__ __launch_bounds__(kBlock) void render_bwd_dp_kernel(RenderDims D, Vie
             const float *__restrict__ base = vox.p + n * vox.s0 + c * vox.s1;
             lane_dp(D, base, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, dw, g, lane, row, dp);
         }
-        wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
+        wmax = max(wmax, abs_bits4(dp));
         store_dp(D, dpbuf + r * D.ZR + lane * 4, lane, dp);
     }
-    publish_max(wmax, lane, dpmax_bits);
+    if (cur >= 0) publish_max(wmax, lane, dpmax_bits + cur);
 }
 
 // ---- brick path, forward: LDS-staged voxel tiles ----------------------------------------------------
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
     const float *__restrict__ vimg = vbuf + (int64_t)img * rr * D.ZR;
     float *__restrict__ dimg = dpbuf + (int64_t)img * rr * D.ZR;
     const float *gimg = gout.p + (img / D.NC) * gout.s0 + (img % D.NC) * gout.s1;
-    float wmax = 0.f;
+    unsigned wmax = 0u;
     double w4[4];
     load_w4(D, dw, kb, w4);
     for (int qbase = w0; qbase < rr; qbase += 64 * nw) {
@@ -621,424 +630,18 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
             bool pass[4];
             dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
             if (ga != 0.0f) { clamp4(D, va, kb, p, pass); dp4w(p, pass, w4, ga, dp); }
-            wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
+            wmax = max(wmax, abs_bits4(dp));
             // samples before kin lie outside the volume: no brick list names them, so their dL/dp is never read
             if (kb + 3 >= kin_a) store_dp(D, dimg + (int64_t)q * D.ZR + kb, lane, dp);
             if (hasb) {
                 dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
                 if (gb != 0.0f) { clamp4(D, vb, kb, p, pass); dp4w(p, pass, w4, gb, dp); }
-                wmax = fmaxf(wmax, fmaxf(fmaxf(fabsf(dp[0]), fabsf(dp[1])), fmaxf(fabsf(dp[2]), fabsf(dp[3]))));
+                wmax = max(wmax, abs_bits4(dp));
                 if (kb + 3 >= kin_b) store_dp(D, dimg + (int64_t)qb * D.ZR + kb, lane, dp);
             }
         }
     }
-    publish_max(wmax, lane, dpmax_bits);
-}
-
-// ==== batch-minor path =================================================================================
-// When the volume is laid out with the IMAGE index fastest in memory (stride[0] == 1: element (n,x,y,z) at
-// ((x*Y + y)*Z + z)*N + n -- any [N,1,X,Y,Z] tensor with such strides, e.g. what Camera_back_projection_layer
-// allocates with batch_minor=True), the 32 lanes of a half-wave can be 32 IMAGES of one sample:
-//   * a trilinear corner is one 128-byte line for all 32 images -- no LDS tiles, no staging, full-line v stores;
-//   * the geometry of a sample is computed once per 32 images (by one lane, handed over through LDS);
-//   * the per-ray scans need no cross-lane operation at all: a lane walks ITS ray's 256 samples serially
-//     (~10 instructions per sample per 64 image-rays instead of ~110 per ray for the DPP tree scans);
-//   * the backward accumulates per 4^3 sub-brick in LDS with lanes = images: no atomics, a fixed summation order
-//     (lists by toolbox/_fused_render.py: build_subbrick_table).
-// Scratch layouts here: v[(q*ZR + k)*N + n], dL/dp likewise.
-constexpr int kBmLanes = 32;                        // images per half-wave
-constexpr int kBmRec = 12;                          // LDS record per sample: offset, mask, entry, pad, 8 weights (3 x b128)
-
-template <bool PS>
-__global__ __launch_bounds__(kBlock) void render_sample_bm_kernel(RenderDims D, View5 vox,
-                                                                   const double *__restrict__ dirs,
-                                                                   const int *__restrict__ fwd_list, int n_entries,
-                                                                   float *__restrict__ vbm)
-{
-    __shared__ __attribute__((aligned(16))) int rec[kWavesPerBlock][64 * kBmRec];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin, and the list is sorted by brick, so XCD x
-    // takes the x-th CONTIGUOUS eighth of the list -- the voxel lines its waves share then meet in ITS L2
-    // (with the plain order every XCD streamed the whole volume through its own L2: 50 % L2 misses)
-    const int per_xcd = (gridDim.x + 7) >> 3;
-    const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int chunk = blk * kWavesPerBlock + wv;
-    const int e0 = chunk * 64;
-    if (e0 >= n_entries) return;
-    int *my = rec[wv];
-    bool chunk_fast;
-    {   // phase A: lane l works out the geometry of entry e0 + l
-        const int e = e0 + lane;
-        unsigned ent = 0xffffffffu;
-        int off = 0, mask = 0;
-        float w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (e < n_entries) {
-            ent = (unsigned)fwd_list[e];
-            const int q = (int)(ent >> 8), k = (int)(ent & 255u);
-            float gx, gy, gz;
-            sample_pos(D, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, k, gx, gy, gz);
-            Cell c;
-            locate(D, gx, gy, gz, c);
-            off = c.x0 * D.sx + c.y0 * D.sy + c.z0 * D.sz;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int x = c.x0 + (i & 1), y = c.y0 + ((i >> 1) & 1), z = c.z0 + ((i >> 2) & 1);
-                if (x >= 0 && x < D.X && y >= 0 && y < D.Y && z >= 0 && z < D.Z) mask |= 1 << i;
-                w[i] = corner_w(c, i);
-            }
-        }
-        chunk_fast = __builtin_amdgcn_ballot_w64(mask == 0xff) == ~0ull;   // 64 interior samples: the pipelined loop
-        int4 *dst = reinterpret_cast<int4 *>(my + lane * kBmRec);
-        dst[0] = make_int4(off, mask, (int)ent, 0);
-        dst[1] = make_int4(__float_as_int(w[0]), __float_as_int(w[1]), __float_as_int(w[2]), __float_as_int(w[3]));
-        dst[2] = make_int4(__float_as_int(w[4]), __float_as_int(w[5]), __float_as_int(w[6]), __float_as_int(w[7]));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // LDS of one wave is processed in issue order
-    // phase B: half-wave h evaluates entry s + h for 32 images at a time.  Interior samples (all eight corners
-    // inside the volume -- nearly all of them) take a branch-free path chosen per wave: 32-bit offsets from the
-    // uniform base pointer, clamp as multiply + median, one fma per corner (the reference's CUDA build contracts
-    // `out += val * weight` too).
-    const int half = lane >> 5, li = lane & 31;
-    const int imgs = D.N * D.NC;
-    const int coff[8] = {0, D.sx, D.sy, D.sx + D.sy, D.sz, D.sx + D.sz, D.sy + D.sz, D.sx + D.sy + D.sz};
-    // byte offsets from the uniform base as 32-bit unsigned values (the host checks the volume spans < 4 GiB): the
-    // loads then take the SGPR-base + VGPR-offset form, one v_add_u32 per corner instead of a 64-bit address
-    const char *__restrict__ vbytes = reinterpret_cast<const char *>(vox.p);
-    for (int g0 = 0; g0 < imgs; g0 += kBmLanes) {
-        const int img = g0 + li;
-        const bool img_on = img < imgs;
-        const int ioff = img_on ? (img / D.NC) * (int)vox.s0 + (img % D.NC) * (int)vox.s1 : 0;     // once per 32 entries
-        if (chunk_fast) {
-            // all 64 samples interior: software-pipelined -- the eight lines of the NEXT sample are requested before
-            // the current one is evaluated (a wave is otherwise one exposed L2 round trip per sample: the kernel
-            // ran at 56 % VALU, latency-bound at full occupancy)
-            int4 h0 = reinterpret_cast<const int4 *>(my + half * kBmRec)[0];
-            float tv[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                tv[i] = *reinterpret_cast<const float *>(vbytes + (((unsigned)(ioff + h0.x) + (unsigned)coff[i]) << 2));
-            for (int s0 = 0; s0 < 64; s0 += 2) {
-                const int4 *r = reinterpret_cast<const int4 *>(my + (s0 + half) * kBmRec);
-                const int4 w03 = r[1], w47 = r[2];
-                const unsigned ent = (unsigned)h0.z;
-                float cur[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) cur[i] = tv[i];
-                if (s0 + 2 < 64) {
-                    h0 = reinterpret_cast<const int4 *>(my + (s0 + 2 + half) * kBmRec)[0];
-#pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        tv[i] = *reinterpret_cast<const float *>(vbytes + (((unsigned)(ioff + h0.x) + (unsigned)coff[i]) << 2));
-                }
-                const float w[8] = {__int_as_float(w03.x), __int_as_float(w03.y), __int_as_float(w03.z), __int_as_float(w03.w),
-                                    __int_as_float(w47.x), __int_as_float(w47.y), __int_as_float(w47.z), __int_as_float(w47.w)};
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float t = PS ? __builtin_amdgcn_fmed3f(cur[i] * D.pre_scale, D.lo, D.hi) : cur[i];
-                    acc = __builtin_fmaf(t, w[i], acc);
-                }
-                if (img_on) vbm[(unsigned)(((ent >> 8) * (unsigned)D.ZR + (ent & 255u)) * (unsigned)imgs + (unsigned)img)] = acc;
-            }
-            continue;
-        }
-        for (int s0 = 0; s0 < 64; s0 += 2) {
-            const int4 *r = reinterpret_cast<const int4 *>(my + (s0 + half) * kBmRec);
-            const int4 h0 = r[0], w03 = r[1], w47 = r[2];
-            const unsigned ent = (unsigned)h0.z;
-            const int off = h0.x, mask = h0.y;
-            const float w[8] = {__int_as_float(w03.x), __int_as_float(w03.y), __int_as_float(w03.z), __int_as_float(w03.w),
-                                __int_as_float(w47.x), __int_as_float(w47.y), __int_as_float(w47.z), __int_as_float(w47.w)};
-            const bool valid = ent != 0xffffffffu;
-            const bool fast = __builtin_amdgcn_ballot_w64(!valid || mask != 0xff) == 0ull;      // wave-uniform
-            const bool on = valid && img_on;
-            const int idx = on ? ioff + off : 0;
-            float acc = 0.f;                                          // ATen corner order
-            if (fast) {
-                float tv[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++)                           // eight lines requested together
-                    tv[i] = *reinterpret_cast<const float *>(vbytes + (((unsigned)idx + (on ? (unsigned)coff[i] : 0u)) << 2));
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float t = PS ? __builtin_amdgcn_fmed3f(tv[i] * D.pre_scale, D.lo, D.hi) : tv[i];
-                    acc = __builtin_fmaf(t, w[i], acc);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (on && (mask & (1 << i))) {                    // zeros outside the volume stay zeros
-                        float t = vox.p[idx + coff[i]];
-                        if (PS) t = __builtin_amdgcn_fmed3f(t * D.pre_scale, D.lo, D.hi);
-                        acc = __builtin_fmaf(t, w[i], acc);
-                    }
-                }
-            }
-            // v index fits 32 bits (host-checked): (ray * ZR + k) * images + image
-            if (on) vbm[(unsigned)(((ent >> 8) * (unsigned)D.ZR + (ent & 255u)) * (unsigned)imgs + (unsigned)img)] = acc;
-        }
-    }
-}
-
-// forward scan, batch-minor: one lane = one (ray, image); serial over the samples in fp64
-// Anchor of the backward scan, 16 bytes per (ray, image): the transmittance T (double) before sample k_f (int), where
-// k_f = ZR when the product never dropped below 1e-290 (then T = prod(1-p)), else the first sample before which it did:
-// behind k_f every dL/dp term is below fp32 resolution, in front of it T_k is recovered by dividing back from the anchor.
-struct BmAnchor { double T; int kf; int pad; };
-
-__global__ __launch_bounds__(kBlock) void render_scan_fwd_bm_kernel(RenderDims D, const float *__restrict__ vbm,
-                                                                     const int *__restrict__ kin,
-                                                                     const float *__restrict__ dw, View4 out,
-                                                                     BmAnchor *__restrict__ anchor)
-{
-    const int imgs = D.N * D.NC, rr = D.R * D.R;
-    const int ipad = (imgs + kBmLanes - 1) / kBmLanes * kBmLanes;      // lanes per ray, multiple of 32
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int q = (int)(t / ipad), img = (int)(t % ipad);
-    if (q >= rr || img >= imgs) return;
-    const int k_in = kin[q];
-    const double lo = (double)D.lo;
-    double T = 1.0, acc = 0.0, Tf = 0.0;
-    int kf = D.ZR;
-    for (int k = 0; k < k_in && k < D.ZR; k++) {                       // outside the volume: v = 0 -> p = lo
-        acc += (lo * T) * (double)dw[k];
-        T *= 1.0 - lo;
-    }
-    const float *__restrict__ vr = vbm + ((int64_t)q * D.ZR) * imgs + img;
-    int k = k_in;
-    for (; k + 8 <= D.ZR; k += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = vr[(int64_t)(k + u) * imgs];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (T < 1e-290 && kf == D.ZR) { kf = k + u; Tf = T; }
-            const double p = (double)fminf(fmaxf(v[u], D.lo), D.hi);  // :66
-            acc += (p * T) * (double)dw[k + u];                       // stop probability x depth weight  (:67-68)
-            T *= 1.0 - p;
-        }
-    }
-    for (; k < D.ZR; k++) {
-        if (T < 1e-290 && kf == D.ZR) { kf = k; Tf = T; }
-        const double p = (double)fminf(fmaxf(vr[(int64_t)k * imgs], D.lo), D.hi);
-        acc += (p * T) * (double)dw[k];
-        T *= 1.0 - p;
-    }
-    if (anchor) {
-        BmAnchor a;
-        a.T = kf == D.ZR ? T : Tf; a.kf = kf; a.pad = 0;
-        anchor[(int64_t)q * imgs + img] = a;
-    }
-    const float total = (float)acc + (float)T;                          // + prod(1-p)  (:69-71), rounded as the tree scan
-    float *oimg = out.p + (img / D.NC) * out.s0 + (img % D.NC) * out.s1;
-    const int i = q / D.R, j = q % D.R;
-    if (D.pad == 0) {
-        oimg[i * out.s2 + j * out.s3] = total;
-    } else {
-        int r_lo, r_n, c0, c1;
-        pad_span(D.R, D.pad, i, j, r_lo, r_n, c0, c1);
-        for (int r = 0; r < r_n; r++) {
-            oimg[(r_lo + r) * out.s2 + c0 * out.s3] = total;
-            if (c1 >= 0) oimg[(r_lo + r) * out.s2 + c1 * out.s3] = total;
-        }
-    }
-}
-
-// backward scan, batch-minor: one lane = one (ray, image), ONE reverse pass over the samples.  T_k (transmittance
-// before sample k) is divided back from the anchor the forward scan left, A_k (the suffix sum of stop probability x
-// depth weight, plus prod(1-p)) is accumulated tail-first; both in fp64.  dL/dp is written for the in-volume samples
-// k_in .. ZR-1, the only ones the gather reads.
-__global__ __launch_bounds__(kBlock) void render_scan_bwd_bm_kernel(RenderDims D, const float *__restrict__ vbm,
-                                                                     const int *__restrict__ kin,
-                                                                     const float *__restrict__ dw, View4 gout,
-                                                                     const BmAnchor *__restrict__ anchor,
-                                                                     float *__restrict__ dpbm)
-{
-    const int imgs = D.N * D.NC, rr = D.R * D.R;
-    const int ipad = (imgs + kBmLanes - 1) / kBmLanes * kBmLanes;
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int q = (int)(t / ipad), img = (int)(t % ipad);
-    if (q >= rr || img >= imgs) return;
-    const int k_in = kin[q];
-    const float g = load_map_grad(D, gout.p + (img / D.NC) * gout.s0 + (img % D.NC) * gout.s1, gout, q);
-    const BmAnchor a = anchor[(int64_t)q * imgs + img];
-    const double gd = (double)g;
-    const int64_t row0 = ((int64_t)q * D.ZR) * imgs + img;
-    const float *__restrict__ vr = vbm + row0;
-    float *__restrict__ dr = dpbm + row0;
-    // behind the anchor (k >= kf) T_k < 1e-290 and so is A_k: dL/dp underflows fp32
-    for (int k = D.ZR - 1; k >= a.kf && k >= k_in; k--) dr[(int64_t)k * imgs] = 0.f;
-    double T = a.T;                                                      // T_{kf}
-    double A = a.kf == D.ZR ? a.T : 0.0;                                 // A_{kf-1}: prod(1-p) if nothing underflowed
-    int k = (a.kf < D.ZR ? a.kf : D.ZR) - 1;
-    for (; k - 3 >= k_in; k -= 4) {
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = vr[(int64_t)(k - u) * imgs];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const bool pass = v[u] >= D.lo && v[u] <= D.hi;             // torch.clamp backward mask
-            const double p = (double)fminf(fmaxf(v[u], D.lo), D.hi);
-            const double qk = 1.0 - p;
-            double r = __builtin_amdgcn_rcp(qk);                         // v_rcp_f64 + one Newton step
-            r = r * (2.0 - qk * r);
-            T *= r;                                                      // T_k = T_{k+1} / (1 - p_k)
-            const double tw = T * (double)dw[k - u];
-            dr[(int64_t)(k - u) * imgs] = pass ? (float)(gd * (tw - A * r)) : 0.f;
-            A += p * tw;                                                 // A_{k-1} = A_k + s_k w_k
-        }
-    }
-    for (; k >= k_in; k--) {
-        const float v = vr[(int64_t)k * imgs];
-        const bool pass = v >= D.lo && v <= D.hi;
-        const double p = (double)fminf(fmaxf(v, D.lo), D.hi);
-        const double qk = 1.0 - p;
-        double r = __builtin_amdgcn_rcp(qk);
-        r = r * (2.0 - qk * r);
-        T *= r;
-        const double tw = T * (double)dw[k];
-        dr[(int64_t)k * imgs] = pass ? (float)(gd * (tw - A * r)) : 0.f;
-        A += p * tw;
-    }
-}
-
-// backward accumulation, batch-minor: a WAVE owns a 4^3-voxel sub-brick and keeps its gradients for 32 images in
-// 8 KB of LDS as plain fp32 [voxel][image].  Lanes are images, so the lanes of an instruction never touch the same
-// word; the two half-waves take the z0 and the z0+1 corner plane of the same sample -- different voxels -- and a wave
-// walks its list (sub_rows / sub_list: every sample with a corner in the sub-brick) in order: no atomics, a fixed
-// summation order.  Measured at batch 32: 1.1 ms -- slower than the 0.76 ms of the standard layout's brick kernel
-// (ablations: ~0.5 ms in the LDS read-modify-writes, ~0.3 ms in the dL/dp line reads), as was a per-voxel gather over
-// precomputed (sample, weight) lists (1.0-1.2 ms; 2.1 ms with 16 rows per half-wave, 1.8 ms with four in lock step,
-// no better with dL/dp stored in brick order).  It makes the batch-minor path differentiable; train in the standard
-// layout.
-constexpr int kSub = 2, kSubE = 1 << kSub, kSubV = kSubE * kSubE * kSubE;
-
-__global__ __launch_bounds__(kBlock) void render_bwd_sub_bm_kernel(RenderDims D, const double *__restrict__ dirs,
-                                                                    const float *__restrict__ dpbm,
-                                                                    const int4 *__restrict__ sub_rows, int n_rows,
-                                                                    const int *__restrict__ sub_list, View5 vox, View5 gvox,
-                                                                    int zero_only)
-{
-    __shared__ float accs[kWavesPerBlock][kSubV * kBmLanes];
-    __shared__ __attribute__((aligned(16))) int recs[kWavesPerBlock][64 * kBmRec];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row = blockIdx.x * kWavesPerBlock + wv;
-    if (row >= n_rows) return;
-    const int4 rw = sub_rows[row];
-    const int sb = rw.x, begin = rw.y, end = rw.z, shared = rw.w;
-    const int nsy = (D.Y + kSubE - 1) >> kSub, nsz = (D.Z + kSubE - 1) >> kSub;
-    const int ox = (sb / (nsy * nsz)) << kSub, oy = ((sb / nsz) % nsy) << kSub, oz = (sb % nsz) << kSub;
-    const int half = lane >> 5, li = lane & 31;
-    const int imgs = D.N * D.NC;
-    float *acc = accs[wv];
-    int *my = recs[wv];
-    for (int g0 = 0; g0 < imgs; g0 += kBmLanes) {
-        const int img = g0 + li;
-        const bool img_on = img < imgs;
-        const int n = img_on ? img / D.NC : 0, c_ = img_on ? img % D.NC : 0;
-        if (zero_only) {                                               // pre-pass: shared sub-bricks start from zero
-            if (shared && img_on)
-                for (int v = half; v < kSubV; v += 2) {
-                    const int x = ox + (v >> (2 * kSub)), y = oy + ((v >> kSub) & (kSubE - 1)), z = oz + (v & (kSubE - 1));
-                    if (x < D.X && y < D.Y && z < D.Z) gvox.p[n * gvox.s0 + c_ * gvox.s1 + x * gvox.s2 + y * gvox.s3 + z * gvox.s4] = 0.f;
-                }
-            continue;
-        }
-#pragma unroll
-        for (int t = 0; t < kSubV * kBmLanes / 64; t++) acc[t * 64 + lane] = 0.f;
-        for (int e0 = begin; e0 < end; e0 += 64) {
-            {   // phase A: lane l works out the geometry of entry e0 + l (see render_sample_bm_kernel)
-                const int e = e0 + lane;
-                unsigned ent = 0xffffffffu;
-                int lidx = 0, mask = 0;
-                float w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (e < end) {
-                    ent = (unsigned)sub_list[e];
-                    const int q = (int)(ent >> 8), k = (int)(ent & 255u);
-                    float gx, gy, gz;
-                    sample_pos(D, dirs[q * 3 + 0] * 2, dirs[q * 3 + 1] * 2, dirs[q * 3 + 2] * 2, k, gx, gy, gz);
-                    Cell c;
-                    locate(D, gx, gy, gz, c);
-                    const int lx = c.x0 - ox, ly = c.y0 - oy, lz = c.z0 - oz;
-                    lidx = (lx * kSubE + ly) * kSubE + lz;                // may be negative: only owned corners are used
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int x = lx + (i & 1), y = ly + ((i >> 1) & 1), z = lz + ((i >> 2) & 1);
-                        if ((unsigned)x < (unsigned)kSubE && (unsigned)y < (unsigned)kSubE && (unsigned)z < (unsigned)kSubE &&
-                            ox + x < D.X && oy + y < D.Y && oz + z < D.Z)
-                            mask |= 1 << i;
-                        w[i] = corner_w(c, i);
-                    }
-                }
-                int4 *dst = reinterpret_cast<int4 *>(my + lane * kBmRec);
-                dst[0] = make_int4(lidx, mask, (int)ent, 0);
-                dst[1] = make_int4(__float_as_int(w[0]), __float_as_int(w[1]), __float_as_int(w[2]), __float_as_int(w[3]));
-                dst[2] = make_int4(__float_as_int(w[4]), __float_as_int(w[5]), __float_as_int(w[6]), __float_as_int(w[7]));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            const int cnt = end - e0 < 64 ? end - e0 : 64;
-            // phase B: one sample per step; half h adds the corners of plane z0 + h (weights 4h .. 4h+3)
-            float dnext = 0.f;
-            {
-                const unsigned ent0 = (unsigned)my[2];
-                dnext = img_on ? dpbm[((ent0 >> 8) * (unsigned)D.ZR + (ent0 & 255u)) * (unsigned)imgs + (unsigned)img] : 0.f;
-            }
-            for (int s0 = 0; s0 < cnt; s0++) {
-                const int4 *r = reinterpret_cast<const int4 *>(my + s0 * kBmRec);
-                const int4 h0 = r[0], wq = r[1 + half];
-                const float d = dnext;
-                if (s0 + 1 < cnt) {                                     // the next sample's line is requested now
-                    const unsigned en = (unsigned)my[(s0 + 1) * kBmRec + 2];
-                    dnext = img_on ? dpbm[((en >> 8) * (unsigned)D.ZR + (en & 255u)) * (unsigned)imgs + (unsigned)img] : 0.f;
-                }
-                const int mask = h0.y >> (4 * half);
-                const int base = h0.x + half;                           // + 1 in z for the upper plane
-                const float w4[4] = {__int_as_float(wq.x), __int_as_float(wq.y), __int_as_float(wq.z), __int_as_float(wq.w)};
-                // the four cells are distinct voxels: read them together, then write them together (written as four
-                // read-modify-writes the compiler must assume aliasing: four dependent LDS round trips per sample)
-                float cur[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int vi = base + ((i & 1) ? kSubE * kSubE : 0) + ((i & 2) ? kSubE : 0);
-                    cur[i] = (mask & (1 << i)) ? acc[vi * kBmLanes + li] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int vi = base + ((i & 1) ? kSubE * kSubE : 0) + ((i & 2) ? kSubE : 0);
-                    if (mask & (1 << i)) acc[vi * kBmLanes + li] = __builtin_fmaf(w4[i], d, cur[i]);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (img_on) {
-            // flush: all clamp-mask lines of this half are requested before the first one is used (32 dependent
-            // round trips otherwise -- longer than the accumulation itself)
-            constexpr int kPer = kSubV / 2;
-            float tv[kPer];
-#pragma unroll
-            for (int t = 0; t < kPer; t++) {
-                const int v = 2 * t + half;
-                const int x = ox + (v >> (2 * kSub)), y = oy + ((v >> kSub) & (kSubE - 1)), z = oz + (v & (kSubE - 1));
-                tv[t] = 0.f;
-                if (D.pre_scale != 0.0f && x < D.X && y < D.Y && z < D.Z)
-                    tv[t] = vox.p[n * vox.s0 + c_ * vox.s1 + x * D.sx + y * D.sy + z * D.sz] * D.pre_scale;
-            }
-#pragma unroll
-            for (int t = 0; t < kPer; t++) {
-                const int v = 2 * t + half;
-                const int x = ox + (v >> (2 * kSub)), y = oy + ((v >> kSub) & (kSubE - 1)), z = oz + (v & (kSubE - 1));
-                if (x < D.X && y < D.Y && z < D.Z) {
-                    float a = acc[v * kBmLanes + li];
-                    if (D.pre_scale != 0.0f) a = (tv[t] >= D.lo && tv[t] <= D.hi) ? a * D.pre_scale : 0.0f;   // clamp adjoint
-                    float *dst = gvox.p + n * gvox.s0 + c_ * gvox.s1 + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
-                    if (!shared) *dst = a;
-                    else if (a != 0.0f) unsafeAtomicAdd(dst, a);
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    publish_max(wmax, lane, dpmax_bits + img);
 }
 
 // ---- backward pass B: brick-owned accumulation ----------------------------------------------------
@@ -1055,10 +658,6 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                                                                    View5 gvox)
 {
     __shared__ unsigned long long tile[kBrick * kBrick * kBrick];
-    // fixed-point scale 2^(44-e), 2^e >= max|dL/dp| (see file header); max == 0 -> everything is 0
-    int e = 0;
-    (void)frexpf(__uint_as_float(*dpmax_bits), &e);
-    const double scale = ldexp(1.0, 44 - e), inv_scale = ldexp(1.0, e - 44);
     // XCD-aware order: workgroups go to the 8 XCDs round-robin by linear id; when the image count allows it, all rows
     // of an image run on ONE XCD (images xcd, xcd + 8, ... in turn), so that image's dL/dp lines and clamp mask meet in
     // that XCD's L2 instead of being fetched by all eight
@@ -1070,6 +669,13 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
         img = xcd + 8 * (idx / n_row);
         trow = idx % n_row;
     }
+    // fixed-point scale 2^(44-e), 2^e >= THIS image's max|dL/dp| (see file header); max == 0 -> everything is 0.  Per
+    // image, so that an image whose upstream gradient is many orders of magnitude below its neighbours' keeps all 44 bits.
+    const unsigned maxbits = dpmax_bits[img];
+    const bool nonfinite = maxbits >= 0x7f800000u;                       // an Inf / NaN dL/dp somewhere in this image
+    int e = 0;
+    (void)frexpf(nonfinite ? 1.0f : __uint_as_float(maxbits), &e);
+    const double scale = ldexp(1.0, 44 - e), inv_scale = ldexp(1.0, e - 44);
     const int brick = brick_table[trow * 4 + 0];
     const int begin = brick_table[trow * 4 + 1], end = brick_table[trow * 4 + 2];
     const int shared = brick_table[trow * 4 + 3];
@@ -1158,8 +764,9 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
             float val = (float)((double)(long long)acc * inv_scale);
             if (D.pre_scale != 0.0f)                         // adjoint of clamp(x * pre_scale, lo, hi)
                 val = (tvs[i] >= D.lo && tvs[i] <= D.hi) ? val * D.pre_scale : 0.0f;
+            if (nonfinite) val = __uint_as_float(0x7fc00000u);          // the reference chain would return NaN here too
             if (!shared) *dst = val;
-            else if (acc != 0ull) unsafeAtomicAdd(dst, val);
+            else if (acc != 0ull || nonfinite) unsafeAtomicAdd(dst, val);
         }
     }
 }
@@ -1320,36 +927,6 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
         GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R,
                       "%s: kin must be int32 [R*R]", op);
         const int imgs = D.N * D.NC;
-        // batch-minor volume (image index fastest in memory) with enough images to fill half-waves
-        int64_t vspan = 1;
-        for (int i = 0; i < 5; i++) vspan += (vox->size[i] - 1) * vox->stride[i];
-        // (the caller must apply the same test to know the layout of v_scratch: toolbox/_fused_render.py: is_batch_minor)
-        if (imgs >= 16 && D.NC == 1 && vox->stride[0] == 1 && vspan < ((int64_t)1 << 30) &&
-            rays * D.ZR < ((int64_t)1 << 31)) {
-            const int n_entries = (int)fwd_chunks->size[0];
-            if (n_entries > 0) {
-                const int gb = ((n_entries + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock) + 7) / 8 * 8;   // multiple of 8 XCDs
-                if (pre_scale != 0.0f)
-                    render_sample_bm_kernel<true><<<gb, kBlock, 0, st>>>(D, view5(vox), (const double *)dirs->data,
-                                                                       (const int *)fwd_chunks->data, n_entries,
-                                                                       (float *)v_scratch->data);
-                else
-                    render_sample_bm_kernel<false><<<gb, kBlock, 0, st>>>(D, view5(vox), (const double *)dirs->data,
-                                                                        (const int *)fwd_chunks->data, n_entries,
-                                                                        (float *)v_scratch->data);
-                GENRE_LAUNCH_CHECK("render_spherical forward (batch-minor sampler)");
-            }
-            const int64_t lanes = (int64_t)D.R * D.R * ((imgs + kBmLanes - 1) / kBmLanes * kBmLanes);
-            // the backward scan's anchors live behind the samples when the caller made room for them
-            // (4 more floats per ray and image; 16-byte aligned because rays*ZR is a multiple of 4)
-            BmAnchor *anchor = v_scratch->size[0] >= rays * (D.ZR + 4)
-                                   ? reinterpret_cast<BmAnchor *>((float *)v_scratch->data + rays * D.ZR) : nullptr;
-            render_scan_fwd_bm_kernel<<<(int)((lanes + kBlock - 1) / kBlock), kBlock, 0, st>>>(
-                D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data, view4(out),
-                anchor);
-            GENRE_LAUNCH_CHECK("render_spherical forward (batch-minor scan)");
-            return 1;
-        }
         // batches: kGroup images share one walk over the sample list; a lone image gets the same kernel with G = 1
         // (512 threads per workgroup: 38.9 us for the batch-1 forward chain against 42.1 with 256, 42.2 with 1024)
         const int ok = imgs >= 2
@@ -1395,11 +972,12 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
         int rows = 0;
         if (!check_tables(op, D, brick_table, chunk_list, rows)) return 0;
         const int nb = ((D.X + kBrick - 1) / kBrick) * ((D.Y + kBrick - 1) / kBrick) * ((D.Z + kBrick - 1) / kBrick);
-        GENRE_REQUIRE(is_f32(dp_scratch, 1) && is_contiguous(dp_scratch) && dp_scratch->size[0] >= rays * D.ZR + 4 &&
+        const int imgs = D.N * D.NC;
+        GENRE_REQUIRE(is_f32(dp_scratch, 1) && is_contiguous(dp_scratch) && dp_scratch->size[0] >= rays * D.ZR + imgs &&
                           aligned16(dp_scratch->data),
-                      "%s: dp_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR + 4 elements", op);
-        unsigned *dpmax = (unsigned *)dp_scratch->data + rays * D.ZR;       // max|dL/dp| lives behind the samples
-        if (hipMemsetAsync(dpmax, 0, 16, st) != hipSuccess) return fail("%s: hipMemsetAsync failed", op);
+                      "%s: dp_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR + N*NC elements", op);
+        unsigned *dpmax = (unsigned *)dp_scratch->data + rays * D.ZR;       // per-image max|dL/dp| behind the samples
+        if (hipMemsetAsync(dpmax, 0, (size_t)imgs * 4, st) != hipSuccess) return fail("%s: hipMemsetAsync failed", op);
         if (rays > 0 && v_scratch && kin) {          // the forward left the raw sample values: scan only
             GENRE_REQUIRE((D.ZR & 3) == 0, "%s: brick path needs ZR %% 4 == 0", op);
             GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && v_scratch->size[0] >= rays * D.ZR &&
@@ -1444,63 +1022,5 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                                                                     (const float *)depth_weight->data,
                                                                     view4(grad_out), view5(grad_vox));
     GENRE_LAUNCH_CHECK("render_spherical backward");
-    return 1;
-}
-
-extern "C" int genre_render_spherical_backward_bm(const genre_tensor *vox, const genre_tensor *dirs,
-                                                  const genre_tensor *depth_weight, const genre_tensor *grad_out,
-                                                  const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
-                                                  const genre_tensor *sub_rows, const genre_tensor *sub_list,
-                                                  const genre_tensor *v_scratch, const genre_tensor *kin,
-                                                  float pre_scale, void *stream)
-{
-    const char *op = "render_spherical_backward_bm";
-    RenderDims D{};
-    if (!check_render(op, vox, dirs, depth_weight, grad_out, D)) return 0;
-    D.pre_scale = pre_scale;
-    GENRE_REQUIRE(is_f32(grad_vox, 5) && same_shape(grad_vox, vox), "%s: grad_vox must have the shape of vox", op);
-    GENRE_REQUIRE(D.ZR <= 256 && (D.ZR & 3) == 0, "%s: needs z_res <= 256 and z_res %% 4 == 0", op);
-    const int imgs = D.N * D.NC;
-    const int64_t rays = (int64_t)imgs * D.R * D.R;
-    if (numel(grad_vox) == 0) return 1;
-    GENRE_REQUIRE(rays * D.ZR < ((int64_t)1 << 31), "%s: rays * z_res must be < 2^31", op);
-    const int nsub = ((D.X + kSubE - 1) >> kSub) * ((D.Y + kSubE - 1) >> kSub) * ((D.Z + kSubE - 1) >> kSub);
-    GENRE_REQUIRE(is_i32(sub_rows, 2) && sub_rows->size[1] == 4 && is_contiguous(sub_rows) && sub_rows->size[0] >= nsub &&
-                      sub_rows->size[0] < ((int64_t)1 << 30) && aligned16(sub_rows->data),
-                  "%s: sub_rows must be a contiguous int32 [rows >= %d, 4] tensor", op, nsub);
-    GENRE_REQUIRE(is_i32(sub_list, 1) && is_contiguous(sub_list), "%s: sub_list must be int32 [S]", op);
-    GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && v_scratch->size[0] >= rays * (D.ZR + 4) &&
-                      aligned16(v_scratch->data),
-                  "%s: v_scratch must be the forward's buffer of >= rays*(ZR+4) floats (samples + anchors)", op);
-    GENRE_REQUIRE(is_f32(dp_scratch, 1) && is_contiguous(dp_scratch) && dp_scratch->size[0] >= rays * D.ZR,
-                  "%s: dp_scratch must be a contiguous fp32 buffer of >= rays*ZR elements", op);
-    GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R, "%s: kin must be int32 [R*R]", op);
-    int64_t gspan = 1, vspan = 1;
-    for (int i = 0; i < 5; i++) {
-        GENRE_REQUIRE(grad_vox->stride[i] >= 0, "%s: negative grad_vox strides are not supported", op);
-        gspan += (grad_vox->size[i] - 1) * grad_vox->stride[i];
-        vspan += (vox->size[i] - 1) * vox->stride[i];
-    }
-    GENRE_REQUIRE(gspan < ((int64_t)1 << 31) && vspan < ((int64_t)1 << 31), "%s: volumes must span < 2^31 elements", op);
-    hipStream_t st = (hipStream_t)stream;
-    if (rays > 0) {
-        const int64_t lanes = (int64_t)D.R * D.R * ((imgs + kBmLanes - 1) / kBmLanes * kBmLanes);
-        render_scan_bwd_bm_kernel<<<(int)((lanes + kBlock - 1) / kBlock), kBlock, 0, st>>>(
-            D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data, view4(grad_out),
-            reinterpret_cast<const BmAnchor *>((const float *)v_scratch->data + rays * D.ZR), (float *)dp_scratch->data);
-        GENRE_LAUNCH_CHECK("render_spherical backward (batch-minor scan)");
-    }
-    const int n_rows = (int)sub_rows->size[0];
-    const int gb = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (n_rows > nsub) {        // some sub-bricks are split over several rows: those accumulate with atomics
-        render_bwd_sub_bm_kernel<<<gb, kBlock, 0, st>>>(D, (const double *)dirs->data, (const float *)dp_scratch->data,
-                                                       (const int4 *)sub_rows->data, n_rows, (const int *)sub_list->data,
-                                                       view5(vox), view5(grad_vox), 1);
-        GENRE_LAUNCH_CHECK("render_spherical backward (zero shared sub-bricks)");
-    }
-    render_bwd_sub_bm_kernel<<<gb, kBlock, 0, st>>>(D, (const double *)dirs->data, (const float *)dp_scratch->data,
-                                                   (const int4 *)sub_rows->data, n_rows, (const int *)sub_list->data,
-                                                   view5(vox), view5(grad_vox), 0);
-    GENRE_LAUNCH_CHECK("render_spherical backward (sub-bricks)");
     return 1;
 }

@@ -1,0 +1,638 @@
+// sph_render_bm.hip -- batch-minor TILE renderer: fused voxel -> spherical depth map for batches, gfx950.
+//
+// Same operator as sph_render.hip -- render_spherical.forward of the reference (toolbox/spherical_proj.py:62-72:
+// grid_sample (PyTorch 0.4.1 == align_corners=True), clamp, CalcStopProb (calc_prob_kernel.cu:113-189),
+// matmul(depth_weight), prod(1-p), add) and its autograd backward -- for volumes whose IMAGE index is fastest in
+// memory (element (n,x,y,z) at x*sx + y*sy + z*sz + n).  Then 32 lanes can be 32 images of ONE sample, and everything
+// that depends on the geometry only (where a sample falls, its eight trilinear weights, which brick holds it, how
+// a ray is cut into per-brick segments) comes from tables built once per geometry on the host
+// (toolbox/_bm_tables.py); the kernels execute no geometry arithmetic at all.
+//
+//  * Bricks of 4 x 8 x 8 voxels.  A SEGMENT = a run of consecutive samples of one ray whose base voxel lies in one
+//    brick (<= 32 samples, 8.7 on average at 128^3 / 128^2 rays / 256 samples).
+//  * The ray integral is associative: a segment contributes (P, S) = (prod(1-p_k), sum_k T_k p_k w_k with T = 1 at
+//    its start); a per-ray pass chains the segments.  Nothing per SAMPLE ever goes through HBM in the forward
+//    (sph_render.hip writes and re-reads 16 MiB of raw sample values per image).
+//  * bm_sample_kernel: a workgroup stages its brick + the high halo (5 x 9 x 9 voxel lines of 32 images, 51 KB) in
+//    LDS; a WAVE marches one segment serially.  Lane = (image, z half): the two half-waves read the z0 / z0+1
+//    corner lines of the same sample -- adjacent in LDS, 256 contiguous bytes, conflict-free by construction -- and
+//    exchange their partial sums with one v_permlane32_swap.  Per sample: 2 broadcast reads of the 48-byte record,
+//    4 ds_read_b32, 4 multiply-adds, the clamp, 3 scan operations.
+//  * Backward: dL/dp_k = g T_k (w_k - R_{k+1}),  R_k = p_k w_k + (1 - p_k) R_{k+1},  R_end = 1 -- no division, no
+//    cancellation.  bm_combine_bwd_kernel leaves g*T at the start and R behind the end of every segment;
+//    bm_scatter_kernel: every brick PULLS the segments that touch one of its voxels, re-runs their (cheap) serial
+//    scans from the saved clamped samples p (the only per-sample stream: 4 B per sample and image, written by the
+//    forward when a gradient is wanted), and accumulates the trilinear adjoint of the samples it owns corners of in an
+//    fp64 LDS tile it alone owns -- ds_add_f64 runs at 8.7 clk per 64-lane instruction on gfx950 against 193 for
+//    ds_add_f32 (tools/bm_tile_bench.hip) -- then writes every voxel of grad_vox exactly once with plain stores.
+//    fp64 accumulation needs no scale (sph_render.hip's 64-bit fixed point needs a batch-global max |dL/dp| pass),
+//    propagates NaN / Inf gradients, and is order-independent to ~1e-16.
+//  * The caller-side clamp(proj * 50, 1e-5, 1 - 1e-5) (depth_pred_with_sph_inpaint.py:124) folds into the tile load
+//    (pre_scale); its adjoint mask is one bit per voxel and image, written by the forward (the brick that owns the
+//    voxel), read by the backward's flush -- the volume itself is not read again.
+#include "common.hpp"
+
+namespace genre {
+namespace {
+
+constexpr int kBX = 4, kBY = 8, kBZ = 8;                 // brick (must match toolbox/_bm_tables.py)
+constexpr int kTX = kBX + 1, kTY = kBY + 1, kTZ = kBZ + 1;
+constexpr int kLinesF = kTX * kTY * kTZ;                 // 405 voxel lines in the forward tile
+constexpr int kLinesB = kBX * kBY * kBZ;                 // 256 in the backward tile
+constexpr int kImgs = 32;                                // images per group = lanes of a half-wave
+constexpr int kMaxSeg = 16;
+constexpr int kRec = 12;                                 // words per sample record
+constexpr int kThreads = 512;
+
+struct BmDims {
+    int N, X, Y, Z, R, pad;
+    int nseg, groups;
+    int64_t nslot;
+    int64_t sx, sy, sz;                                  // element strides of vox (image stride == 1)
+    int64_t gx, gy, gz;                                  // ... of grad_vox
+    float pre_scale, lo, hi;
+};
+
+__device__ __forceinline__ float other_half_sum(float v)
+{
+    // lanes 0-31 and 32-63 hold the z0 / z0+1 partial sums of the same (sample, image): v_permlane32_swap
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS operations of one wave execute in order: only the compiler has to be kept from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void brick_origin(const BmDims &D, int brick, int &ox, int &oy, int &oz)
+{
+    const int nby = (D.Y + kBY - 1) / kBY, nbz = (D.Z + kBZ - 1) / kBZ;
+    ox = (brick / (nby * nbz)) * kBX; oy = ((brick / nbz) % nby) * kBY; oz = (brick % nbz) * kBZ;
+}
+
+// ---- forward: brick sampler ---------------------------------------------------------------------------
+// grid = (rows, groups).  ps [group][segment][2][32] <- (P, S); stash [group][slot][32] <- clamped sample, negated
+// where the clamp does not pass the gradient; mask [group][voxel] <- bit i: image i passes the pre_scale clamp.
+template <bool PS, bool SAVE, int NT>
+__global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__restrict__ vox,
+                                                             const int4 *__restrict__ segs, const int *__restrict__ rec_f,
+                                                             const int4 *__restrict__ rows, float *__restrict__ ps,
+                                                             float *__restrict__ stash, unsigned *__restrict__ mask)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    float *tile = lds_f;                                               // [kLinesF][32]
+    int *recs = reinterpret_cast<int *>(lds_f + kLinesF * kImgs);      // [(NT / 64)][kMaxSeg * kRec]
+    const int4 row = rows[blockIdx.x];
+    const int g = blockIdx.y, n0 = g * kImgs;
+    int ox, oy, oz;
+    brick_origin(D, row.x, ox, oy, oz);
+    const bool vec = (D.N & 3) == 0 && (D.sx & 3) == 0 && (D.sy & 3) == 0 && (D.sz & 3) == 0;
+    // Stage the tile: thread t + 512 j takes 16 bytes (4 images) of voxel line (t + 512 j) / 8.  ALL loads of a thread are
+    // issued before the first one is used -- one exposed HBM round trip per tile instead of seven.
+    constexpr int kIter = (kLinesF * 8 + NT - 1) / NT;
+    float4 q[kIter];
+    int xyz[kIter];                                                    // x | y << 10 | z << 20, or -1 outside the volume
+#pragma unroll
+    for (int j = 0; j < kIter; j++) {
+        const int t = threadIdx.x + j * NT;
+        const int line = t >> 3, piece = t & 7;
+        const int lz = line % kTZ, ly = (line / kTZ) % kTY, lx = line / (kTZ * kTY);
+        const int x = ox + lx, y = oy + ly, z = oz + lz;
+        q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xyz[j] = -1;
+        if (t < kLinesF * 8 && x < D.X && y < D.Y && z < D.Z) {
+            xyz[j] = x | (y << 10) | (z << 20);
+            const int n = n0 + piece * 4;
+            const float *src = vox + x * D.sx + y * D.sy + z * D.sz + n;
+            if (vec && n + 3 < D.N) q[j] = *reinterpret_cast<const float4 *>(src);
+            else {
+                if (n + 0 < D.N) q[j].x = src[0];
+                if (n + 1 < D.N) q[j].y = src[1];
+                if (n + 2 < D.N) q[j].z = src[2];
+                if (n + 3 < D.N) q[j].w = src[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kIter; j++) {
+        const int t = threadIdx.x + j * NT;
+        const int line = t >> 3, piece = t & 7;
+        float v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+        unsigned bits = 0;
+        const bool in = xyz[j] >= 0;
+        if (PS && in) {                                                // depth_pred_with_sph_inpaint.py:124
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float raw = v[c] * D.pre_scale;
+                bits |= (raw >= D.lo && raw <= D.hi) ? (1u << c) : 0u;
+                v[c] = fminf(fmaxf(raw, D.lo), D.hi);
+            }
+        }
+        if (t < kLinesF * 8) *reinterpret_cast<float4 *>(tile + line * kImgs + piece * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        if (PS && SAVE) {
+            // the 8 threads of a line sit in 8 consecutive lanes: OR their nibbles together with DPP
+            bits <<= piece * 4;
+            bits |= __builtin_amdgcn_update_dpp(0u, bits, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+            bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+            bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x141, 0xf, 0xf, true);     // row_half_mirror
+            const int x = xyz[j] & 1023, y = (xyz[j] >> 10) & 1023, z = xyz[j] >> 20;
+            if (piece == 0 && in && x - ox < kBX && y - oy < kBY && z - oz < kBZ)
+                mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] = bits;
+        }
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int half = lane >> 5, l = lane & 31;
+    int *myrec = recs + wave * ((kMaxSeg + 1) * kRec);
+    const char *tl = reinterpret_cast<const char *>(tile + half * kImgs + l);
+    constexpr int kXS = kTY * kTZ * kImgs, kYS = kTZ * kImgs;          // floats between x / y neighbours
+    // Software pipeline over this wave's segments s, s + 8, ...: while segment s is marched, the records of the next
+    // one are in flight to registers and the header of the one after that is being fetched -- per segment the wave
+    // would otherwise sit through two dependent global round trips (header -> records) before its first sample.
+    const int4 none = make_int4(0, 0, 0, 0);
+    int s = row.y + wave;
+    int4 sg = s < row.z ? segs[s] : none;
+    int4 sg1 = s + (NT / 64) < row.z ? segs[s + (NT / 64)] : none;
+    int4 rq = none;                                                    // lane's 16 bytes of the segment's L*3 x 16
+    if (lane < sg.z * 3) rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)sg.w * kRec)[lane];
+    for (; s < row.z; s += (NT / 64)) {
+        const int L = __builtin_amdgcn_readfirstlane(sg.z);
+        const int64_t slot0 = __builtin_amdgcn_readfirstlane(sg.w);
+        if (lane < L * 3) reinterpret_cast<int4 *>(myrec)[lane] = rq;
+        wave_lds_fence();
+        const int4 sg2 = s + 2 * (NT / 64) < row.z ? segs[s + 2 * (NT / 64)] : none;
+        if (lane < sg1.z * 3) rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)sg1.w * kRec)[lane];
+        float T = 1.f, S = 0.f, sprev = 0.f;
+        float *st = SAVE ? stash + ((size_t)g * D.nslot + slot0) * kImgs + l : nullptr;
+        int2 hd = *reinterpret_cast<const int2 *>(myrec);                             // (tile byte offset, depth weight)
+        float4 w = *reinterpret_cast<const float4 *>(myrec + 4 + half * 4);
+        for (int i = 0; i < L; i++) {
+            const float *a = reinterpret_cast<const float *>(tl + hd.x);
+            const float a0 = a[0], a1 = a[kXS], a2 = a[kYS], a3 = a[kXS + kYS];
+            const float dwk = __int_as_float(hd.y);
+            const float4 wc = w;
+            // the next sample's record is requested before this one's taps are consumed (slot L is scratch)
+            const int *r = myrec + (i + 1) * kRec;
+            hd = *reinterpret_cast<const int2 *>(r);
+            w = *reinterpret_cast<const float4 *>(r + 4 + half * 4);
+            float v = a0 * wc.x;
+            v = __builtin_fmaf(a1, wc.y, v);
+            v = __builtin_fmaf(a2, wc.z, v);
+            v = __builtin_fmaf(a3, wc.w, v);
+            v = other_half_sum(v);
+            const float p = fminf(fmaxf(v, D.lo), D.hi);                              // spherical_proj.py:66
+            if (SAVE) {     // samples 2j (lower half-wave) and 2j+1 (upper) leave together: one 256-byte store per pair
+                const float sp = (v >= D.lo && v <= D.hi) ? p : -p;
+                if (i & 1) st[(size_t)(i - 1 + half) * kImgs] = half ? sp : sprev;
+                else if (i == L - 1 && half == 0) st[(size_t)i * kImgs] = sp;
+                sprev = sp;
+            }
+            S = __builtin_fmaf(T * p, dwk, S);                                        // + s_k w_k  (:68)
+            T *= 1.0f - p;
+        }
+        ps[((size_t)(g * D.nseg + s) * 2 + half) * kImgs + l] = half ? S : T;
+        wave_lds_fence();                                                             // records are overwritten next
+        sg = sg1; sg1 = sg2;
+    }
+}
+
+// sph_pad (spherical_proj.py:21-28) as a fan-out of map pixel (i, j): see sph_render.hip: pad_span
+__device__ __forceinline__ void pad_span(int R, int pm, int i, int j, int &r_lo, int &r_n, int &c0, int &c1)
+{
+    r_lo = (i == 0) ? 0 : i + pm;
+    r_n = ((i == R - 1) ? R - 1 + 2 * pm : i + pm) - r_lo + 1;
+    c0 = j + pm;
+    c1 = (j >= R - pm) ? j - (R - pm) : (j < pm ? j + R + pm : -1);
+}
+
+// ---- forward: chain the segments of a ray --------------------------------------------------------------
+// a half-wave per ray, lane = image; fp64 (18 segments per ray on average: nothing to save here)
+__global__ __launch_bounds__(256) void bm_combine_fwd_kernel(BmDims D, const float *__restrict__ ps,
+                                                             const int *__restrict__ ray_ptr,
+                                                             const int *__restrict__ ray_seg,
+                                                             const double2 *__restrict__ ray_pre, View4 out)
+{
+    const int q = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (q >= D.R * D.R) return;
+    const int g = blockIdx.y, n = g * kImgs + l;
+    const int j0 = ray_ptr[q], j1 = ray_ptr[q + 1];
+    const double2 pre = ray_pre[q];
+    double T = pre.x, S = pre.y;
+    const float *base = ps + (size_t)g * D.nseg * 2 * kImgs + l;
+    // the ray's segment ids are fetched 32 at a time (one per lane of the half-wave) and handed round with shuffles;
+    // the (P, S) lines of four segments are in flight together
+    for (int jb = j0; jb < j1; jb += 32) {
+        const int cnt = (j1 - jb < 32) ? j1 - jb : 32;
+        const int myid = l < cnt ? ray_seg[jb + l] : 0;
+        for (int t = 0; t < cnt; t += 4) {
+            float P[4], Sg[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = __shfl(myid, t + u, 32);
+                const bool on = t + u < cnt;
+                P[u] = on ? base[(size_t)s * 2 * kImgs] : 1.f;
+                Sg[u] = on ? base[(size_t)s * 2 * kImgs + kImgs] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                S += T * (double)Sg[u];
+                T *= (double)P[u];
+            }
+        }
+    }
+    if (n >= D.N) return;
+    const float val = (float)(S + T);                                   // + prod(1-p)  (:69-71)
+    float *o = out.p + n * out.s0;
+    const int i = q / D.R, jj = q % D.R;
+    if (D.pad == 0) { o[i * out.s2 + jj * out.s3] = val; return; }
+    int r_lo, r_n, c0, c1;
+    pad_span(D.R, D.pad, i, jj, r_lo, r_n, c0, c1);
+    for (int r = 0; r < r_n; r++) {
+        o[(r_lo + r) * out.s2 + c0 * out.s3] = val;
+        if (c1 >= 0) o[(r_lo + r) * out.s2 + c1 * out.s3] = val;
+    }
+}
+
+// ---- backward: per-ray pass ------------------------------------------------------------------------------
+// tr [group][segment][2][32] <- (g * T at the segment's start, R behind its end)
+__global__ __launch_bounds__(256) void bm_combine_bwd_kernel(BmDims D, const float *__restrict__ ps,
+                                                             const int *__restrict__ ray_ptr,
+                                                             const int *__restrict__ ray_seg,
+                                                             const double2 *__restrict__ ray_pre, View4 gout,
+                                                             float *__restrict__ tr)
+{
+    const int q = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (q >= D.R * D.R) return;
+    const int g = blockIdx.y, n = g * kImgs + l;
+    float gv = 0.f;
+    if (n < D.N) {                                                       // gradient of the ray's value: its padded positions
+        const float *gi = gout.p + n * gout.s0;
+        const int i = q / D.R, jj = q % D.R;
+        if (D.pad == 0) gv = gi[i * gout.s2 + jj * gout.s3];
+        else {
+            int r_lo, r_n, c0, c1;
+            pad_span(D.R, D.pad, i, jj, r_lo, r_n, c0, c1);
+            for (int r = 0; r < r_n; r++) {
+                gv += gi[(r_lo + r) * gout.s2 + c0 * gout.s3];
+                if (c1 >= 0) gv += gi[(r_lo + r) * gout.s2 + c1 * gout.s3];
+            }
+        }
+    }
+    const int j0 = ray_ptr[q], j1 = ray_ptr[q + 1];
+    const size_t gb = (size_t)g * D.nseg * 2 * kImgs + l;
+    double T = ray_pre[q].x;
+    for (int jb = j0; jb < j1; jb += 32) {                               // forward: g T at every segment's start
+        const int cnt = (j1 - jb < 32) ? j1 - jb : 32;
+        const int myid = l < cnt ? ray_seg[jb + l] : 0;
+        for (int t = 0; t < cnt; t += 4) {
+            float P[4];
+            size_t o[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                o[u] = gb + (size_t)__shfl(myid, t + u, 32) * 2 * kImgs;
+                P[u] = t + u < cnt ? ps[o[u]] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (t + u < cnt) tr[o[u]] = (float)((double)gv * T);
+                T *= (double)P[u];
+            }
+        }
+    }
+    double Rr = 1.0;                                                      // behind the last sample: prod(1-p) * 1
+    for (int je = j1; je > j0; je -= 32) {                                // reverse: R behind every segment's end
+        const int cnt = (je - j0 < 32) ? je - j0 : 32;
+        const int myid = l < cnt ? ray_seg[je - 1 - l] : 0;              // lane t holds segment je - 1 - t
+        for (int t = 0; t < cnt; t += 4) {
+            float P[4], Sg[4];
+            size_t o[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                o[u] = gb + (size_t)__shfl(myid, t + u, 32) * 2 * kImgs;
+                const bool on = t + u < cnt;
+                P[u] = on ? ps[o[u]] : 0.f;
+                Sg[u] = on ? ps[o[u] + kImgs] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (t + u < cnt) {
+                    tr[o[u] + kImgs] = (float)Rr;
+                    Rr = (double)Sg[u] + (double)P[u] * Rr;
+                }
+            }
+        }
+    }
+}
+
+// ---- backward: brick-owned pull scatter ----------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, float *__restrict__ gvox)
+{
+    const int4 row = rows[blockIdx.x];
+    if (row.w == 0) return;
+    int ox, oy, oz;
+    brick_origin(D, row.x, ox, oy, oz);
+    const int n0 = blockIdx.y * kImgs;
+    for (int e = threadIdx.x; e < kLinesB * kImgs; e += kThreads) {
+        const int line = e >> 5, n = n0 + (e & 31);
+        const int x = ox + line / (kBY * kBZ), y = oy + (line / kBZ) % kBY, z = oz + line % kBZ;
+        if (x < D.X && y < D.Y && z < D.Z && n < D.N) gvox[x * D.gx + y * D.gy + z * D.gz + n] = 0.f;
+    }
+}
+
+// swap the two half-waves' values: returns (value held by the lower half, value held by the upper half) in every lane
+__device__ __forceinline__ void both_halves(float v, float &lower, float &upper)
+{
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    lower = __uint_as_float(r[0]); upper = __uint_as_float(r[1]);
+}
+
+constexpr int kThreadsB = 1024, kWavesB = kThreadsB / 64;
+constexpr int kHalfSeg = kMaxSeg / 2;
+
+template <bool PS>
+__global__ __launch_bounds__(kThreadsB, 8) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
+                                                               const int4 *__restrict__ rows, const float *__restrict__ dw,
+                                                               const float *__restrict__ tr, const float *__restrict__ stash,
+                                                               const unsigned *__restrict__ mask, float *__restrict__ gvox)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    double *tile = lds_d;                                               // [kLinesB][32]
+    int *recs = reinterpret_cast<int *>(lds_d + kLinesB * kImgs);       // [kWavesB][kMaxSeg * kRec]
+    unsigned *mlds = reinterpret_cast<unsigned *>(recs + kWavesB * kMaxSeg * kRec);     // [kLinesB] clamp masks
+    const int4 row = rows[blockIdx.x];
+    const int g = blockIdx.y, n0 = g * kImgs;
+    int ox, oy, oz;
+    brick_origin(D, row.x, ox, oy, oz);
+    if (PS && threadIdx.x < kLinesB) {                                   // in flight while the samples are scattered
+        const int line = threadIdx.x;
+        const int x = ox + line / (kBY * kBZ), y = oy + (line / kBZ) % kBY, z = oz + line % kBZ;
+        mlds[line] = (x < D.X && y < D.Y && z < D.Z) ? mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] : 0u;
+    }
+    for (int e = threadIdx.x; e < kLinesB * kImgs; e += kThreadsB) tile[e] = 0.0;
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int half = lane >> 5, l = lane & 31;
+    int *myrec = recs + wave * (kMaxSeg * kRec);
+    char *tl = reinterpret_cast<char *>(tile + half * kImgs + l);
+    constexpr int kXS = kBY * kBZ * kImgs, kYS = kBZ * kImgs;           // doubles between x / y neighbours
+    // entry = (segment, stash slot of its first sample, i0 | i1 << 6 | L << 12 | k0 << 18, rec_b slot of sample i0).
+    // Software pipeline: while entry e is scattered, the saved samples, the two ray scalars and the records of entry
+    // e + 16 are in flight to registers and the header of e + 32 is being fetched.  The per-sample arrays are SPLIT over
+    // the two half-waves (lanes l and l + 32 are the same image): the lower half keeps the even samples, the upper half
+    // the odd ones, exchanged with v_permlane32_swap when needed -- 24 registers instead of 48, which is what lets
+    // 16 waves per workgroup (8 per SIMD) hide the latency of this kernel's gathers.
+    const int4 none = make_int4(0, 0, 0, 0);
+    int e = row.y + wave;
+    int4 en = e < row.z ? ents[e] : none;
+    int4 en1 = e + kWavesB < row.z ? ents[e + kWavesB] : none;
+    float pn[kHalfSeg];
+    float Tn = 0.f, Rn = 0.f;
+    int4 rq = none;
+    auto fetch = [&](const int4 &h) {
+        const int Lh = (h.z >> 12) & 63;
+        const float *st = stash + ((size_t)g * D.nslot + h.y + half) * kImgs + l;
+#pragma unroll
+        for (int j = 0; j < kHalfSeg; j++) pn[j] = (2 * j + half < Lh) ? st[(size_t)(2 * j) * kImgs] : 0.f;
+        const size_t to = ((size_t)(g * D.nseg + h.x) * 2) * kImgs + l;
+        Tn = tr[to]; Rn = tr[to + kImgs];
+        const int cnt = (((h.z >> 6) & 63) - (h.z & 63)) * 3;
+        if (lane < cnt) rq = reinterpret_cast<const int4 *>(rec_b + (int64_t)h.w * kRec)[lane];
+    };
+    if (e < row.z) fetch(en);
+    for (; e < row.z; e += kWavesB) {
+        const int pk = __builtin_amdgcn_readfirstlane(en.z);
+        const int i0 = pk & 63, i1 = (pk >> 6) & 63, L = (pk >> 12) & 63, k0 = (pk >> 18) & 255;
+        float pv[kHalfSeg], cg[kHalfSeg];
+#pragma unroll
+        for (int j = 0; j < kHalfSeg; j++) pv[j] = pn[j];
+        float Tg = Tn, Rr = Rn;
+        if (lane < (i1 - i0) * 3) reinterpret_cast<int4 *>(myrec)[lane] = rq;
+        wave_lds_fence();
+        const int4 en2 = e + 2 * kWavesB < row.z ? ents[e + 2 * kWavesB] : none;
+        if (e + kWavesB < row.z) fetch(en1);
+#pragma unroll
+        for (int j = 0; j < kHalfSeg; j++) {                            // forward: g T_k where the clamp passes the gradient
+            if (2 * j < L) {
+                float pe, po;
+                both_halves(pv[j], pe, po);                             // samples 2j, 2j + 1 (po = 0 beyond the end)
+                const float ce = pe > 0.f ? Tg : 0.f;
+                Tg *= 1.0f - fabsf(pe);
+                const float co = po > 0.f ? Tg : 0.f;
+                Tg *= 1.0f - fabsf(po);
+                cg[j] = half ? co : ce;
+            }
+        }
+        auto sample = [&](int i, float pa, float c) {                   // reverse: R_k = p w + (1-p) R_{k+1}; dL/dp_k; scatter
+            const float wk = dw[k0 + i];
+            const float d = wk - Rr;
+            const float dp = c * d;
+            Rr = __builtin_fmaf(pa, d, Rr);
+            if (i < i1) {
+                const int *r = myrec + (i - i0) * kRec;
+                const int2 hd = *reinterpret_cast<const int2 *>(r);                   // (tile byte offset, ownership)
+                const float4 w = *reinterpret_cast<const float4 *>(r + 4 + half * 4);
+                double *a = reinterpret_cast<double *>(tl + hd.x);
+                const unsigned own = (unsigned)hd.y >> (4 * half);
+                if (own & 1u) unsafeAtomicAdd(a, (double)(w.x * dp));                 // ds_add_f64
+                if (own & 2u) unsafeAtomicAdd(a + kXS, (double)(w.y * dp));
+                if (own & 4u) unsafeAtomicAdd(a + kYS, (double)(w.z * dp));
+                if (own & 8u) unsafeAtomicAdd(a + kXS + kYS, (double)(w.w * dp));
+            }
+        };
+#pragma unroll
+        for (int j = kHalfSeg - 1; j >= 0; j--) {
+            if (2 * j < L && 2 * j + 1 >= i0) {
+                float pe, po, ce, co;
+                both_halves(pv[j], pe, po);
+                both_halves(cg[j], ce, co);
+                if (2 * j + 1 < L) sample(2 * j + 1, fabsf(po), co);
+                if (2 * j >= i0) sample(2 * j, fabsf(pe), ce);
+            }
+        }
+        wave_lds_fence();
+        en = en1; en1 = en2;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int e2 = threadIdx.x; e2 < kLinesB * kImgs; e2 += kThreadsB) {
+        const int line = e2 >> 5, n = n0 + (e2 & 31);
+        const int x = ox + line / (kBY * kBZ), y = oy + (line / kBZ) % kBY, z = oz + line % kBZ;
+        if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
+            float val = (float)tile[e2];
+            if (PS) val = ((mlds[line] >> (e2 & 31)) & 1u) ? val * D.pre_scale : 0.f;  // adjoint of clamp(x * pre_scale, lo, hi)
+            float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
+            if (row.w == 0) *dst = val;
+            else if (val != 0.f) unsafeAtomicAdd(dst, val);
+        }
+    }
+}
+
+int check_bm(const char *op, const genre_tensor *vox, const genre_tensor *map, const genre_tensor *segs,
+             const genre_tensor *ray_ptr, const genre_tensor *ray_seg, const genre_tensor *ray_pre, BmDims &D, bool grad)
+{
+    GENRE_REQUIRE(is_f32(vox, 5) && vox->size[1] == 1 && vox->stride[0] == 1, "%s: %s must be a batch-minor fp32 tensor "
+                  "[N,1,X,Y,Z] (stride[0] == 1)", op, grad ? "grad_vox" : "vox");
+    D.N = (int)vox->size[0]; D.X = (int)vox->size[2]; D.Y = (int)vox->size[3]; D.Z = (int)vox->size[4];
+    int64_t span = 1;
+    for (int i = 0; i < 5; i++) {
+        GENRE_REQUIRE(vox->stride[i] >= 0, "%s: negative strides are not supported", op);
+        span += (vox->size[i] - 1) * vox->stride[i];
+    }
+    GENRE_REQUIRE(span < ((int64_t)1 << 40) && numel(vox) > 0, "%s: empty or oversized volume", op);
+    GENRE_REQUIRE(is_i32(ray_ptr, 1) && is_contiguous(ray_ptr) && ray_ptr->size[0] >= 2, "%s: ray_ptr must be int32 [R*R+1]", op);
+    const int64_t rr = ray_ptr->size[0] - 1;
+    int R = 1;
+    while ((int64_t)R * R < rr) R++;
+    GENRE_REQUIRE((int64_t)R * R == rr, "%s: ray_ptr must have R*R+1 entries", op);
+    D.R = R;
+    GENRE_REQUIRE(is_f32(map, 4) && map->size[0] == vox->size[0] && map->size[1] == 1 && map->size[2] == map->size[3] &&
+                      map->size[2] >= R && ((map->size[2] - R) & 1) == 0 && (map->size[2] - R) <= R,
+                  "%s: the spherical map must be fp32 [N,1,R+2p,R+2p] with 0 <= 2p <= R = %d", op, R);
+    D.pad = (int)(map->size[2] - R) / 2;
+    GENRE_REQUIRE(is_i32(segs, 2) && segs->size[1] == 4 && is_contiguous(segs) && aligned16(segs->data) &&
+                      segs->size[0] < ((int64_t)1 << 26), "%s: segs must be a contiguous int32 [nseg,4] tensor", op);
+    D.nseg = (int)segs->size[0];
+    GENRE_REQUIRE(is_i32(ray_seg, 1) && is_contiguous(ray_seg) && ray_seg->size[0] == D.nseg, "%s: ray_seg must be int32 [nseg]", op);
+    GENRE_REQUIRE(is_f32(ray_pre, 2) && ray_pre->size[0] == rr && ray_pre->size[1] == 4 && is_contiguous(ray_pre) &&
+                      aligned16(ray_pre->data), "%s: ray_pre must be the float64 [R*R,2] table viewed as fp32 [R*R,4]", op);
+    D.groups = (D.N + kImgs - 1) / kImgs;
+    GENRE_REQUIRE(D.groups <= 65535 && (int64_t)D.groups * D.nseg < ((int64_t)1 << 31), "%s: batch too large", op);
+    D.lo = 1e-5f; D.hi = (float)(1 - 1e-5);                              // spherical_proj.py:66
+    return 1;
+}
+
+int check_rows(const char *op, const BmDims &D, const genre_tensor *rows)
+{
+    const int nb = ((D.X + kBX - 1) / kBX) * ((D.Y + kBY - 1) / kBY) * ((D.Z + kBZ - 1) / kBZ);
+    GENRE_REQUIRE(is_i32(rows, 2) && rows->size[1] == 4 && is_contiguous(rows) && aligned16(rows->data) &&
+                      rows->size[0] >= nb && rows->size[0] < ((int64_t)1 << 30),
+                  "%s: row table must be a contiguous int32 [rows >= %d, 4] tensor", op, nb);
+    return 1;
+}
+
+template <typename K>
+int reserve_lds(const char *op, K kernel, size_t bytes)
+{
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    GENRE_REQUIRE(e == hipSuccess, "%s: cannot reserve %zu bytes of LDS", op, bytes);
+    return 1;
+}
+
+}  // namespace
+}  // namespace genre
+
+using namespace genre;
+
+extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tensor *out, const genre_tensor *segs,
+                                       const genre_tensor *rec_f, const genre_tensor *fwd_rows,
+                                       const genre_tensor *ray_ptr, const genre_tensor *ray_seg,
+                                       const genre_tensor *ray_pre, const genre_tensor *ps_scratch,
+                                       const genre_tensor *p_stash, const genre_tensor *mask, float pre_scale,
+                                       void *stream)
+{
+    const char *op = "render_bm_forward";
+    BmDims D{};
+    if (!check_bm(op, vox, out, segs, ray_ptr, ray_seg, ray_pre, D, false)) return 0;
+    if (!check_rows(op, D, fwd_rows)) return 0;
+    D.sx = vox->stride[2]; D.sy = vox->stride[3]; D.sz = vox->stride[4];
+    D.pre_scale = pre_scale;
+    GENRE_REQUIRE(is_i32(rec_f, 2) && rec_f->size[1] == kRec && is_contiguous(rec_f) && aligned16(rec_f->data),
+                  "%s: rec_f must be a contiguous int32 [S,12] tensor", op);
+    D.nslot = rec_f->size[0];
+    GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ps_scratch->size[0] >= (int64_t)D.groups * D.nseg * 2 * kImgs,
+                  "%s: ps_scratch must hold groups*nseg*64 floats", op);
+    const bool save = p_stash != nullptr;
+    if (save) {
+        GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] >= (int64_t)D.groups * D.nslot * kImgs,
+                      "%s: p_stash must hold groups*S*32 floats", op);
+        GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) &&
+                                            mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z),
+                      "%s: pre_scale with a saved state needs mask int32 [groups*X*Y*Z]", op);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // 1024 threads: 16 waves share one tile, two workgroups per CU = 8 waves per SIMD (measured 257 us against 318 with 512)
+    constexpr int nt = 1024;
+    const size_t lds = (size_t)kLinesF * kImgs * 4 + (size_t)(nt / 64) * (kMaxSeg + 1) * kRec * 4;
+    const dim3 grid((unsigned)fwd_rows->size[0], (unsigned)D.groups);
+#define GENRE_BM_SAMPLE_NT(PSV, SV, NTV)                                                                                  \
+    do {                                                                                                                  \
+        static const int ok_ = reserve_lds(op, &bm_sample_kernel<PSV, SV, NTV>, lds);                                     \
+        if (!ok_) return 0;                                                                                               \
+        bm_sample_kernel<PSV, SV, NTV><<<grid, NTV, lds, st>>>(                                                           \
+            D, (const float *)vox->data, (const int4 *)segs->data, (const int *)rec_f->data, (const int4 *)fwd_rows->data, \
+            (float *)ps_scratch->data, save ? (float *)p_stash->data : nullptr,                                           \
+            (save && pre_scale != 0.0f) ? (unsigned *)mask->data : nullptr);                                              \
+    } while (0)
+#define GENRE_BM_SAMPLE(PSV, SV) GENRE_BM_SAMPLE_NT(PSV, SV, nt)
+    if (pre_scale != 0.0f) { if (save) GENRE_BM_SAMPLE(true, true); else GENRE_BM_SAMPLE(true, false); }
+    else { if (save) GENRE_BM_SAMPLE(false, true); else GENRE_BM_SAMPLE(false, false); }
+#undef GENRE_BM_SAMPLE
+#undef GENRE_BM_SAMPLE_NT
+    GENRE_LAUNCH_CHECK("render_bm forward (bricks)");
+    bm_combine_fwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
+        D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
+        (const double2 *)ray_pre->data, view4(out));
+    GENRE_LAUNCH_CHECK("render_bm forward (rays)");
+    return 1;
+}
+
+extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genre_tensor *grad_vox,
+                                        const genre_tensor *segs, const genre_tensor *ray_ptr,
+                                        const genre_tensor *ray_seg, const genre_tensor *ray_pre,
+                                        const genre_tensor *ent, const genre_tensor *rec_b,
+                                        const genre_tensor *bwd_rows, const genre_tensor *depth_weight,
+                                        const genre_tensor *ps_scratch, const genre_tensor *tr_scratch,
+                                        const genre_tensor *p_stash, const genre_tensor *mask, float pre_scale,
+                                        void *stream)
+{
+    const char *op = "render_bm_backward";
+    BmDims D{};
+    if (!check_bm(op, grad_vox, grad_out, segs, ray_ptr, ray_seg, ray_pre, D, true)) return 0;
+    if (!check_rows(op, D, bwd_rows)) return 0;
+    D.gx = grad_vox->stride[2]; D.gy = grad_vox->stride[3]; D.gz = grad_vox->stride[4];
+    D.pre_scale = pre_scale;
+    GENRE_REQUIRE(is_i32(ent, 2) && ent->size[1] == 4 && is_contiguous(ent) && aligned16(ent->data), "%s: ent must be int32 [E,4]", op);
+    GENRE_REQUIRE(is_i32(rec_b, 2) && rec_b->size[1] == kRec && is_contiguous(rec_b) && aligned16(rec_b->data),
+                  "%s: rec_b must be a contiguous int32 [SB,12] tensor", op);
+    GENRE_REQUIRE(is_f32(depth_weight, 1) && is_contiguous(depth_weight), "%s: depth_weight must be fp32 [ZR]", op);
+    const int64_t per = (int64_t)D.groups * D.nseg * 2 * kImgs;
+    GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ps_scratch->size[0] >= per &&
+                      is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && tr_scratch->size[0] >= per,
+                  "%s: ps_scratch / tr_scratch must hold groups*nseg*64 floats", op);
+    GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] % kImgs == 0 && D.groups > 0 &&
+                      p_stash->size[0] / kImgs % D.groups == 0, "%s: p_stash must be the forward's [groups*S*32] buffer", op);
+    D.nslot = p_stash->size[0] / kImgs / D.groups;
+    GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) && mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z),
+                  "%s: pre_scale needs the forward's mask int32 [groups*X*Y*Z]", op);
+    hipStream_t st = (hipStream_t)stream;
+    bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
+        D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
+        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data);
+    GENRE_LAUNCH_CHECK("render_bm backward (rays)");
+    const int nb = ((D.X + kBX - 1) / kBX) * ((D.Y + kBY - 1) / kBY) * ((D.Z + kBZ - 1) / kBZ);
+    const dim3 grid((unsigned)bwd_rows->size[0], (unsigned)D.groups);
+    if (bwd_rows->size[0] > nb) {            // some bricks are split over several rows: those add atomically
+        bm_zero_shared_kernel<<<grid, kThreads, 0, st>>>(D, (const int4 *)bwd_rows->data, (float *)grad_vox->data);
+        GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");
+    }
+    const size_t lds = (size_t)kLinesB * kImgs * 8 + (size_t)kWavesB * kMaxSeg * kRec * 4 + (size_t)kLinesB * 4;
+#define GENRE_BM_SCATTER(PSV)                                                                                             \
+    do {                                                                                                                  \
+        static const int ok_ = reserve_lds(op, &bm_scatter_kernel<PSV>, lds);                                             \
+        if (!ok_) return 0;                                                                                               \
+        bm_scatter_kernel<PSV><<<grid, kThreadsB, lds, st>>>(                                                              \
+            D, (const int4 *)ent->data, (const int *)rec_b->data, (const int4 *)bwd_rows->data,                           \
+            (const float *)depth_weight->data, (const float *)tr_scratch->data, (const float *)p_stash->data,             \
+            pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr, (float *)grad_vox->data);                         \
+    } while (0)
+    if (pre_scale != 0.0f) GENRE_BM_SCATTER(true); else GENRE_BM_SCATTER(false);
+#undef GENRE_BM_SCATTER
+    GENRE_LAUNCH_CHECK("render_bm backward (bricks)");
+    return 1;
+}

@@ -119,69 +119,28 @@ def tables_for(vox_shape, device, dirs64, z_res):
     return t
 
 
-SUB = 2                 # log2 of the sub-brick edge of the batch-minor backward (4^3 voxels); matches kSub in sph_render.hip
-SUB_SPLIT = 512         # sub-brick rows above this many samples are split (atomic flush)
-
-
-def build_subbrick_table(X, Y, Z, dirs64, z_res, split=SUB_SPLIT):
-    """Geometry-only table of the batch-minor backward (csrc/sph_render.hip: render_bwd_sub_bm_kernel): for every
-    4^3-voxel sub-brick the samples with at least one trilinear corner inside it.
-
-      sub_rows  int32 [rows,4] = (sub-brick id (sx*nsy + sy)*nsz + sz, begin, end, shared), heaviest first; one row per
-                sub-brick, more when it holds over `split` samples (shared = 1: flushed with atomics onto zeroed voxels)
-      sub_list  int32 [S]      = (ray << 8) | k, per sub-brick sorted by (ray, k)
-
-    Same fp64/fp32 position arithmetic as the kernels (sample_pos, locate), so membership is exact."""
-    R = dirs64.shape[0]
-    assert z_res <= 256 and R * R < (1 << 24)
-    d2 = dirs64.reshape(-1, 3).astype(np.float64) * 2.0
-    step = 1.0 / (z_res - 1) if z_res > 1 else 0.0
-    alpha = np.arange(z_res, dtype=np.float64) * step
-    alpha[-1] = 1.0
-    a = 1.0 - alpha
-    one, two = np.float32(1), np.float32(2)
-    nsx, nsy, nsz = -(-X >> SUB), -(-Y >> SUB), -(-Z >> SUB)
-    axes = []
-    anyin = None
-    for ax, size in enumerate((X, Y, Z)):
-        g = (d2[:, None, ax] * a[None, :]).astype(np.float32)
-        i0 = np.floor(((g + one) / two) * np.float32(size - 1)).astype(np.int32)
-        inside = (i0 >= -1) & (i0 < size)
-        anyin = inside if anyin is None else (anyin & inside)
-        b0, v0 = i0 >> SUB, i0 >= 0
-        b1 = (i0 + 1) >> SUB
-        v1 = (i0 + 1 <= size - 1) & ((b1 != b0) | ~v0)
-        axes.append(((b0, v0), (b1, v1)))
-    sample_id = np.arange(R * R * z_res, dtype=np.int64).reshape(R * R, z_res)
-    keys = []
-    for cx in axes[0]:
-        for cy in axes[1]:
-            for cz in axes[2]:
-                m = anyin & cx[1] & cy[1] & cz[1]
-                if m.any():
-                    sb = (cx[0][m].astype(np.int64) * nsy + cy[0][m]) * nsz + cz[0][m]
-                    keys.append((sb << 32) | sample_id[m])
-    keys = np.sort(np.concatenate(keys)) if keys else np.zeros((0,), np.int64)
-    sid = keys & 0xFFFFFFFF
-    rows, words = _rows((keys >> 32).astype(np.int64), sid // z_res, sid % z_res, nsx * nsy * nsz, split, 1)
-    return dict(sub_rows=rows, sub_list=words)
-
-
-def sub_for(vox_shape, device, dirs64, z_res):
-    """sub-brick sample lists of the batch-minor backward, built on first use and cached"""
-    key = ("sub", tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device))
+def bm_tables_for(vox_shape, device, dirs64, depth_weight):
+    """tables of the batch-minor tile renderer (toolbox/_bm_tables.py), built on first use and cached per geometry and
+    device; the float64 per-ray prefix table travels as its fp32 words"""
+    from . import _bm_tables
+    dw = depth_weight.detach().cpu().numpy()
+    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], dw.shape[0], hash(dw.tobytes()), str(device))
     t = _TABLES.get(key)
     if t is None:
-        np_t = build_subbrick_table(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), z_res)
-        t = {k: torch.from_numpy(v).to(device) for k, v in np_t.items()}
+        np_t = _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), dw.shape[0], dw)
+        t = {}
+        for k, v in np_t.items():
+            tv = torch.from_numpy(np.ascontiguousarray(v))
+            if k == "ray_pre":
+                tv = tv.view(torch.float32).reshape(-1, 4)
+            t[k] = tv.to(device)
         _TABLES[key] = t
     return t
 
 
 def is_batch_minor(vox):
     """image index fastest in memory (the layout the batch-minor kernels of csrc/sph_render.hip want)"""
-    return (vox.dim() == 5 and vox.shape[1] == 1 and vox.shape[0] >= 16 and vox.stride(0) == 1
-            and vox.numel() < (1 << 30))
+    return vox.dim() == 5 and vox.shape[1] == 1 and vox.shape[0] >= 16 and vox.stride(0) == 1
 
 
 def empty_batch_minor(shape, dtype, device):
@@ -205,34 +164,52 @@ class RenderSphericalFused(Function):
         pad = int(pad)
         assert 0 <= 2 * pad <= res
         out = torch.empty((vox.shape[0], vox.shape[1], res + 2 * pad, res + 2 * pad), dtype=vox.dtype, device=vox.device)
+        ctx.pre_scale = float(pre_scale)
+        ctx.batch_minor = is_batch_minor(vox)
+        if ctx.batch_minor:
+            # image index fastest in memory: tile renderer, lanes = images (csrc/sph_render_bm.hip)
+            t = bm_tables_for(vox.shape, vox.device, dirs64, depth_weight)
+            groups = -(-vox.shape[0] // 32)
+            f32 = dict(dtype=torch.float32, device=vox.device)
+            ps = torch.empty((groups * t["segs"].shape[0] * 64,), **f32)
+            stash = mask = None
+            if ctx.needs_input_grad[0]:
+                stash = torch.empty((groups * t["rec_f"].shape[0] * 32,), **f32)
+                if pre_scale:
+                    mask = torch.empty((groups * vox.shape[2] * vox.shape[3] * vox.shape[4],), dtype=torch.int32,
+                                       device=vox.device)
+            lib.render_bm_forward(vox, out, t["segs"], t["rec_f"], t["fwd_rows"], t["ray_ptr"], t["ray_seg"],
+                                  t["ray_pre"], ps, stash, mask, ctx.pre_scale)
+            ctx.vox_shape = vox.shape
+            ctx.mask = mask
+            ctx.save_for_backward(dirs64, depth_weight, ps, stash)
+            return out
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
         rays = vox.shape[0] * vox.shape[1] * res * res
-        ctx.batch_minor = is_batch_minor(vox) and rays * z_res < (1 << 31)
-        # batch-minor volumes: 4 floats per ray and image behind the samples for the backward scan's anchors
-        v = torch.empty((rays * (z_res + 4) if ctx.batch_minor else rays * z_res,), dtype=torch.float32, device=vox.device)
+        v = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
         lib.render_spherical_forward(vox, dirs64.view(torch.float32), depth_weight, out,
                                      v, t["fwd_table"], t["fwd_chunks"], t["kin"], float(pre_scale))
         ctx.save_for_backward(vox, dirs64, depth_weight, v)
-        ctx.pre_scale = float(pre_scale)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        vox, dirs64, depth_weight, v = ctx.saved_tensors
         lib = _loader().render_lib
+        if ctx.batch_minor:
+            dirs64, depth_weight, ps, stash = ctx.saved_tensors
+            t = bm_tables_for(ctx.vox_shape, grad_out.device, dirs64, depth_weight)
+            grad_vox = empty_batch_minor(ctx.vox_shape, grad_out.dtype, grad_out.device)
+            lib.render_bm_backward(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], t["ent"],
+                                   t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,
+                                   ctx.pre_scale)
+            return grad_vox, None, None, None, None
+        vox, dirs64, depth_weight, v = ctx.saved_tensors
         z_res = depth_weight.shape[0]
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
         rays = vox.shape[0] * vox.shape[1] * dirs64.shape[0] * dirs64.shape[0]
-        if ctx.batch_minor:
-            c = sub_for(vox.shape, vox.device, dirs64, z_res)
-            grad_vox = empty_batch_minor(vox.shape, vox.dtype, vox.device)
-            scratch = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
-            lib.render_spherical_backward_bm(vox, dirs64.view(torch.float32), depth_weight, grad_out.contiguous(),
-                                             grad_vox, scratch, c["sub_rows"], c["sub_list"], v, t["kin"], ctx.pre_scale)
-            return grad_vox, None, None, None, None
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
-        scratch = torch.empty((rays * z_res + 4,), dtype=torch.float32, device=vox.device)
+        scratch = torch.empty((rays * z_res + vox.shape[0] * vox.shape[1],), dtype=torch.float32, device=vox.device)
         lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,
                                       scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"], ctx.pre_scale)
         return grad_vox, None, None, None, None

@@ -228,8 +228,9 @@ int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *
  * op chain).  grad_out [N,NC,R,R] -> grad_vox [N,NC,X,Y,Z], fully written.
  * Requires ZR <= 256.  Modes:
  *  - dp_scratch, brick_table, chunk_list given: brick-owned accumulation without
- *    global atomics.  dp_scratch: fp32 [>= N*NC*R*R*ZR + 4], 16-byte aligned (receives
- *    dL/dp per sample and, behind them, max|dL/dp| for the fixed-point scale).
+ *    global atomics.  dp_scratch: fp32 [>= N*NC*R*R*ZR + N*NC], 16-byte aligned (receives
+ *    dL/dp per sample and, behind them, each image's max|dL/dp| for its fixed-point scale;
+ *    an image with a non-finite dL/dp gets NaN gradients, as the reference chain would).
  *    brick_table: int32 [rows,4] = (brick id, begin, end, mode), every brick in >= 1 row;
  *    mode 0: the row is the brick's only one, mode 1: the brick's samples are split over
  *    several rows.  chunk_list: as fwd_chunks, but a brick's rows cover every sample with
@@ -245,27 +246,47 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
                                     const genre_tensor *v_scratch, const genre_tensor *kin,
                                     float pre_scale, void *stream);
 
-/* Batch-minor layout (extension).  When vox is laid out with the image index fastest in memory
- * (stride[0] == 1 with NC == 1; element (n,x,y,z) at ((x*Y + y)*Z + z)*N + n) and holds >= 16 images,
- * genre_render_spherical_forward (brick tables given) runs kernels in which a half-wave is 32 IMAGES
- * of one sample / one ray: full-line loads and stores, per-lane serial scans.  v_scratch is then laid
- * out [ray*ZR + k][image]; if it has room for 4 more floats per ray and image (>= rays*(ZR+4)) the
- * forward also leaves the anchors the backward below needs.  Results agree with the standard layout to
- * fp32 rounding (the scan order differs), not bit for bit. */
+/* ---- batch-minor tile renderer (extension; csrc/sph_render_bm.hip) ------------------------------
+ *
+ * The same operator for BATCHES whose volume is laid out with the image index fastest in memory:
+ * vox [N,1,X,Y,Z] with stride[0] == 1 (element (n,x,y,z) at x*sx + y*sy + z*sz + n; e.g. memory order
+ * (X,Y,Z,N)).  32 lanes = 32 images of one sample; all geometry comes from tables built once per geometry
+ * (genre-shapehd_amd/toolbox/_bm_tables.py: build_bm_tables -- formats are documented there and repeated here):
+ *   segs      int32 [nseg,4]  (ray, first sample k0, length L, slot of the first sample); a segment = a run of
+ *                             consecutive samples of one ray whose base voxel lies in one 4x8x8-voxel brick (L <= 16);
+ *                             sorted by (brick, ray, k0); slots number the in-volume samples in that order
+ *   rec_f     int32 [S,12]    per slot: byte offset of the base voxel line in the brick's 5x9x9 x 32-image fp32 tile,
+ *                             depth_weight[k] (fp32 bits), 0, 0, the 8 trilinear weights (x fastest, then y, then z)
+ *   fwd_rows  int32 [rows,4]  (brick, seg begin, seg end, 0): one workgroup each; every brick in >= 1 row
+ *   ray_ptr   int32 [R*R+1], ray_seg int32 [nseg]: the segments of each ray in sample order
+ *   ray_pre   float64 [R*R,2] viewed as fp32 [R*R,4]: (transmittance, partial sum) of the samples before the ray
+ *                             enters the volume (p = 1e-5 each)
+ *   ent       int32 [E,4]     (segment, slot of its first sample, i0 | i1<<6 | L<<12 | k0<<18, rec_b slot of sample i0):
+ *                             samples i0..i1-1 of the segment have a
+ *                             corner inside the brick of the row that lists the entry
+ *   rec_b     int32 [SB,12]   byte offset in the brick's own 4x8x8 x 32-image fp64 tile, ownership bits
+ *                             (bit c + 4h: corner (x,y) = c of z half h belongs to this brick), 0, 0, 8 weights
+ *   bwd_rows  int32 [rows,4]  (brick, ent begin, ent end, shared): shared = 1 rows add onto pre-zeroed voxels
+ * Scratch (caller-allocated, groups = ceil(N/32)):
+ *   ps_scratch fp32 [groups*nseg*64]: per segment and image (prod(1-p), sum T p w) -- forward output, backward input
+ *   p_stash    fp32 [groups*S*32] or NULL: clamped sample values (negated where the clamp blocks the gradient);
+ *              pass it when a backward will follow;  mask int32 [groups*X*Y*Z] (with p_stash and pre_scale != 0):
+ *              bit i = image i passes clamp(vox*pre_scale)
+ *   tr_scratch fp32 [groups*nseg*64]: backward only
+ * out / grad_out [N,1,R+2p,R+2p] (p = padding margin as above, any strides); pre_scale as above.
+ * grad_vox must be batch-minor too (stride[0] == 1); every element is written exactly once. */
+int genre_render_bm_forward(const genre_tensor *vox, const genre_tensor *out, const genre_tensor *segs,
+                            const genre_tensor *rec_f, const genre_tensor *fwd_rows, const genre_tensor *ray_ptr,
+                            const genre_tensor *ray_seg, const genre_tensor *ray_pre,
+                            const genre_tensor *ps_scratch, const genre_tensor *p_stash, const genre_tensor *mask,
+                            float pre_scale, void *stream);
 
-/* Backward of the fused renderer for that layout: a reverse scan writes dL/dp [ray*ZR + k][image] into dp_scratch
- * (>= rays*ZR floats; v_scratch must be the forward's buffer with its anchors), then a wave owns a 4^3-voxel sub-brick, keeps
- * its gradients for 32 images in LDS (lanes = images, so no atomics) and walks the samples that touch it:
- *   sub_rows : int32 [rows,4] = (sub-brick (sx*nsy + sy)*nsz + sz, begin, end, shared); every sub-brick present,
- *              split rows (shared = 1) flush with float atomics onto voxels zeroed by a pre-pass
- *   sub_list : int32 [S] = (ray << 8) | k, per sub-brick sorted by (ray, k)
- * Builder: genre-shapehd_amd/toolbox/_fused_render.py: build_subbrick_table. */
-int genre_render_spherical_backward_bm(const genre_tensor *vox, const genre_tensor *dirs,
-                                       const genre_tensor *depth_weight, const genre_tensor *grad_out,
-                                       const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
-                                       const genre_tensor *sub_rows, const genre_tensor *sub_list,
-                                       const genre_tensor *v_scratch, const genre_tensor *kin, float pre_scale,
-                                       void *stream);
+int genre_render_bm_backward(const genre_tensor *grad_out, const genre_tensor *grad_vox, const genre_tensor *segs,
+                             const genre_tensor *ray_ptr, const genre_tensor *ray_seg, const genre_tensor *ray_pre,
+                             const genre_tensor *ent, const genre_tensor *rec_b, const genre_tensor *bwd_rows,
+                             const genre_tensor *depth_weight, const genre_tensor *ps_scratch,
+                             const genre_tensor *tr_scratch, const genre_tensor *p_stash, const genre_tensor *mask,
+                             float pre_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -117,6 +117,105 @@ class RenderSphericalCPU(torch.nn.Module):
         return exp_depth + torch.prod(1.0 - prob, dim=4)
 
 
+class RenderSphericalF64(torch.nn.Module):
+    """spherical_proj.py:31-72 evaluated in float64 on CPU torch (closed forms of calc_prob_kernel.cu:129-141): the
+    yardstick for how far an fp32 implementation (the reference's op sequence, the fused kernels) sits from the exact
+    value.  samples="fp32" (default): the trilinear SAMPLE VALUES are the fp32 ones every fp32 implementation computes
+    (ATen grid_sampler_3d in float32 -- the reference's own arithmetic), promoted to double; everything downstream
+    (clamp, transmittance, expectation) and the whole adjoint are float64.  That separates the error of the scans
+    and of the gradient accumulation -- what the kernels are responsible for -- from the 2^-24 rounding of the sample
+    values, which the clamp bounds and 1/(1-p) amplify identically for every fp32 implementation.  samples="fp64":
+    the samples are interpolated in double as well."""
+
+    def __init__(self, sph_res=128, z_res=256, samples="fp32"):
+        super().__init__()
+        grid, dw = render_grid(sph_res, z_res)
+        self.grid32, self.grid, self.depth_weight = grid, grid.double(), dw.double()
+        self.lo, self.hi = float(np.float32(1e-5)), float(np.float32(1 - 1e-5))
+        self.samples = samples
+
+    def forward(self, vox):
+        v64 = vox.double().permute(0, 1, 4, 3, 2)
+        kw = dict(mode="bilinear", padding_mode="zeros", align_corners=True)
+        prob = torch.nn.functional.grid_sample(v64, self.grid.expand(vox.shape[0], -1, -1, -1, -1), **kw)
+        if self.samples == "fp32":
+            with torch.no_grad():
+                p32 = torch.nn.functional.grid_sample(vox.detach().float().permute(0, 1, 4, 3, 2),
+                                                      self.grid32.expand(vox.shape[0], -1, -1, -1, -1), **kw).double()
+            prob = prob + (p32 - prob).detach()            # fp32 sample values, float64 adjoint
+        prob = torch.clamp(prob, self.lo, self.hi)
+        q = 1.0 - prob
+        trans = torch.cumprod(q, dim=4)
+        before = torch.cat((torch.ones_like(trans[..., :1]), trans[..., :-1]), dim=4)     # prod_{j<k} (1 - p_j)
+        stop = prob * before
+        return torch.matmul(stop, self.depth_weight) + trans[..., -1]
+
+
+class _RenderExact(Function):
+    """float64 evaluation of the reference's fp32-DEFINED operator: the trilinear sample values are ATen's float32
+    ones (torch grid_sample on CPU -- the op the reference calls, spherical_proj.py:65) and the adjoint uses ATen's
+    float32 corner weights (its float32 coordinate arithmetic is part of the operator: at |ix| ~ 100 one ulp is
+    8e-6, so float64-interpolated weights describe a slightly different operator), but every product and every sum
+    -- transmittance, expectation, dL/dp, and the accumulation of up to 2^17 contributions per voxel -- is float64."""
+
+    @staticmethod
+    def forward(ctx, vox, grid32, depth_weight):
+        n, c, X, Y, Z = vox.shape
+        assert c == 1
+        kw = dict(mode="bilinear", padding_mode="zeros", align_corners=True)
+        v32 = torch.nn.functional.grid_sample(vox.detach().float().permute(0, 1, 4, 3, 2),
+                                              grid32.expand(n, -1, -1, -1, -1), **kw)[:, 0].double().numpy()
+        lo, hi = float(np.float32(1e-5)), float(np.float32(1 - 1e-5))
+        p = np.clip(v32, lo, hi)                                            # [n, R, R, ZR]
+        w = depth_weight.double().numpy()
+        trans = np.cumprod(1.0 - p, axis=-1)
+        before = np.concatenate((np.ones_like(trans[..., :1]), trans[..., :-1]), -1)
+        s = p * before
+        out = (s * w).sum(-1) + trans[..., -1]
+        ctx.state = (v32, p, before, s, w, trans[..., -1], grid32.numpy(), (X, Y, Z))
+        return torch.from_numpy(out)[:, None]
+
+    @staticmethod
+    def backward(ctx, g):
+        v32, p, before, s, w, tail, grid, (X, Y, Z) = ctx.state
+        lo, hi = float(np.float32(1e-5)), float(np.float32(1 - 1e-5))
+        gd = g[:, 0].double().numpy()[..., None]
+        sw = s * w
+        after = np.flip(np.cumsum(np.flip(sw, -1), -1), -1) - sw + tail[..., None]       # sum_{j>k} s_j w_j + prod(1-p)
+        dp = gd * (before * w - after / (1.0 - p)) * ((v32 >= lo) & (v32 <= hi))
+        # ATen grid_sampler_3d corner indices and float32 weights (align_corners=True); grid x -> X axis
+        one, two = np.float32(1), np.float32(2)
+        idx, wts = [], []
+        for ax, size in enumerate((X, Y, Z)):
+            ix = ((grid[..., ax] + one) / two) * np.float32(size - 1)
+            f = np.floor(ix)
+            idx.append(f.astype(np.int64))
+            wts.append(((f + one) - ix, ix - f))
+        grad = np.zeros((gd.shape[0], X * Y * Z))
+        for cnr in range(8):
+            b = (cnr & 1, (cnr >> 1) & 1, (cnr >> 2) & 1)
+            ci = [idx[a] + b[a] for a in range(3)]
+            ok = np.ones(ci[0].shape, bool)
+            for a, size in enumerate((X, Y, Z)):
+                ok &= (ci[a] >= 0) & (ci[a] < size)
+            wc = ((wts[0][b[0]] * wts[1][b[1]]) * wts[2][b[2]]).astype(np.float64)      # ATen: (wx * wy) * wz in float32
+            lin = ((ci[0] * Y + ci[1]) * Z + ci[2])[ok]
+            for i in range(gd.shape[0]):
+                grad[i] += np.bincount(lin, weights=(wc * dp[i])[ok], minlength=X * Y * Z)
+        return torch.from_numpy(grad.reshape(gd.shape[0], 1, X, Y, Z)), None, None
+
+
+class RenderSphericalExact(torch.nn.Module):
+    """the yardstick of the gradient parity tests (see _RenderExact); vox [N,1,X,Y,Z] -> float64 [N,1,R,R]"""
+
+    def __init__(self, sph_res=128, z_res=256):
+        super().__init__()
+        self.grid, self.depth_weight = render_grid(sph_res, z_res)
+
+    def forward(self, vox):
+        return _RenderExact.apply(vox.double(), self.grid, self.depth_weight)
+
+
 def sph_pad(sph, pm=16):
     """spherical_proj.py:21-28"""
     out = torch.nn.functional.pad(sph, (pm, pm, pm, pm), mode="replicate")

@@ -33,7 +33,7 @@ T = _fused_render.tables_for(tdf.shape, dev, mod._dirs64, 256)
 out = torch.empty((B, 1, 128, 128), device=dev)
 gout = torch.randn_like(out)
 vbuf = torch.empty((B * 128 * 128 * 256,), device=dev)
-scratch = torch.empty((vbuf.numel() + 4,), device=dev)
+scratch = torch.empty((vbuf.numel() + max(4, B),), device=dev)
 gvox = torch.empty_like(tdf)
 lib = _fused_render._loader().render_lib
 for _ in range(3):

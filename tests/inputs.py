@@ -101,3 +101,28 @@ def clouds(b=1, n=2048, m=2048, seed1=0, seed2=1):
     x1 = np.random.default_rng(seed1).random((b, n, 3), dtype=np.float32)
     x2 = np.random.default_rng(seed2).random((b, m, 3), dtype=np.float32)
     return x1, x2
+
+
+def genre_offclamp_volumes(oracle, n, seed=40, margin=3e-5, solid_margin=None):
+    """GenRe-class near-binary occupancy volumes whose values stay OFF the clamp bounds of render_spherical:
+    clamp(shift_tdf(cam_bp(depth)) * 50) (depth_pred_with_sph_inpaint.py:120-124) of n different noisy spheres with
+    the empty level lifted to margin*(1+u) and the solid level lowered to 1 - margin*(1+u'), u seeded per voxel.
+    Every trilinear sample of such a field lies strictly inside (1e-5, 1-1e-5) (except the few rays that graze the
+    zero-padded faces of the cube), so the clamp derivative is continuous there and gradients can be compared --
+    while the transmittance still underflows behind the surface and dL/dp spans many orders of magnitude, which
+    is what the kernels have to survive.  `solid_margin` lowers the solid level further (1 - solid_margin*(1+u')):
+    with 1 - p ~ 3e-5 a ONE-ulp difference in a sampled value (6e-8) changes 1 - p by 2e-3 relative, so two correct
+    fp32 implementations that add the eight trilinear terms in a different order already differ by ~1e-3 in the
+    gradient; solid_margin = 0.02 keeps the field near-binary but conditions the gradient well enough for a 1e-5
+    comparison.  float32 [n,1,128,128,128]."""
+    rng = np.random.default_rng(seed)
+    d = batch_depth(n, seed=seed + 1)
+    fl, cd = cam_params(n)
+    out = np.empty((n, 1, RES, RES, RES), np.float32)
+    for i in range(n):
+        tdf, _ = oracle.back_projection_forward(d[i:i + 1], cd[i:i + 1], fl[i:i + 1])
+        occ = np.clip((1 - RES * tdf) * 50, 0.0, 1.0)
+        lo = margin * (1 + rng.random(occ.shape))
+        hi = 1 - (margin if solid_margin is None else solid_margin) * (1 + rng.random(occ.shape))
+        out[i] = (lo + occ * (hi - lo)).astype(np.float32)[0]
+    return out

@@ -1,0 +1,57 @@
+"""CPU checks of the batch-minor tile renderer's host side (genre-shapehd_amd/toolbox/_bm_tables.py): the tables, walked by
+a plain-numpy emulation of the kernels' data flow (tests/bm_emulation.py), must reproduce the reference chain
+(toolbox/spherical_proj.py:62-72 on CPU torch + the C oracle's calc_prob) forward and backward."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bm_emulation as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mod():
+    # the table builder is pure numpy: load it without importing the package (which needs libgenre_hip.so)
+    spec = importlib.util.spec_from_file_location("_bm_tables", os.path.join(ROOT, "genre-shapehd_amd", "toolbox", "_bm_tables.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _field(res, seed):
+    rng = np.random.default_rng(seed)
+    ax = (np.arange(res) + 0.5) / res - 0.5
+    r2 = ax[:, None, None] ** 2 + (ax[None, :, None] - 0.07) ** 2 + (ax[None, None, :] + 0.04) ** 2
+    return (0.003 + 0.9 * (r2 < 0.05) + rng.uniform(0, 0.02, (res,) * 3)).astype(np.float32)
+
+
+@pytest.mark.parametrize("res,sph,zr,pre_scale,split", [(16, 8, 32, 0.0, None), (20, 10, 48, 0.0, 64), (13, 6, 24, 3.0, 40)])
+def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, oracle):
+    from oracle.torch_oracle import RenderSphericalCPU, unit_dirs
+    m = _mod()
+    dw = np.linspace(0, 1, zr).astype(np.float32)
+    dw = torch.linspace(0, 1, zr).numpy()
+    kw = {} if split is None else dict(split_f=split, split_b=split)
+    t = m.build_bm_tables(res, res, res, unit_dirs(sph), zr, dw, **kw)
+    vox = _field(res, res)
+    if pre_scale:
+        vox = (vox / np.float32(pre_scale) * np.float32(1.3)).astype(np.float32)       # some voxels clamp, some do not
+    out, PS, stash, mask = E.forward(m, t, vox, pre_scale)
+    vt = torch.from_numpy(vox[None, None]).requires_grad_(True)
+    vin = vt if not pre_scale else torch.clamp(vt * pre_scale, 1e-5, 1 - 1e-5)
+    ref = RenderSphericalCPU(oracle, sph, zr)(vin)
+    assert np.abs(out - ref.detach().numpy().reshape(-1)).max() <= 1e-5
+    g = np.random.default_rng(1).standard_normal(sph * sph).astype(np.float32)
+    ref.backward(torch.from_numpy(g).reshape(ref.shape))
+    grad = E.backward(m, t, vox.shape, PS, stash, mask, g, dw, pre_scale)
+    gr = vt.grad[0, 0].numpy()
+    assert (np.abs(grad - gr) / np.maximum(1, np.abs(gr))).max() <= 2e-5
+    # structure: segments partition the in-volume samples, rows cover all bricks
+    assert t["segs"][:, 2].sum() == t["rec_f"].shape[0] and t["segs"][:, 2].max() <= m.MAXSEG
+    pk = t["ent"][:, 2]
+    assert (((pk >> 6) & 63) - (pk & 63)).sum() == t["rec_b"].shape[0]
+    nb = -(-res // m.BX) * -(-res // m.BY) * -(-res // m.BZ)
+    assert set(t["fwd_rows"][:, 0]) == set(range(nb)) and set(t["bwd_rows"][:, 0]) == set(range(nb))

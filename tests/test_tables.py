@@ -64,32 +64,64 @@ def test_brick_tables_cover_exactly_the_in_volume_samples(res, sph, zr):
     assert pairs == expect
 
 
-def test_subbrick_table_lists_every_touching_sample():
-    res, sph, zr = 20, 10, 24
+@pytest.mark.parametrize("res,sph,zr", [(20, 10, 24), (33, 8, 40)])
+def test_bm_listing_names_every_touching_sample_once_per_brick(res, sph, zr):
+    """batch-minor tile renderer (toolbox/_bm_tables.py): a brick's backward entries list exactly the samples with a
+    weighted corner inside it, the ownership bits mark exactly those corners, segments partition the rays"""
+    from genre_shapehd_amd.toolbox import _bm_tables as B
     mod = G.render_spherical(sph_res=sph, z_res=zr, fused=False)
     dirs = mod._dirs64.numpy()
-    t = F.build_subbrick_table(res, res, res, dirs, zr, split=64)
+    t = B.build_bm_tables(res, res, res, dirs, zr, mod.depth_weight.numpy(), split_f=50, split_b=40)
     cells, inside = brute_force(res, res, res, dirs, zr)
-    ns = -(-res >> F.SUB)
-    words = t["sub_list"].view(np.uint32)
-    pairs = set()
-    seen_sub = set()
-    for sb, beg, end, shared in t["sub_rows"]:
-        assert end - beg <= 64 or not shared
-        seen_sub.add(int(sb))
-        qq, kk = (words[beg:end] >> 8).astype(np.int64), (words[beg:end] & 255).astype(np.int64)
-        pairs.update(zip([int(sb)] * (end - beg), (qq * zr + kk).tolist()))
-    assert seen_sub == set(range(ns ** 3))                                   # every sub-brick has a row (gets written)
-    expect = set()
+    assert np.array_equal(inside, np.arange(zr)[None, :] >= t["kin"][:, None])
+    nbr = (-(-res // B.BX), -(-res // B.BY), -(-res // B.BZ))
+    bs = (B.BX, B.BY, B.BZ)
+    segs = t["segs"]
+    # segments: consecutive samples of one ray, every in-volume sample in exactly one, per ray in order
+    seen = np.zeros(inside.shape, int)
+    for q, k0, L, slot0 in segs:
+        seen[q, k0:k0 + L] += 1
+    assert np.array_equal(seen, inside.astype(int))
+    for q in range(sph * sph):
+        ids = t["ray_seg"][t["ray_ptr"][q]:t["ray_ptr"][q + 1]]
+        assert (segs[ids, 0] == q).all() and (np.diff(segs[ids, 1]) > 0).all()
+        assert segs[ids, 2].sum() == inside[q].sum()
+    # expected (brick, sample, corner) triples: corners inside the volume; the -1 corner of a low-side sample is padding
+    expect = {}
     qs, ks = np.nonzero(inside)
-    for dx in (0, 1):
-        for dy in (0, 1):
-            for dz in (0, 1):
-                x, y, z = cells[0][qs, ks] + dx, cells[1][qs, ks] + dy, cells[2][qs, ks] + dz
-                ok = (x >= 0) & (x < res) & (y >= 0) & (y < res) & (z >= 0) & (z < res)
-                sid = ((x[ok] >> F.SUB) * ns + (y[ok] >> F.SUB)) * ns + (z[ok] >> F.SUB)
-                expect.update(zip(sid.tolist(), (qs[ok] * zr + ks[ok]).tolist()))
-    assert pairs == expect
+    for c in range(8):
+        d = (c & 1, (c >> 1) & 1, (c >> 2) & 1)
+        xyz = [cells[a][qs, ks] + d[a] for a in range(3)]
+        ok = np.ones(len(qs), bool)
+        for a in range(3):
+            ok &= (xyz[a] >= 0) & (xyz[a] < res)
+        bid = ((xyz[0][ok] // bs[0]) * nbr[1] + xyz[1][ok] // bs[1]) * nbr[2] + xyz[2][ok] // bs[2]
+        for b_, q_, k_ in zip(bid.tolist(), qs[ok].tolist(), ks[ok].tolist()):
+            expect.setdefault((b_, q_ * zr + k_), set()).add(c)
+    got = {}
+    for b_, e0, e1, shared in t["bwd_rows"]:
+        for s_, slot0_, pk, rs in t["ent"][e0:e1]:
+            q, k0, L, slot0 = segs[s_]
+            i0, i1 = pk & 63, (pk >> 6) & 63
+            assert ((pk >> 12) & 63, (pk >> 18) & 255, slot0_) == (L, k0, slot0)
+            assert 0 <= i0 < i1 <= L
+            for i in range(i0, i1):
+                own = int(t["rec_b"][rs + i - i0, 1])
+                key = (int(b_), int(q) * zr + int(k0) + i)
+                assert key not in got
+                got[key] = own
+    assert set(got) == set(expect)
+    # ownership bits <-> corners.  A low-side sample (base -1) is re-based on voxel 0: its real corner moves from
+    # bit 1 to bit 0 of that axis and the other one carries weight 0 and is not owned
+    for key, own in got.items():
+        q, k = divmod(key[1], zr)
+        low = [cells[a][q, k] == -1 for a in range(3)]
+        want = 0
+        for c in expect[key]:
+            bits = [(c >> a) & 1 for a in range(3)]
+            bits = [0 if low[a] else bits[a] for a in range(3)]
+            want |= 1 << ((bits[0] | (bits[1] << 1)) + 4 * bits[2])
+        assert own == want, (key, own, want)
 
 
 def test_row_splitting_keeps_order_and_flags():
