@@ -39,15 +39,39 @@ BYTES_CP_BWD_FUSED = 4 * 128 * 128 * 256 * 4              # p, s, grad in + grad
 BYTES_RENDER_FUSED = 128 ** 3 * 4 + 128 * 128 * 4         # vox in + map out           =  8 454 144
 
 
-# profiles/r01g_pmc_hbm_traffic.txt, bytes per launch at batch 32 (kernel groups as in kernel_table)
-PMC_TRAFFIC_SOURCE = "profiles/r01g_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-PMC_TRAFFIC_B32 = {
-    "render_bwd_fused": 710.1e6 + 1296.3e6 + 96.2e6,     # scan_bwd + bwd_brick + zero_shared_bricks
-    "render_fwd_fused": 1017.7e6 + 367.5e6,              # sample_brick_group + scan_fwd
-    "calc_prob_fwd": 1073.8e6,
-    "calc_prob_bwd_fused": 2147.7e6,
-    "cam_bp_fwd": 538.9e6 + 24.3e6 + 50.5e6,             # fill + scatter_tile + normalise_tile
-}
+def source_sha():
+    """sha256 over the kernel sources: identifies the code a PMC table was measured on (the GPU box has no .git)"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "genre-shapehd_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_names, batch):
+    """HBM bytes per launch of a kernel group from the newest committed PMC table (profiles/*_pmc_hbm_traffic.json,
+    written by profiles/collect_pmc.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes).  None -- never a stale number -- unless the table was measured on exactly these
+    kernel sources and this batch size."""
+    import glob
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    if not tables:
+        return None, None
+    with open(tables[-1]) as f:
+        t = json.load(f)
+    if t.get("source_sha") != source_sha() or t.get("batch") != batch:
+        return None, "%s is for sources %s / batch %s, not %s / %d" % (
+            os.path.basename(tables[-1]), t.get("source_sha"), t.get("batch"), source_sha(), batch)
+    total = 0.0
+    for k in kernel_names:
+        row = t["kernels"].get(k)
+        if row is None:
+            return None, "%s has no row for %s" % (os.path.basename(tables[-1]), k)
+        total += row["hbm_bytes"]
+    return total, "profiles/" + os.path.basename(tables[-1])
 
 
 def parse():
@@ -59,7 +83,51 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="force the reference op sequence in render_spherical")
+    ap.add_argument("--layout", choices=["bm", "std"], default="bm",
+                    help="memory order of the projected volume between cam_bp and the renderer: bm = image index fastest "
+                         "(batch-minor tile renderer, batches >= 16), std = the reference's NCXYZ")
+    ap.add_argument("--no-m1", action="store_true", help="skip the GenRe whole-model forward (M1)")
+    ap.add_argument("--stub", action="store_true", help="launcher self-test: a trivial CPU step over gloo, no GPU")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) without a torchrun environment: re-execute under torch.distributed.run, one
+    rank per GPU, and hand its exit code back"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def stub_main(args):
+    """the launcher path with a trivial CPU step (tests/test_bench_launcher.py): init from the torchrun environment,
+    barrier-bracketed timing, max over ranks, one JSON line from rank 0"""
+    from importlib import util as _u
+    spec = _u.spec_from_file_location("dist_utils", os.path.join(ROOT, "genre-shapehd_amd", "dist_utils.py"))
+    du = _u.module_from_spec(spec)
+    spec.loader.exec_module(du)
+    rank, _, world = du.env_rank_world()
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    dist = du.init_from_env("gloo")
+    x = torch.ones(64, 64)
+    du.fence(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = (x @ x).clamp_(max=1.0)
+    du.fence(dist)
+    el = du.max_over_ranks(dist, time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": world * args.batch * args.steps / el, "unit": "shapes/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "stub": True}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 class HotPath(torch.nn.Module):
@@ -78,11 +146,21 @@ class HotPath(torch.nn.Module):
         return self.render(proj, pre_scale=50.0, pad=16)
 
 
-def event_time_us(fn, iters, warm):
-    """average duration of fn() in microseconds, HIP events on the current (launch) stream"""
+def event_time_us(fn, iters, warm, min_seconds=0.5):
+    """average duration of fn() in microseconds, HIP events on the current (launch) stream; the measured loop runs for
+    at least min_seconds (so that an SMI sampler sees the GPU busy and clocks settle)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if min_seconds:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        est = max(a.elapsed_time(b) / 3 * 1e-3, 1e-7)
+        iters = int(min(max(iters, min_seconds / est), 20000))
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
@@ -106,14 +184,16 @@ def kernel_table(G, dev, B):
     s = torch.empty_like(p)
     g = torch.randn_like(p)
     o = torch.empty_like(p)
-    iters = max(20, 400 // B)
+    iters = 20
     rows = {}
     t = event_time_us(lambda: cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt), iters, 5)
-    rows["cam_bp_fwd"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="fill2_vec4+scatter_tile+normalise_tile")
+    rows["cam_bp_fwd"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="fill2_vec4+scatter_tile+normalise_tile",
+                              pmc=["fill2_vec4_kernel", "scatter_tile_kernel<false>", "normalise_tile_kernel<false>"])
     t = event_time_us(lambda: calc_prob_lib.calc_prob_forward(p, s), iters, 5)
-    rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel")
+    rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel", pmc=["stop_fwd_vec4_kernel"])
     t = event_time_us(lambda: calc_prob_lib.calc_prob_backward_fused(p, s, g, o), iters, 5)
-    rows["calc_prob_bwd_fused"] = dict(us=t, bytes=B * BYTES_CP_BWD_FUSED, kernels="stop_bwd_vec4_kernel<fused>")
+    rows["calc_prob_bwd_fused"] = dict(us=t, bytes=B * BYTES_CP_BWD_FUSED, kernels="stop_bwd_vec4_kernel<fused>",
+                                       pmc=["stop_bwd_vec4_kernel<true>"])
     from genre_shapehd_amd.toolbox import _fused_render
     fused_ok = _fused_render.available()
     if fused_ok:
@@ -131,12 +211,44 @@ def kernel_table(G, dev, B):
         t = event_time_us(lambda: render_lib.render_spherical_forward(
             proj, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0), iters, 5)
         rows["render_fwd_fused"] = dict(us=t, bytes=B * BYTES_RENDER_FUSED,
-                                        kernels="render_sample_brick_group_kernel+render_scan_fwd_kernel")
+                                        kernels="render_sample_brick_group_kernel+render_scan_fwd_kernel",
+                                        pmc=["render_sample_brick_group_kernel<2, 512>", "render_scan_fwd_kernel"])
         t = event_time_us(lambda: render_lib.render_spherical_backward(
             proj, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"], vbuf, T["kin"], 50.0),
             iters, 5)
         rows["render_bwd_fused"] = dict(us=t, bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                                        kernels="render_scan_bwd_kernel+render_bwd_brick_kernel")
+                                        kernels="render_scan_bwd_kernel+zero_shared_bricks_kernel+render_bwd_brick_kernel",
+                                        pmc=["render_scan_bwd_kernel", "zero_shared_bricks_kernel", "render_bwd_brick_kernel"])
+        if B >= 16:     # batch-minor tile renderer (csrc/sph_render_bm.hip): the volume with the image index fastest
+            layer = G.Camera_back_projection_layer(batch_minor=True).to(dev)
+            with torch.no_grad():
+                proj_bm = layer(d)
+            TB = _fused_render.bm_tables_for(proj_bm.shape, dev, mod._dirs64, mod.depth_weight)
+            groups = -(-B // 32)
+            ps = torch.empty((groups * TB["segs"].shape[0] * 64,), device=dev)
+            tr = torch.empty_like(ps)
+            stash = torch.empty((groups * TB["rec_f"].shape[0] * 32,), device=dev)
+            mask = torch.empty((groups * 128 ** 3,), dtype=torch.int32, device=dev)
+            out_p = torch.empty((B, 1, 160, 160), device=dev)
+            gout_p = torch.randn_like(out_p)
+            gvox_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
+
+            def bm_fwd(save):
+                render_lib.render_bm_forward(proj_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"],
+                                             TB["ray_seg"], TB["ray_pre"], ps, stash if save else None,
+                                             mask if save else None, 50.0)
+            rows["render_fwd_bm"] = dict(us=event_time_us(lambda: bm_fwd(True), iters, 5), bytes=B * BYTES_RENDER_FUSED,
+                                         kernels="bm_sample_kernel+bm_combine_fwd_kernel",
+                                         pmc=["bm_sample_kernel<true, true, 1024>", "bm_combine_fwd_kernel"])
+            rows["render_fwd_bm_nosave"] = dict(us=event_time_us(lambda: bm_fwd(False), iters, 5),
+                                                bytes=B * BYTES_RENDER_FUSED, kernels="bm_sample_kernel (no saved state)")
+            rows["render_bwd_bm"] = dict(
+                us=event_time_us(lambda: render_lib.render_bm_backward(
+                    gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"], TB["rec_b"],
+                    TB["bwd_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0), iters, 5),
+                bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
+                kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+bm_scatter_kernel",
+                pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel", "bm_scatter_kernel<true>"])
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3
     # forward-only chain (inference) at this batch size, standard layout and batch-minor layout
@@ -270,6 +382,30 @@ def batch1_graph(G, dev):
     return res
 
 
+def m1_genre_forward(G, dev):
+    """BASELINE.json metric, first half: GenRe forward passes per second, 256x256 RGB -> 128^3 voxels, on one GPU.
+    The reference's full model (models/genre_full_model.py:116-132: MarrNet-1, the geometric ops, the inpainting
+    U-ResNet, the spherical back-projection, Unet_3D) with seeded random weights (no checkpoint ships),
+    eval mode, no_grad; batch 1 and batch 8, each captured once in a HIP graph and replayed."""
+    from genre_shapehd_amd.models import GenReNet, GenReInference
+    torch.manual_seed(0)
+    net = GenReNet().to(dev).eval()
+    res = {"what": "GenRe full-model forward (3 networks + geometric ops), random weights, fp32, HIP-graph replay",
+           "target_fwd_per_s_batch1": 50.0}
+    for n in (1, 8):
+        inf = GenReInference(net, device=dev, graph=True)
+        rgb = torch.rand(n, 3, 256, 256, device=dev)
+        sil = torch.zeros(n, 1, 256, 256, device=dev)
+        sil[:, :, 48:208, 48:208] = 100.0
+        inf.predict(rgb, sil)                                             # capture
+        g = inf._captured[tuple(rgb.shape)][0]
+        us = event_time_us(g.replay, 10, 2)
+        eager = GenReInference(net, device=dev, graph=False)
+        us_eager = event_time_us(lambda: eager.predict(rgb, sil), 10, 2)
+        res["batch%d" % n] = {"ms_per_forward": us / 1e3, "shapes_per_s": n / us * 1e6, "eager_ms": us_eager / 1e3}
+    return res
+
+
 def cpu_baseline(budget_s):
     """the same step on the host cores: reference kernel bodies (oracle/_ref) if they travelled
     with the snapshot, else the C port; torch CPU ops (1 thread) for grid_sample/matmul."""
@@ -329,6 +465,10 @@ def cpu_baseline(budget_s):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return respawn_under_torchrun(args)            # `python bench.py --gpus N`: one rank per GPU over RCCL
+    if args.stub:
+        return stub_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -338,13 +478,14 @@ def main():
     import genre_shapehd_amd as G
     from genre_shapehd_amd import dist_utils
     dist = dist_utils.init_from_env("nccl", dev)           # RCCL; None when WORLD_SIZE == 1
-    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     import inputs
     from genre_shapehd_amd.toolbox import _fused_render
     fused = (not args.unfused) and _fused_render.available()
-    model = HotPath(G, fused).to(dev)
     B = args.batch
+    bm = fused and args.layout == "bm" and B >= 16
+    model = HotPath(G, fused, batch_minor=bm).to(dev)
     depth = torch.from_numpy(inputs.batch_depth(B, seed=100 + 1000 * rank)).to(dev).requires_grad_(True)
     grad_out = torch.randn((B, 1, 160, 160), device=dev)
 
@@ -356,7 +497,7 @@ def main():
     def fence():
         dist_utils.fence(dist, torch.cuda.synchronize)
 
-    step()                                  # set-up pass: builds the geometry tables (host, ~2 s); never timed
+    step()                                  # set-up pass: builds the geometry tables on the host; never timed
     for _ in range(args.warmup):
         step()
     fence()
@@ -371,35 +512,41 @@ def main():
 
     if rank == 0:
         rows = kernel_table(G, dev, B)
-        # dominant hand-written kernel of the step = the one moving the most algorithmic bytes
-        # kernel groups that are part of the timed step in this mode (the fused renderer replaces calc_prob's kernels)
-        in_step = [k for k in rows if k == "cam_bp_fwd" or k.startswith("render_" if fused else "calc_prob")]
+        # kernel groups that are part of the timed step in this mode; the dominant one = the one taking the most time
+        if not fused:
+            in_step = ["cam_bp_fwd", "calc_prob_fwd", "calc_prob_bwd_fused"]
+        elif bm:
+            in_step = ["cam_bp_fwd", "render_fwd_bm", "render_bwd_bm"]
+        else:
+            in_step = ["cam_bp_fwd", "render_fwd_fused", "render_bwd_fused"]
         dom_name = max(in_step, key=lambda k: rows[k]["us"])
         dom = rows[dom_name]
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately and corrected as
-        # MI355X_MICROARCH.md prescribes); rocprofv3 cannot run inside this process, so the figures of the committed
-        # passes are quoted, and only for the configuration they were measured on (batch 32, fused renderer)
-        traffic = PMC_TRAFFIC_B32.get(dom_name) if (B == 32 and fused) else None
+        traffic, traffic_src = pmc_traffic(dom.get("pmc", []), B)
         m2_us = rows["cam_bp_fwd"]["us"] + rows["calc_prob_fwd"]["us"]
         m2_bytes = rows["cam_bp_fwd"]["bytes"] + rows["calc_prob_fwd"]["bytes"]
+        b1 = batch1_graph(G, dev)
         out = {
             "metric": "hot-path shapes/sec (256x256 depth -> 128^3 vox -> 160x160 sph, fwd+bwd) ; "
-                      "cam_bp+calc_prob HBM GB/s vs roofline in m2",
+                      "GenRe fwd shapes/sec in m1 ; cam_bp+calc_prob HBM GB/s vs roofline in m2 / m2_batch1",
             "value": value, "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: cam_bp + calc_prob fwd/bwd, 256x256 depth -> 128^3 voxel -> "
                                    "128x128x256 rays -> 160x160 spherical", "batch_per_gpu": B,
                        "render_spherical": "fused" if fused else "reference op sequence (grid_sample + CalcStopProb)",
+                       "volume_layout": "batch-minor (image index fastest)" if bm else "NCXYZ",
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom_name + " (" + dom["kernels"] + ")",
                          "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": PMC_TRAFFIC_SOURCE if traffic else None,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["us"]},
             "m2": {"what": "cam_bp fwd + calc_prob fwd, algorithmic bytes / time, batch %d" % B,
                    "achieved": m2_bytes / m2_us / 1e3, "unit": "GB/s", "frac": m2_bytes / m2_us / 1e3 / HBM_PEAK_GBS,
                    "us_per_image": m2_us / B},
+            "m2_batch1": {"what": "cam_bp fwd + calc_prob fwd at batch 1 (BASELINE.json: >= 40 % of 8 TB/s), HIP-graph replay",
+                          "achieved": b1["GBs"], "unit": "GB/s", "frac": b1["frac"], "us_per_image": b1["us_per_image"],
+                          "target_frac": 0.40},
             "kernels": {k: {"us": round(v["us"], 2), "GBs": round(v["GBs"], 1)} for k, v in rows.items()},
             "nnd": {"what": "Chamfer forward, both directions, %d x 2048 x 2048; 8 fp32 flops per pair, no fma" % B,
                     "TFLOPs": rows["nnd_fwd"]["TFLOPs"], "peak": 157.3, "frac": rows["nnd_fwd"]["frac_fp32_valu"],
@@ -411,15 +558,26 @@ def main():
                              "standard_layout_us": rows.get("chain_fwd", {}).get("us"),
                              "batch_minor_layout_us": rows.get("chain_fwd_batch_minor", {}).get("us"),
                              "shapes_per_s": (B / rows["chain_fwd_batch_minor"]["us"] * 1e6) if "chain_fwd_batch_minor" in rows else None},
-            "batch1": batch1_graph(G, dev),
+            "batch1": b1,
         }
+        if not args.no_m1:
+            try:
+                m1 = m1_genre_forward(G, dev)
+                geo = b1.get("genre_geometry_fwd_us_per_image")
+                if geo:
+                    m1["geometry_us_batch1"] = geo
+                    m1["geometry_share_batch1"] = geo / (m1["batch1"]["ms_per_forward"] * 1e3)
+                out["m1"] = m1
+            except Exception as e:          # pragma: no cover -- never fatal for the bench line
+                out["m1"] = {"error": str(e)[:300]}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,11 +1,20 @@
 """FETCH_SIZE / WRITE_SIZE per dispatch from two rocprofv3 --pmc passes over profiles/pmc_targets.py.
-usage: python profiles/pmc_traffic_table.py fetch_results.db write_results.db
+usage: python profiles/pmc_traffic_table.py fetch_results.db write_results.db [out.json batch]
+With out.json: also writes the table bench.py reads for roofline.traffic -- per kernel the corrected HBM bytes per
+launch, stamped with the sha256 of the kernel sources it was measured on (bench.py: source_sha) and the batch size.
 gfx950 correction (MI355X_MICROARCH.md): FETCH_SIZE reports half the bytes of a wide coalesced read stream, so it is
 doubled; units are KB."""
 import collections
+import json
+import os
 import re
 import sqlite3
 import sys
+
+# kernels whose reads are wide (16 B / lane) coalesced streams: FETCH_SIZE doubled (MI355X_MICROARCH.md, "HBM"); for the
+# others -- 4 B / lane gathers and line reads -- the counter was found NOT to be halved (profiles/r01g_pmc_hbm_traffic.txt)
+WIDE_STREAMS = ("fill2_vec4_kernel", "stop_fwd_vec4_kernel", "stop_bwd_vec4_kernel", "render_scan_fwd_kernel",
+                "render_scan_bwd_kernel", "bm_sample_kernel")
 
 
 def per_kernel(db, counter):
@@ -28,10 +37,21 @@ def short(name):
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
-print("%-34s %10s %14s %14s %18s" % ("kernel", "dispatches", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "HBM_MB=(2F+W)*1024"))
+print("%-40s %10s %14s %14s %6s %12s" % ("kernel", "dispatches", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "xF", "HBM_MB"))
+table = {}
 for k in sorted(set(fetch) | set(write), key=short):
     if "genre" not in k:
         continue
     f = sum(fetch.get(k, [0])) / max(1, len(fetch.get(k, [0])))
     w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
-    print("%-34s %10d %14.0f %14.0f %18.1f" % (short(k)[:34], len(fetch.get(k, [])), f, w, (2 * f + w) * 1024 / 1e6))
+    factor = 2 if short(k).split("<")[0] in WIDE_STREAMS else 1
+    hbm = (factor * f + w) * 1024
+    table[short(k)] = dict(dispatches=len(fetch.get(k, [])), fetch_kb=f, write_kb=w, fetch_factor=factor, hbm_bytes=hbm)
+    print("%-40s %10d %14.0f %14.0f %6d %12.1f" % (short(k)[:40], len(fetch.get(k, [])), f, w, factor, hbm / 1e6))
+if len(sys.argv) > 3:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    with open(sys.argv[3], "w") as fh:
+        json.dump(dict(source_sha=bench.source_sha(), batch=int(sys.argv[4]), kernels=table,
+                       how="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over profiles/pmc_targets.py"),
+                  fh, indent=1, sort_keys=True)

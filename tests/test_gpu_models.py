@@ -1,0 +1,115 @@
+"""SURVEY 8 f-2 / f-3 on the GPU: the GenRe model (three networks around the native ops) against the same modules on
+CPU torch with the oracle's ops in between (oracle/torch_oracle.py: GenReGlueCPU), stage by stage -- the geometric
+stages contain floor() decisions, so every stage is fed the CPU chain's input and compared on its own -- plus an
+end-to-end run, the HIP-graph inference entry, and one joint fine-tuning step with the Chamfer term."""
+import numpy as np
+import pytest
+import torch
+
+import networks_fill as NF
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair(genre, dev):
+    from genre_shapehd_amd.models import GenReNet
+    torch.manual_seed(0)
+    cpu = NF.fill_state(GenReNet(), seed=3).eval()
+    gpu = NF.fill_state(GenReNet(), seed=3).eval().to(dev)
+    return cpu, gpu
+
+
+def _inputs(n, seed=5):
+    rng = np.random.default_rng(seed)
+    rgb = torch.from_numpy(rng.uniform(0, 1, (n, 3, 256, 256)).astype(np.float32))
+    ax = np.linspace(-1, 1, 256)
+    sil = ((ax[:, None] ** 2 + ax[None, :] ** 2) < 0.5).astype(np.float32)[None, None].repeat(n, 0) * 100
+    return rgb, torch.from_numpy(sil)
+
+
+def _rel(a, b):
+    return ((a - b).abs() / b.abs().clamp(min=1.0)).max().item()
+
+
+def test_genre_forward_stage_by_stage(pair, oracle, dev):
+    from genre_shapehd_amd.models import Inputs
+    from oracle.torch_oracle import GenReGlueCPU
+    cpu, gpu = pair
+    rgb, sil = _inputs(2)
+    glue = GenReGlueCPU(oracle)
+    with torch.no_grad():
+        # stage 1: MarrNet-1 (MIOpen vs CPU convolutions)
+        o_c = cpu.depth_and_inpaint.net1(Inputs(rgb, sil))
+        o_g = gpu.depth_and_inpaint.net1(Inputs(rgb.to(dev), sil.to(dev)))
+        for k in ("depth", "normal", "silhou", "depth_minmax"):
+            assert _rel(o_g[k].cpu(), o_c[k]) <= 1e-4, k
+        # a plausible depth for the geometry (random weights give garbage min/max): 40..60 of 100, range [1.9, 2.5]
+        o_c["depth"] = 50 + 10 * torch.tanh(o_c["depth"])
+        o_c["depth_minmax"] = torch.tensor([[1.9, 2.5]]).repeat(2, 1)
+        # stage 2: get_abs_depth -> cam_bp -> render -> pad, from the CPU chain's net1 output
+        d_c = glue.get_abs_depth(o_c["depth"], o_c["depth_minmax"], sil)
+        proj50_c, sph_c = glue.depth_to_spherical(d_c)
+        og = {k: v.to(dev) for k, v in o_c.items()}
+        d_g = gpu.depth_and_inpaint.get_abs_depth(og, Inputs(None, sil.to(dev)))
+        assert torch.equal(d_g.cpu(), d_c)
+        proj_g = gpu.depth_and_inpaint.proj_depth(d_g)
+        assert (proj_g.cpu() * 50 - proj50_c).abs().max().item() <= 50 * 128e-5
+        sph_g = gpu.depth_and_inpaint.render_spherical(proj_g, pre_scale=50.0, pad=16)
+        assert (sph_g.cpu() - sph_c).abs().max().item() <= 1e-5
+        # stage 3: the inpainting network on the CPU chain's map
+        full_c = cpu.depth_and_inpaint.net2(sph_c)["spherical"]
+        full_g = gpu.depth_and_inpaint.net2(sph_c.to(dev))["spherical"]
+        assert _rel(full_g.cpu(), full_c) <= 1e-4
+        # stage 4: spherical back-projection + refiner input; a map in (0.2, 0.8) so that the points land in the cube
+        full_c = 0.5 + 0.3 * torch.tanh(full_c)
+        ri_c, cnt_c = glue.refiner_input(full_c, proj50_c)
+        from genre_shapehd_amd.callers import RefinerInput
+        grid = gpu.grid.expand(2, -1, -1, -1, -1)
+        ri_g, cnt_g = RefinerInput.apply(full_c.to(dev), grid, proj50_c.to(dev), 16)
+        assert torch.equal(cnt_g.cpu(), cnt_c)
+        assert (ri_g.cpu() - ri_c).abs().max().item() <= 1e-4
+        # stage 5: the 3-D refiner on the CPU chain's input
+        vox_c = cpu.refine_net(ri_c)
+        vox_g = gpu.refine_net(ri_c.to(dev))
+        assert _rel(vox_g.cpu(), vox_c) <= 1e-4
+
+
+def test_genre_end_to_end_and_graph_replay(pair, dev):
+    """the whole forward on the GPU: finite, right shapes; the HIP-graph entry replays bit-identically"""
+    from genre_shapehd_amd.models import GenReInference, Inputs
+    _, gpu = pair
+    rgb, sil = _inputs(1, seed=9)
+    with torch.no_grad():
+        out = gpu(Inputs(rgb.to(dev), sil.to(dev)))
+    assert out["pred_voxel"].shape == (1, 1, 128, 128, 128) and torch.isfinite(out["pred_voxel"]).all()
+    assert out["pred_sph_partial"].shape == (1, 1, 160, 160) and out["proj_depth"].shape == (1, 1, 128, 128, 128)
+    inf = GenReInference(gpu, device=dev, graph=True)
+    a = inf.predict(rgb, sil)["pred_voxel"].clone()
+    b = inf.predict(rgb, sil)["pred_voxel"].clone()                    # second call = pure replay
+    assert torch.equal(a, b)
+    # float atomics in cam_bp / the spherical back-projection make multi-hit voxels order-dependent: compare loosely
+    assert ((a - out["pred_voxel"]).abs() <= 1e-3 * out["pred_voxel"].abs().clamp(min=1)).float().mean().item() > 0.999
+    rgb2, _ = _inputs(1, seed=10)
+    c = inf.predict(rgb2, sil)["pred_voxel"]
+    assert not torch.equal(a, c)                                          # the static inputs really are refreshed
+
+
+def test_joint_finetune_step_reaches_marrnet1_through_the_projections(dev):
+    """config #5 at world_size 1: one Adam step of the joint loss + Chamfer term; the gradient arrives in MarrNet-1's
+    depth decoder through Unet_3D <- spherical back-projection <- net2 <- render_spherical <- cam_bp <- get_abs_depth"""
+    from genre_shapehd_amd import train as T
+    from genre_shapehd_amd.models import GenReNet, GenReOptions
+    torch.manual_seed(1)
+    opt = GenReOptions(joint_train=True)
+    net = NF.fill_state(GenReNet(opt), seed=4).to(dev).train()
+    inputs, gt = T.genre_batch(2, dev, seed=11)
+    optim = torch.optim.Adam(net.parameters(), lr=1e-6)
+    w0 = net.depth_and_inpaint.net1.decoder_depth[4][3].weight.detach().clone()
+    loss = T.genre_train_step(net, optim, inputs, gt, opt, chamfer_weight=0.1)
+    assert torch.isfinite(loss)
+    g = net.depth_and_inpaint.net1.decoder_depth[4][3].weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
+    assert not torch.equal(w0, net.depth_and_inpaint.net1.decoder_depth[4][3].weight.detach())
+    for p in net.refine_net.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()

@@ -9,16 +9,14 @@ near-binary GenRe occupancy volumes (tests/inputs.py: genre_offclamp_volumes), f
     contributions per voxel around the centre and the polar axis, 255 fp32-rounded recursion steps in
     calc_prob_kernel.cu:169-187): measured and printed per image.
 
-Two input classes:
-  "sharp"  empty 3e-5*(1+u), solid 1 - 3e-5*(1+u'): GenRe's actual levels, lifted just off the clamp bounds.  Here the
-           gradient is ill-conditioned in fp32: 1 - p ~ 3e-5 turns a one-ulp difference of a sampled value into a
-           2e-3 relative change of the transmittance behind it, so two fp32 implementations that add the eight
-           trilinear terms in a different order differ by ~1e-3 (measured).  Checked: map 1e-5 against both; gradient
-           no further from the exact value, and from the fp32 chain, than twice the chain's own distance from exact.
-  "soft"   solid level 1 - 0.02*(1+u'): still near-binary, transmittance still collapses behind the surface, but well
-           conditioned.  Checked: map 1e-5; gradient within 1e-5 * max(s', |g|) per voxel of the exact value, s' = the
-           image's own upstream gradient scale (1 ... 2^-24 across the batch) times max(1, pre_scale): an image whose
-           gradient is 2^-24 of its neighbour's must still be resolved (per-image fixed-point scale / fp64 tiles).
+Two input classes, same bars (measured on MI355X: kernels 2e-6 ... 9e-6 from exact, the fp32 chain 8e-5 ... 2.7e-4):
+  "sharp"  empty 3e-5*(1+u), solid 1 - 3e-5*(1+u'): GenRe's actual levels, lifted just off the clamp bounds
+           (1/(1-p) ~ 3e4 amplification behind the surface).
+  "soft"   solid level 1 - 0.02*(1+u').
+Checked per image: map 1e-5 against both references; gradient within 1e-5 * max(s', |g|) per voxel of the exact value,
+s' = the image's own upstream gradient scale (1 ... 2^-24 across the batch) times max(1, pre_scale) -- an image whose
+gradient is 2^-24 of its neighbour's must still be resolved (per-image fixed-point scale / fp64 tiles); and no further
+from the fp32 chain than the chain is from exact.
 """
 import numpy as np
 import pytest
@@ -107,11 +105,10 @@ def test_fused_render_gradient_on_genre_class_volumes(n, pre_scale, pad, layout,
         print("   error by distance from the centre (kernel, fp32 chain):", "; ".join(shells))
         print("%s image %d scale %.1e: kernel-vs-exact %.2e, kernel-vs-fp32-chain %.2e, fp32-chain-vs-exact %.2e"
               % (cls, i, s, rel, err, ref_rel))
-        if cls == "soft":
-            assert rel <= TOL, (i, "gradient vs the exact value, relative to the image's gradient scale", rel, s)
-        else:
-            assert rel <= 2 * ref_rel + TOL, (i, "gradient vs the exact value", rel, ref_rel)
-            assert err <= 2 * ref_rel + TOL, (i, "gradient vs fp32 reference chain", err, ref_rel)
+        # the kernels: within 1e-5 of the exact value of the operator on BOTH classes, relative to the image's own scale
+        assert rel <= TOL, (i, "gradient vs the exact value, relative to the image's gradient scale", rel, s)
+        # and no further from the reference's fp32 chain than that chain is from the exact value
+        assert err <= ref_rel + 2 * TOL, (i, "gradient vs fp32 reference chain", err, ref_rel)
 
 
 @pytest.mark.parametrize("layout", ["std", "bm"])
