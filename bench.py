@@ -245,7 +245,7 @@ def kernel_table(G, dev, B):
             rows["render_bwd_bm"] = dict(
                 us=event_time_us(lambda: render_lib.render_bm_backward(
                     gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"], TB["rec_b"],
-                    TB["bwd_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0), iters, 5),
+                    TB["bwd_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0, TB["pull_code"]), iters, 5),
                 bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
                 kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+bm_scatter_kernel",
                 pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel", "bm_scatter_kernel<true>"])

@@ -39,7 +39,7 @@ def _load():
         raise ImportError("libgenre_hip.so ABI %d != expected %d -- rebuild" % (lib.genre_abi_version(), ABI_VERSION))
     T, V = C.POINTER(GenreTensor), C.c_void_p
     scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float],
-               "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float],
+               "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float, C.c_int],
                "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float]}
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
                         ("genre_get_surface_mask", 5), ("genre_back_projection_forward_shifted", 5),
@@ -203,10 +203,10 @@ class _RenderLib:
 
     @staticmethod
     def render_bm_backward(grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, ent, rec_b, bwd_rows,
-                           depth_weight, ps_scratch, tr_scratch, p_stash, mask=None, pre_scale=0.0):
+                           depth_weight, ps_scratch, tr_scratch, p_stash, mask=None, pre_scale=0.0, pull_brick=488):
         return _call("genre_render_bm_backward", grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, ent,
                      rec_b, bwd_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask,
-                     scalars=(C.c_float(pre_scale),))
+                     scalars=(C.c_float(pre_scale), C.c_int(pull_brick)))
 
 
 class _GlueLib:

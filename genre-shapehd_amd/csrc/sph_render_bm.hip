@@ -38,7 +38,6 @@ namespace {
 constexpr int kBX = 4, kBY = 8, kBZ = 8;                 // brick (must match toolbox/_bm_tables.py)
 constexpr int kTX = kBX + 1, kTY = kBY + 1, kTZ = kBZ + 1;
 constexpr int kLinesF = kTX * kTY * kTZ;                 // 405 voxel lines in the forward tile
-constexpr int kLinesB = kBX * kBY * kBZ;                 // 256 in the backward tile
 constexpr int kImgs = 32;                                // images per group = lanes of a half-wave
 constexpr int kMaxSeg = 16;
 constexpr int kRec = 12;                                 // words per sample record
@@ -69,10 +68,11 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int BX = kBX, int BY = kBY, int BZ = kBZ>
 __device__ __forceinline__ void brick_origin(const BmDims &D, int brick, int &ox, int &oy, int &oz)
 {
-    const int nby = (D.Y + kBY - 1) / kBY, nbz = (D.Z + kBZ - 1) / kBZ;
-    ox = (brick / (nby * nbz)) * kBX; oy = ((brick / nbz) % nby) * kBY; oz = (brick % nbz) * kBZ;
+    const int nby = (D.Y + BY - 1) / BY, nbz = (D.Z + BZ - 1) / BZ;
+    ox = (brick / (nby * nbz)) * BX; oy = ((brick / nbz) % nby) * BY; oz = (brick % nbz) * BZ;
 }
 
 // ---- forward: brick sampler ---------------------------------------------------------------------------
@@ -156,8 +156,10 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     // would otherwise sit through two dependent global round trips (header -> records) before its first sample.
     const int4 none = make_int4(0, 0, 0, 0);
     int s = row.y + wave;
-    int4 sg = s < row.z ? segs[s] : none;
-    int4 sg1 = s + (NT / 64) < row.z ? segs[s + (NT / 64)] : none;
+    int4 sg = none;
+    if (s < row.z) sg = segs[s];
+    int4 sg1 = none;
+    if (s + (NT / 64) < row.z) sg1 = segs[s + (NT / 64)];
     int4 rq = none;                                                    // lane's 16 bytes of the segment's L*3 x 16
     if (lane < sg.z * 3) rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)sg.w * kRec)[lane];
     for (; s < row.z; s += (NT / 64)) {
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
         const int64_t slot0 = __builtin_amdgcn_readfirstlane(sg.w);
         if (lane < L * 3) reinterpret_cast<int4 *>(myrec)[lane] = rq;
         wave_lds_fence();
-        const int4 sg2 = s + 2 * (NT / 64) < row.z ? segs[s + 2 * (NT / 64)] : none;
+        int4 sg2 = none;
+        if (s + 2 * (NT / 64) < row.z) sg2 = segs[s + 2 * (NT / 64)];
         if (lane < sg1.z * 3) rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)sg1.w * kRec)[lane];
         float T = 1.f, S = 0.f, sprev = 0.f;
         float *st = SAVE ? stash + ((size_t)g * D.nslot + slot0) * kImgs + l : nullptr;
@@ -330,16 +333,19 @@ __global__ __launch_bounds__(256) void bm_combine_bwd_kernel(BmDims D, const flo
 }
 
 // ---- backward: brick-owned pull scatter ----------------------------------------------------------------
+// The backward's bricks ("pull bricks", PX x PY x PZ voxels) need not be the forward's: a bigger one lowers the number of
+// bricks a segment touches (every touching brick re-reads the segment's saved samples) at the price of LDS.
+template <int PX, int PY, int PZ>
 __global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, float *__restrict__ gvox)
 {
     const int4 row = rows[blockIdx.x];
     if (row.w == 0) return;
     int ox, oy, oz;
-    brick_origin(D, row.x, ox, oy, oz);
+    brick_origin<PX, PY, PZ>(D, row.x, ox, oy, oz);
     const int n0 = blockIdx.y * kImgs;
-    for (int e = threadIdx.x; e < kLinesB * kImgs; e += kThreads) {
+    for (int e = threadIdx.x; e < PX * PY * PZ * kImgs; e += kThreads) {
         const int line = e >> 5, n = n0 + (e & 31);
-        const int x = ox + line / (kBY * kBZ), y = oy + (line / kBZ) % kBY, z = oz + line % kBZ;
+        const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
         if (x < D.X && y < D.Y && z < D.Z && n < D.N) gvox[x * D.gx + y * D.gy + z * D.gz + n] = 0.f;
     }
 }
@@ -352,15 +358,15 @@ __device__ __forceinline__ void both_halves(float v, float &lower, float &upper)
     lower = __uint_as_float(r[0]); upper = __uint_as_float(r[1]);
 }
 
-constexpr int kThreadsB = 1024, kWavesB = kThreadsB / 64;
 constexpr int kHalfSeg = kMaxSeg / 2;
 
-template <bool PS>
-__global__ __launch_bounds__(kThreadsB, 8) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
+template <bool PS, int PX, int PY, int PZ, int kThreadsB>
+__global__ __launch_bounds__(kThreadsB) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
                                                                const int4 *__restrict__ rows, const float *__restrict__ dw,
                                                                const float *__restrict__ tr, const float *__restrict__ stash,
                                                                const unsigned *__restrict__ mask, float *__restrict__ gvox)
 {
+    constexpr int kLinesB = PX * PY * PZ, kWavesB = kThreadsB / 64;
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     double *tile = lds_d;                                               // [kLinesB][32]
     int *recs = reinterpret_cast<int *>(lds_d + kLinesB * kImgs);       // [kWavesB][kMaxSeg * kRec]
@@ -368,10 +374,9 @@ __global__ __launch_bounds__(kThreadsB, 8) void bm_scatter_kernel(BmDims D, cons
     const int4 row = rows[blockIdx.x];
     const int g = blockIdx.y, n0 = g * kImgs;
     int ox, oy, oz;
-    brick_origin(D, row.x, ox, oy, oz);
-    if (PS && threadIdx.x < kLinesB) {                                   // in flight while the samples are scattered
-        const int line = threadIdx.x;
-        const int x = ox + line / (kBY * kBZ), y = oy + (line / kBZ) % kBY, z = oz + line % kBZ;
+    brick_origin<PX, PY, PZ>(D, row.x, ox, oy, oz);
+    for (int line = threadIdx.x; PS && line < kLinesB; line += kThreadsB) {  // in flight while the samples are scattered
+        const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
         mlds[line] = (x < D.X && y < D.Y && z < D.Z) ? mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] : 0u;
     }
     for (int e = threadIdx.x; e < kLinesB * kImgs; e += kThreadsB) tile[e] = 0.0;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(kThreadsB, 8) void bm_scatter_kernel(BmDims D, cons
     const int half = lane >> 5, l = lane & 31;
     int *myrec = recs + wave * (kMaxSeg * kRec);
     char *tl = reinterpret_cast<char *>(tile + half * kImgs + l);
-    constexpr int kXS = kBY * kBZ * kImgs, kYS = kBZ * kImgs;           // doubles between x / y neighbours
+    constexpr int kXS = PY * PZ * kImgs, kYS = PZ * kImgs;           // doubles between x / y neighbours
     // entry = (segment, stash slot of its first sample, i0 | i1 << 6 | L << 12 | k0 << 18, rec_b slot of sample i0).
     // Software pipeline: while entry e is scattered, the saved samples, the two ray scalars and the records of entry
     // e + 16 are in flight to registers and the header of e + 32 is being fetched.  The per-sample arrays are SPLIT over
@@ -389,8 +394,10 @@ __global__ __launch_bounds__(kThreadsB, 8) void bm_scatter_kernel(BmDims D, cons
     // 16 waves per workgroup (8 per SIMD) hide the latency of this kernel's gathers.
     const int4 none = make_int4(0, 0, 0, 0);
     int e = row.y + wave;
-    int4 en = e < row.z ? ents[e] : none;
-    int4 en1 = e + kWavesB < row.z ? ents[e + kWavesB] : none;
+    int4 en = none;
+    if (e < row.z) en = ents[e];
+    int4 en1 = none;
+    if (e + kWavesB < row.z) en1 = ents[e + kWavesB];
     float pn[kHalfSeg];
     float Tn = 0.f, Rn = 0.f;
     int4 rq = none;
@@ -414,7 +421,8 @@ __global__ __launch_bounds__(kThreadsB, 8) void bm_scatter_kernel(BmDims D, cons
         float Tg = Tn, Rr = Rn;
         if (lane < (i1 - i0) * 3) reinterpret_cast<int4 *>(myrec)[lane] = rq;
         wave_lds_fence();
-        const int4 en2 = e + 2 * kWavesB < row.z ? ents[e + 2 * kWavesB] : none;
+        int4 en2 = none;
+        if (e + 2 * kWavesB < row.z) en2 = ents[e + 2 * kWavesB];
         if (e + kWavesB < row.z) fetch(en1);
 #pragma unroll
         for (int j = 0; j < kHalfSeg; j++) {                            // forward: g T_k where the clamp passes the gradient
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(kThreadsB, 8) void bm_scatter_kernel(BmDims D, cons
 #pragma unroll 4
     for (int e2 = threadIdx.x; e2 < kLinesB * kImgs; e2 += kThreadsB) {
         const int line = e2 >> 5, n = n0 + (e2 & 31);
-        const int x = ox + line / (kBY * kBZ), y = oy + (line / kBZ) % kBY, z = oz + line % kBZ;
+        const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
         if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
             float val = (float)tile[e2];
             if (PS) val = ((mlds[line] >> (e2 & 31)) & 1u) ? val * D.pre_scale : 0.f;  // adjoint of clamp(x * pre_scale, lo, hi)
@@ -507,9 +515,9 @@ int check_bm(const char *op, const genre_tensor *vox, const genre_tensor *map, c
     return 1;
 }
 
-int check_rows(const char *op, const BmDims &D, const genre_tensor *rows)
+int check_rows(const char *op, const BmDims &D, const genre_tensor *rows, int bx = kBX, int by = kBY, int bz = kBZ)
 {
-    const int nb = ((D.X + kBX - 1) / kBX) * ((D.Y + kBY - 1) / kBY) * ((D.Z + kBZ - 1) / kBZ);
+    const int nb = ((D.X + bx - 1) / bx) * ((D.Y + by - 1) / by) * ((D.Z + bz - 1) / bz);
     GENRE_REQUIRE(is_i32(rows, 2) && rows->size[1] == 4 && is_contiguous(rows) && aligned16(rows->data) &&
                       rows->size[0] >= nb && rows->size[0] < ((int64_t)1 << 30),
                   "%s: row table must be a contiguous int32 [rows >= %d, 4] tensor", op, nb);
@@ -589,12 +597,14 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
                                         const genre_tensor *bwd_rows, const genre_tensor *depth_weight,
                                         const genre_tensor *ps_scratch, const genre_tensor *tr_scratch,
                                         const genre_tensor *p_stash, const genre_tensor *mask, float pre_scale,
-                                        void *stream)
+                                        int pull_brick, void *stream)
 {
     const char *op = "render_bm_backward";
     BmDims D{};
     if (!check_bm(op, grad_vox, grad_out, segs, ray_ptr, ray_seg, ray_pre, D, true)) return 0;
-    if (!check_rows(op, D, bwd_rows)) return 0;
+    GENRE_REQUIRE(pull_brick == 488 || pull_brick == 888, "%s: pull_brick must be 488 (4x8x8 voxels) or 888 (8x8x8)", op);
+    const int px = pull_brick / 100;
+    if (!check_rows(op, D, bwd_rows, px, 8, 8)) return 0;
     D.gx = grad_vox->stride[2]; D.gy = grad_vox->stride[3]; D.gz = grad_vox->stride[4];
     D.pre_scale = pre_scale;
     GENRE_REQUIRE(is_i32(ent, 2) && ent->size[1] == 4 && is_contiguous(ent) && aligned16(ent->data), "%s: ent must be int32 [E,4]", op);
@@ -615,23 +625,28 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
         D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
         (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data);
     GENRE_LAUNCH_CHECK("render_bm backward (rays)");
-    const int nb = ((D.X + kBX - 1) / kBX) * ((D.Y + kBY - 1) / kBY) * ((D.Z + kBZ - 1) / kBZ);
+    const int nb = ((D.X + px - 1) / px) * ((D.Y + 7) / 8) * ((D.Z + 7) / 8);
     const dim3 grid((unsigned)bwd_rows->size[0], (unsigned)D.groups);
-    if (bwd_rows->size[0] > nb) {            // some bricks are split over several rows: those add atomically
-        bm_zero_shared_kernel<<<grid, kThreads, 0, st>>>(D, (const int4 *)bwd_rows->data, (float *)grad_vox->data);
-        GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");
-    }
-    const size_t lds = (size_t)kLinesB * kImgs * 8 + (size_t)kWavesB * kMaxSeg * kRec * 4 + (size_t)kLinesB * 4;
-#define GENRE_BM_SCATTER(PSV)                                                                                             \
+    const bool split = bwd_rows->size[0] > nb;     // some bricks are split over several rows: those add atomically
+    // 4x8x8: 64 KB tile, 768 threads, two workgroups per CU (72 VGPRs: 6 of the 7 possible waves per SIMD);
+    // 8x8x8: 128 KB tile, 1024 threads, one workgroup per CU
+#define GENRE_BM_SCATTER(PSV, PXV, NTV)                                                                                   \
     do {                                                                                                                  \
-        static const int ok_ = reserve_lds(op, &bm_scatter_kernel<PSV>, lds);                                             \
+        if (split) {                                                                                                      \
+            bm_zero_shared_kernel<PXV, 8, 8><<<grid, kThreads, 0, st>>>(D, (const int4 *)bwd_rows->data,                  \
+                                                                        (float *)grad_vox->data);                         \
+            GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");                                                \
+        }                                                                                                                 \
+        constexpr size_t lds = (size_t)PXV * 64 * kImgs * 8 + (size_t)(NTV / 64) * kMaxSeg * kRec * 4 + (size_t)PXV * 64 * 4; \
+        static const int ok_ = reserve_lds(op, &bm_scatter_kernel<PSV, PXV, 8, 8, NTV>, lds);                             \
         if (!ok_) return 0;                                                                                               \
-        bm_scatter_kernel<PSV><<<grid, kThreadsB, lds, st>>>(                                                              \
+        bm_scatter_kernel<PSV, PXV, 8, 8, NTV><<<grid, NTV, lds, st>>>(                                                   \
             D, (const int4 *)ent->data, (const int *)rec_b->data, (const int4 *)bwd_rows->data,                           \
             (const float *)depth_weight->data, (const float *)tr_scratch->data, (const float *)p_stash->data,             \
             pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr, (float *)grad_vox->data);                         \
     } while (0)
-    if (pre_scale != 0.0f) GENRE_BM_SCATTER(true); else GENRE_BM_SCATTER(false);
+    if (px == 4) { if (pre_scale != 0.0f) GENRE_BM_SCATTER(true, 4, 768); else GENRE_BM_SCATTER(false, 4, 768); }
+    else { if (pre_scale != 0.0f) GENRE_BM_SCATTER(true, 8, 1024); else GENRE_BM_SCATTER(false, 8, 1024); }
 #undef GENRE_BM_SCATTER
     GENRE_LAUNCH_CHECK("render_bm backward (bricks)");
     return 1;

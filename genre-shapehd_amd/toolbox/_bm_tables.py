@@ -27,8 +27,10 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
                               segment touch the brick of the row
   rec_b     int32 [SB,12]    (tile byte offset in the brick's own fp64 tile -- may point outside it for corners the
                               brick does not own --, ownership bits (corner c, z half h) -> bit c + 4h, 0, 0, 8 weights)
-  bwd_rows  int32 [rows,4]   (brick, ent begin, ent end, shared), heaviest first; shared = 1: the brick is split over
-                              several rows, which add their tiles atomically onto pre-zeroed voxels
+  bwd_rows  int32 [rows,4]   (pull brick, ent begin, ent end, shared), heaviest first; shared = 1: the brick is split
+                              over several rows, which add their tiles atomically onto pre-zeroed voxels.  The backward's
+                              ("pull") bricks are PULL = 8x8x8 voxels by default -- a segment then touches fewer bricks (each
+                              of which re-reads its saved samples) than with the forward's 4x8x8
 """
 import numpy as np
 
@@ -54,7 +56,10 @@ def _axis(d2a, a, size):
     return i0, w0.astype(np.float32), w1.astype(np.float32)
 
 
-def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split_b=SPLIT_B):
+PULL = (8, 8, 8)                # the backward's bricks (csrc/sph_render_bm.hip: pull_brick 488 or 888)
+
+
+def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split_b=SPLIT_B, pull=PULL):
     R = dirs64.shape[0]
     RR = R * R
     assert z_res <= 256 and RR < (1 << 22)
@@ -140,24 +145,26 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     cum = np.concatenate(([0], np.cumsum(segs[:, 2].astype(np.int64))))
     fwd_rows = _split_rows(sb, se, cum, split_f, 0)
 
-    # ---- backward listing: every brick pulls the samples that touch one of its voxels ----
+    # ---- backward listing: every PULL brick lists the samples that touch one of its voxels ----
+    assert tuple(pull) in ((4, 8, 8), (8, 8, 8))
+    pnbr = [-(-sz // b) for sz, b in zip(sizes, pull)]
+    pnb = pnbr[0] * pnbr[1] * pnbr[2]
+    pb = [bxyz[ax] // pull[ax] for ax in range(3)]                          # pull brick of the base corner
     flags = []
-    for ax, l in enumerate((lx, ly, lz)):
+    for ax in range(3):
         v1 = v1s[ax][qq, kk]
-        flags.append(v1 & (l == bsz[ax] - 1))                               # the +1 corner lies in the next brick
+        flags.append(v1 & ((bxyz[ax] + 1) // pull[ax] != pb[ax]))           # the +1 corner lies in the next pull brick
     keys, whos = [], []
     sid = np.arange(ns, dtype=np.int64)
     for d in range(8):
         m = np.ones(ns, bool)
-        off = 0
         for ax in range(3):
             if (d >> ax) & 1:
                 m &= flags[ax]
         if not m.any():
             continue
         dxyz = [(d >> ax) & 1 for ax in range(3)]
-        b2 = ((bxyz[0][m] // BX + dxyz[0]).astype(np.int64) * nbr[1] + (bxyz[1][m] // BY + dxyz[1])) * nbr[2] \
-            + (bxyz[2][m] // BZ + dxyz[2])
+        b2 = ((pb[0][m] + dxyz[0]).astype(np.int64) * pnbr[1] + (pb[1][m] + dxyz[1])) * pnbr[2] + (pb[2][m] + dxyz[2])
         keys.append((b2 << 40) | (samp_seg[m] << 8) | samp_i[m])
         whos.append(np.stack([sid[m], np.full(int(m.sum()), d, np.int64)], 1))
     keys = np.concatenate(keys)
@@ -180,10 +187,10 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     # rec_b of every listed sample, relative to the pulling brick
     s_id, dcode = whos[:, 0], whos[:, 1]
     rel = []
-    for ax, l in enumerate((lx, ly, lz)):
-        rel.append(l[s_id] - ((dcode >> ax) & 1) * bsz[ax])                 # base corner relative to the pulling brick
+    for ax in range(3):                                                     # base corner relative to the pulling brick
+        rel.append(bxyz[ax][s_id] - (pb[ax][s_id] + ((dcode >> ax) & 1)) * pull[ax])
     rec_b = np.zeros((nl, 12), np.int32)
-    rec_b[:, 0] = ((rel[0] * BY + rel[1]) * BZ + rel[2]) * LINE_B
+    rec_b[:, 0] = ((rel[0] * pull[1] + rel[1]) * pull[2] + rel[2]) * LINE_B
     own = np.zeros(nl, np.int32)
     valid = [(np.ones(ns, bool), v1s[ax][qq, kk]) for ax in range(3)]
     for c in range(8):
@@ -191,19 +198,19 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
         for ax in range(3):
             bit = (c >> ax) & 1
             coord = rel[ax] + bit
-            okc &= (coord >= 0) & (coord < bsz[ax]) & valid[ax][bit][s_id]
+            okc &= (coord >= 0) & (coord < pull[ax]) & valid[ax][bit][s_id]
         h, cxy = c >> 2, c & 3
         own |= okc.astype(np.int32) << (cxy + 4 * h)
     rec_b[:, 1] = own
     rec_b[:, 4:12] = wts[s_id].view(np.int32)
     assert (own != 0).all()
-    eb = np.searchsorted(ent_brick, np.arange(nb), side="left")
-    ee = np.searchsorted(ent_brick, np.arange(nb), side="right")
+    eb = np.searchsorted(ent_brick, np.arange(pnb), side="left")
+    ee = np.searchsorted(ent_brick, np.arange(pnb), side="right")
     cumb = np.concatenate(([0], np.cumsum((i_last + 1 - i_first).astype(np.int64))))
     bwd_rows = _split_rows(eb, ee, cumb, split_b, 1)
 
     return dict(segs=segs, rec_f=rec_f, fwd_rows=fwd_rows, ray_ptr=ray_ptr, ray_seg=ray_seg, ray_pre=ray_pre,
-                ent=ent, rec_b=rec_b, bwd_rows=bwd_rows, kin=kin)
+                ent=ent, rec_b=rec_b, bwd_rows=bwd_rows, kin=kin, pull=np.asarray(pull, np.int32))
 
 
 def _split_rows(begin, end, cum, split, shared_mode):

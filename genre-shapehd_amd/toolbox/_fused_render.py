@@ -122,14 +122,19 @@ def tables_for(vox_shape, device, dirs64, z_res):
 def bm_tables_for(vox_shape, device, dirs64, depth_weight):
     """tables of the batch-minor tile renderer (toolbox/_bm_tables.py), built on first use and cached per geometry and
     device; the float64 per-ray prefix table travels as its fp32 words"""
+    import os
     from . import _bm_tables
     dw = depth_weight.detach().cpu().numpy()
-    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], dw.shape[0], hash(dw.tobytes()), str(device))
+    pull = {"488": (4, 8, 8), "888": (8, 8, 8)}[os.environ.get("GENRE_BM_PULL", "888")]      # backward brick (A/B switch)
+    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], dw.shape[0], hash(dw.tobytes()), str(device), pull)
     t = _TABLES.get(key)
     if t is None:
-        np_t = _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), dw.shape[0], dw)
-        t = {}
+        np_t = _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), dw.shape[0], dw,
+                                          pull=pull)
+        t = {"pull_code": int(np_t["pull"][0]) * 100 + int(np_t["pull"][1]) * 10 + int(np_t["pull"][2])}
         for k, v in np_t.items():
+            if k == "pull":
+                continue
             tv = torch.from_numpy(np.ascontiguousarray(v))
             if k == "ray_pre":
                 tv = tv.view(torch.float32).reshape(-1, 4)
@@ -202,7 +207,7 @@ class RenderSphericalFused(Function):
             grad_vox = empty_batch_minor(ctx.vox_shape, grad_out.dtype, grad_out.device)
             lib.render_bm_backward(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], t["ent"],
                                    t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,
-                                   ctx.pre_scale)
+                                   ctx.pre_scale, t["pull_code"])
             return grad_vox, None, None, None, None
         vox, dirs64, depth_weight, v = ctx.saved_tensors
         z_res = depth_weight.shape[0]

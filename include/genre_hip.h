@@ -266,7 +266,8 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *                             corner inside the brick of the row that lists the entry
  *   rec_b     int32 [SB,12]   byte offset in the brick's own 4x8x8 x 32-image fp64 tile, ownership bits
  *                             (bit c + 4h: corner (x,y) = c of z half h belongs to this brick), 0, 0, 8 weights
- *   bwd_rows  int32 [rows,4]  (brick, ent begin, ent end, shared): shared = 1 rows add onto pre-zeroed voxels
+ *   bwd_rows  int32 [rows,4]  (pull brick, ent begin, ent end, shared): shared = 1 rows add onto pre-zeroed voxels;
+ *                             the backward's bricks are pull_brick = 488 (4x8x8 voxels) or 888 (8x8x8), as the tables were built
  * Scratch (caller-allocated, groups = ceil(N/32)):
  *   ps_scratch fp32 [groups*nseg*64]: per segment and image (prod(1-p), sum T p w) -- forward output, backward input
  *   p_stash    fp32 [groups*S*32] or NULL: clamped sample values (negated where the clamp blocks the gradient);
@@ -286,7 +287,7 @@ int genre_render_bm_backward(const genre_tensor *grad_out, const genre_tensor *g
                              const genre_tensor *ent, const genre_tensor *rec_b, const genre_tensor *bwd_rows,
                              const genre_tensor *depth_weight, const genre_tensor *ps_scratch,
                              const genre_tensor *tr_scratch, const genre_tensor *p_stash, const genre_tensor *mask,
-                             float pre_scale, void *stream);
+                             float pre_scale, int pull_brick, void *stream);
 
 #ifdef __cplusplus
 }

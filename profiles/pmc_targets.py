@@ -61,7 +61,7 @@ for _ in range(3):
         lib.render_bm_forward(proj_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"], TB["ray_seg"],
                               TB["ray_pre"], ps, stash, mask, 50.0)
         lib.render_bm_backward(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"],
-                               TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, trs, stash, mask, 50.0)
+                               TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, trs, stash, mask, 50.0, TB["pull_code"])
 # Chamfer forward (VALU-bound: used with --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ...)
 from genre_shapehd_amd.toolbox.nndistance._ext import my_lib  # noqa: E402
 xa = torch.rand((B, 2048, 3), device=dev)

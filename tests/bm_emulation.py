@@ -59,7 +59,7 @@ def forward(mod, t, vox, pre_scale=0.0, lo=np.float32(1e-5), hi=np.float32(1 - 1
 def backward(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
     """g [RR] upstream gradient -> grad_vox [X,Y,Z] (float64)"""
     X, Y, Z = shape
-    BX, BY, BZ = mod.BX, mod.BY, mod.BZ
+    BX, BY, BZ = (int(v) for v in t["pull"])                           # the backward's (pull) bricks
     nby, nbz = -(-Y // BY), -(-Z // BZ)
     segs = t["segs"]
     TR = np.zeros((segs.shape[0], 2))
@@ -108,15 +108,15 @@ def backward(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
         if shared:
             acc_shared[brick] = acc_shared.get(brick, 0) + tile
             continue
-        _flush(grad, written, tile, brick, mod, nby, nbz, mask, pre_scale)
+        _flush(grad, written, tile, brick, (BX, BY, BZ), nby, nbz, mask, pre_scale)
     for brick, tile in acc_shared.items():
-        _flush(grad, written, tile, brick, mod, nby, nbz, mask, pre_scale)
+        _flush(grad, written, tile, brick, (BX, BY, BZ), nby, nbz, mask, pre_scale)
     assert (written == 1).all(), "every voxel must be written exactly once"
     return grad
 
 
-def _flush(grad, written, tile, brick, mod, nby, nbz, mask, pre_scale):
-    BX, BY, BZ = mod.BX, mod.BY, mod.BZ
+def _flush(grad, written, tile, brick, dims, nby, nbz, mask, pre_scale):
+    BX, BY, BZ = dims
     ox, oy, oz = (brick // (nby * nbz)) * BX, ((brick // nbz) % nby) * BY, (brick % nbz) * BZ
     tl = tile.reshape(BX, BY, BZ)
     view = grad[ox:ox + BX, oy:oy + BY, oz:oz + BZ]

@@ -10,8 +10,8 @@ def fill_state(module, seed=0):
     seen = {}
     for k in sorted(sd):
         t = sd[k]
-        if not t.dtype.is_floating_point:
-            continue
+        if not t.dtype.is_floating_point or k.rsplit(".", 1)[-1] in ("grid", "depth_weight"):
+            continue                                   # counters; geometry constants of the renderer / back-projection
         if t.data_ptr() in seen:                       # one module registered under two names (Net_inpaint.deconv2)
             continue
         g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(k.encode()))

@@ -28,13 +28,14 @@ def _field(res, seed):
     return (0.003 + 0.9 * (r2 < 0.05) + rng.uniform(0, 0.02, (res,) * 3)).astype(np.float32)
 
 
-@pytest.mark.parametrize("res,sph,zr,pre_scale,split", [(16, 8, 32, 0.0, None), (20, 10, 48, 0.0, 64), (13, 6, 24, 3.0, 40)])
-def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, oracle):
+@pytest.mark.parametrize("res,sph,zr,pre_scale,split,pull", [(16, 8, 32, 0.0, None, (8, 8, 8)), (20, 10, 48, 0.0, 64, (4, 8, 8)),
+                                                              (13, 6, 24, 3.0, 40, (8, 8, 8))])
+def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, pull, oracle):
     from oracle.torch_oracle import RenderSphericalCPU, unit_dirs
     m = _mod()
     dw = np.linspace(0, 1, zr).astype(np.float32)
     dw = torch.linspace(0, 1, zr).numpy()
-    kw = {} if split is None else dict(split_f=split, split_b=split)
+    kw = dict(pull=pull) if split is None else dict(split_f=split, split_b=split, pull=pull)
     t = m.build_bm_tables(res, res, res, unit_dirs(sph), zr, dw, **kw)
     vox = _field(res, res)
     if pre_scale:
@@ -54,4 +55,5 @@ def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, or
     pk = t["ent"][:, 2]
     assert (((pk >> 6) & 63) - (pk & 63)).sum() == t["rec_b"].shape[0]
     nb = -(-res // m.BX) * -(-res // m.BY) * -(-res // m.BZ)
-    assert set(t["fwd_rows"][:, 0]) == set(range(nb)) and set(t["bwd_rows"][:, 0]) == set(range(nb))
+    pnb = -(-res // pull[0]) * -(-res // pull[1]) * -(-res // pull[2])
+    assert set(t["fwd_rows"][:, 0]) == set(range(nb)) and set(t["bwd_rows"][:, 0]) == set(range(pnb))

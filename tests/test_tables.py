@@ -64,18 +64,18 @@ def test_brick_tables_cover_exactly_the_in_volume_samples(res, sph, zr):
     assert pairs == expect
 
 
-@pytest.mark.parametrize("res,sph,zr", [(20, 10, 24), (33, 8, 40)])
-def test_bm_listing_names_every_touching_sample_once_per_brick(res, sph, zr):
+@pytest.mark.parametrize("res,sph,zr,pull", [(20, 10, 24, (4, 8, 8)), (33, 8, 40, (8, 8, 8))])
+def test_bm_listing_names_every_touching_sample_once_per_brick(res, sph, zr, pull):
     """batch-minor tile renderer (toolbox/_bm_tables.py): a brick's backward entries list exactly the samples with a
     weighted corner inside it, the ownership bits mark exactly those corners, segments partition the rays"""
     from genre_shapehd_amd.toolbox import _bm_tables as B
     mod = G.render_spherical(sph_res=sph, z_res=zr, fused=False)
     dirs = mod._dirs64.numpy()
-    t = B.build_bm_tables(res, res, res, dirs, zr, mod.depth_weight.numpy(), split_f=50, split_b=40)
+    t = B.build_bm_tables(res, res, res, dirs, zr, mod.depth_weight.numpy(), split_f=50, split_b=40, pull=pull)
     cells, inside = brute_force(res, res, res, dirs, zr)
     assert np.array_equal(inside, np.arange(zr)[None, :] >= t["kin"][:, None])
-    nbr = (-(-res // B.BX), -(-res // B.BY), -(-res // B.BZ))
-    bs = (B.BX, B.BY, B.BZ)
+    nbr = tuple(-(-res // b) for b in pull)                                  # the backward's (pull) bricks
+    bs = pull
     segs = t["segs"]
     # segments: consecutive samples of one ray, every in-volume sample in exactly one, per ray in order
     seen = np.zeros(inside.shape, int)

@@ -53,7 +53,7 @@ def fwd(save):
 
 def bwd():
     lib.render_bm_backward(gout, gvox, T["segs"], T["ray_ptr"], T["ray_seg"], T["ray_pre"], T["ent"], T["rec_b"],
-                           T["bwd_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0)
+                           T["bwd_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0, T["pull_code"])
 
 
 print("B=%d  forward(no save) %.1f us  forward(save) %.1f us  backward %.1f us" % (
