@@ -50,11 +50,12 @@ def _load():
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
                         ("genre_render_spherical_forward", 8), ("genre_render_spherical_backward", 10),
                         ("genre_render_bm_forward", 11), ("genre_render_bm_backward", 14),
-                        ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4)):
+                        ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4),
+                        ("genre_nnd_forward_host", 6), ("genre_nnd_backward_host", 8)):
         fn = getattr(lib, name, None)
         if fn is None:
             raise ImportError("libgenre_hip.so does not export %s -- rebuild (make -C genre-shapehd_amd/csrc)" % name)
-        fn.argtypes = [T] * nargs + scalars.get(name, []) + [V]
+        fn.argtypes = [T] * nargs + scalars.get(name, []) + ([] if name.endswith("_host") else [V])
         fn.restype = C.c_int
     return lib
 
@@ -62,10 +63,12 @@ def _load():
 _lib = _load()
 
 
-def _desc(t, what):
+def _desc(t, what, host=False):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s: expected a torch.Tensor, got %r" % (what, type(t)))
-    if not t.is_cuda:
+    if host and t.is_cuda:
+        raise RuntimeError("%s: a host entry point was handed a tensor on %s" % (what, t.device))
+    if not host and not t.is_cuda:
         raise RuntimeError("%s: tensor is on %s; the MI355X ops take CUDA (HIP) tensors only -- "
                            "there is no CPU path" % (what, t.device))
     if t.dtype == torch.float32:
@@ -102,6 +105,14 @@ def _call(name, *tensors, scalars=()):
         stream = torch.cuda.current_stream(dev).cuda_stream
         ok = getattr(_lib, name)(*[None if d is None else C.byref(d) for d in descs], *scalars, C.c_void_p(stream))
     if ok != 1:
+        raise RuntimeError("%s failed: %s" % (name, _lib.genre_last_error().decode()))
+    return 1
+
+
+def _call_host(name, *tensors):
+    """the reference's CPU entry points (my_lib.nnd_forward / nnd_backward): host tensors, synchronous"""
+    descs = [_desc(t, "%s arg %d" % (name, k), host=True) for k, t in enumerate(tensors)]
+    if getattr(_lib, name)(*[C.byref(d) for d in descs]) != 1:
         raise RuntimeError("%s failed: %s" % (name, _lib.genre_last_error().decode()))
     return 1
 
@@ -224,8 +235,8 @@ class _GlueLib:
 
 
 class _MyLib:
-    """stands in for nndistance/_ext/my_lib (my_lib.h:3-5, my_lib_cuda.h:1-4).
-    The reference's CPU entry points exist here only to fail loudly."""
+    """stands in for nndistance/_ext/my_lib (my_lib.h:3-5, my_lib_cuda.h:1-4): the two CUDA entries run the HIP
+    kernels, the two CPU entries the host code of csrc/nnd_host.hip (CPU tensors only; nothing falls back to them)."""
 
     @staticmethod
     def nnd_forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2):
@@ -236,11 +247,14 @@ class _MyLib:
         return _call("genre_nnd_backward", xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
 
     @staticmethod
-    def nnd_forward(*args):
-        raise RuntimeError("nnd_forward (CPU, my_lib.c:30-49) is not part of the MI355X build; "
-                           "move the clouds to the GPU -- there is no CPU fallback")
+    def nnd_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
+        """my_lib.h:3 -- the reference's CPU entry (host tensors)"""
+        return _call_host("genre_nnd_forward_host", xyz1, xyz2, dist1, dist2, idx1, idx2)
 
-    nnd_backward = nnd_forward
+    @staticmethod
+    def nnd_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+        """my_lib.h:5"""
+        return _call_host("genre_nnd_backward_host", xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
 
 
 cam_bp_lib = _CamBpLib()

@@ -304,7 +304,9 @@ __global__ __launch_bounds__(kBlock) void normalise_tile_kernel(Dims D, View4 de
         }
 #pragma unroll
         for (int u = 0; u < kTilesInFlight; u++) {
-            if (T.key[u] >= 0 && s[u] < 0.0f) {                           // still a raw (negated) sum
+            // still a raw (negated) sum?  `<=`: a point that sits exactly on its voxel's centre leaves a raw sum of
+            // -0.0; finished values are > 0 in the shifted modes and recomputing a finished 0 is idempotent in identity mode
+            if (T.key[u] >= 0 && s[u] <= 0.0f) {
                 // :304 (mean distance); post = identity (scale 1, bias 0), the camera layer's shift 1 - res*tdf
                 // (mode 0 with scale -res, bias 1), or GenRe's spherical glue (-tdf + 1/res)*res (mode 1,
                 // genre_full_model.py:141: post_bias holds 1/res, post_scale holds res)

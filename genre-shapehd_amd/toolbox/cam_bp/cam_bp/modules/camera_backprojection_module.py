@@ -23,9 +23,11 @@ class Camera_back_projection_layer(nn.Module):
     def _const(self, value, n, device):
         # the reference allocates + fills a fresh [n,1] tensor every call (:16-21); cache it so the
         # layer issues no extra kernels and can be captured in a HIP graph
-        key = (float(value), n, str(device))
+        # one entry per (constant, device): a new batch size replaces the old tensor, so the cache cannot grow with the
+        # batch sizes seen; the tensors are read-only inputs of the op (autograd saves them) -- do not modify them
+        key = (float(value), str(device))
         t = self._consts.get(key)
-        if t is None:
+        if t is None or t.shape[0] != n:
             t = torch.full((n, 1), float(value), dtype=torch.float32, device=device)
             self._consts[key] = t
         return t

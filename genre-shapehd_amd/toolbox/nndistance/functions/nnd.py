@@ -2,10 +2,11 @@
 toolbox/nndistance/functions/nnd.py:8-85 (Chamfer nearest-neighbour distance, squared L2,
 both directions; int32 indices).
 
-Only CUDA (HIP) tensors are accepted: the reference's CPU branch (my_lib.nnd_forward,
-:27-28) is not part of the MI355X build and there is deliberately no CPU fallback.
-Outputs are allocated on the inputs' device directly (the reference allocates on the host
-and copies, :21-33).
+CUDA (HIP) tensors run the gfx950 kernels (my_lib.nnd_*_cuda); CPU tensors take the reference's
+CPU entry points my_lib.nnd_forward / nnd_backward (:27-28,53-54), host code in csrc/nnd_host.hip
+-- the dispatch is by the tensors' device, exactly as in the reference; a CUDA tensor never falls
+back to the host.  Outputs are allocated on the inputs' device directly (the reference allocates
+on the host and copies, :21-33).
 """
 import torch
 from torch.autograd import Function
@@ -24,10 +25,7 @@ class NNDFunction(Function):
         assert xyz1.dtype == torch.float32 and xyz2.dtype == torch.float32, \
             'only FloatTensor are supported for NNDistance'
         assert xyz1.is_contiguous() and xyz2.is_contiguous()
-        if not xyz1.is_cuda:
-            raise RuntimeError("NNDFunction: CPU tensors are not supported by the MI355X build "
-                               "(no CPU fallback); call .cuda() on the clouds")
-        ctx.is_cuda = True
+        ctx.is_cuda = xyz1.is_cuda
         b, n, _ = xyz1.size()
         m = xyz2.size(1)
         dev = xyz1.device
@@ -35,7 +33,7 @@ class NNDFunction(Function):
         dist2 = torch.empty((b, m), dtype=torch.float32, device=dev)
         idx1 = torch.empty((b, n), dtype=torch.int32, device=dev)
         idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
-        my_lib.nnd_forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2)
+        (my_lib.nnd_forward_cuda if ctx.is_cuda else my_lib.nnd_forward)(xyz1, xyz2, dist1, dist2, idx1, idx2)
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
         return dist1, dist2, idx1, idx2
@@ -44,7 +42,7 @@ class NNDFunction(Function):
     @once_differentiable
     def backward(ctx, graddist1, graddist2, gradidx1, gradidx2):
         """takes placeholder grads for the two index outputs, like the reference (:41-43)"""
-        assert graddist1.is_cuda and graddist2.is_cuda
+        assert graddist1.is_cuda == ctx.is_cuda and graddist2.is_cuda == ctx.is_cuda
         xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
         graddist1 = graddist1.contiguous()
         graddist2 = graddist2.contiguous()
@@ -52,7 +50,8 @@ class NNDFunction(Function):
             'only FloatTensor are supported for NNDistance'
         gradxyz1 = torch.empty_like(xyz1)
         gradxyz2 = torch.empty_like(xyz2)
-        my_lib.nnd_backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
+        (my_lib.nnd_backward_cuda if ctx.is_cuda else my_lib.nnd_backward)(xyz1, xyz2, gradxyz1, gradxyz2, graddist1,
+                                                                            graddist2, idx1, idx2)
         return gradxyz1, gradxyz2
 
 

@@ -187,6 +187,19 @@ int genre_nnd_backward(const genre_tensor *xyz1, const genre_tensor *xyz2,
                        const genre_tensor *graddist1, const genre_tensor *graddist2,
                        const genre_tensor *idx1, const genre_tensor *idx2, void *stream);
 
+/* HOST entry points: the reference's my_lib.nnd_forward / nnd_backward (toolbox/nndistance/src/my_lib.h:3-5,
+ * my_lib.c:30-118), which its NNDFunction takes for CPU tensors (functions/nnd.py:27-28,53-54).  All pointers are
+ * HOST memory; same shapes as above; synchronous; multi-threaded over (batch item, block of queries).  Values and
+ * indices equal the reference's single-threaded loop bit for bit (same float expression, first minimum wins,
+ * serial gradient accumulation inside a batch item). */
+int genre_nnd_forward_host(const genre_tensor *xyz1, const genre_tensor *xyz2,
+                           const genre_tensor *dist1, const genre_tensor *dist2,
+                           const genre_tensor *idx1, const genre_tensor *idx2);
+int genre_nnd_backward_host(const genre_tensor *xyz1, const genre_tensor *xyz2,
+                            const genre_tensor *gradxyz1, const genre_tensor *gradxyz2,
+                            const genre_tensor *graddist1, const genre_tensor *graddist2,
+                            const genre_tensor *idx1, const genre_tensor *idx2);
+
 /* ---- render_spherical : toolbox/spherical_proj.py:31-72 (extension) ---------- */
 
 /* No native counterpart in the reference: fuses the PyTorch op sequence of

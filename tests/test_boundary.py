@@ -95,16 +95,20 @@ def test_validation_errors_do_not_launch(genre):
     assert lib.genre_back_projection_forward(C.byref(e), C.byref(ep), C.byref(ep), C.byref(ev), C.byref(ev), None) == 1
 
 
-def test_ops_refuse_cpu_tensors(genre):
-    with pytest.raises(RuntimeError, match="no CPU"):
-        genre.nndistance(torch.rand(1, 5, 3), torch.rand(1, 6, 3))
+def test_cuda_only_ops_refuse_cpu_tensors(genre):
+    """cam_bp, calc_prob and the spherical back-projection are CUDA-only in the reference too (`assert ...is_cuda`,
+    cam_back_projection.py:18-20, calc_prob.py:14): no CPU path, no fallback.  nndistance is the one op with a CPU
+    entry point in the reference (my_lib.nnd_forward) -- tests/test_nnd_host.py; its CUDA entry still refuses host
+    tensors"""
     with pytest.raises(AssertionError):
         genre.CalcStopProb.apply(torch.rand(1, 1, 2, 2, 8))
     with pytest.raises(AssertionError):
         genre.CameraBackProjection.apply(torch.rand(1, 1, 8, 8), torch.ones(1, 1), torch.ones(1, 1), 128)
     from genre_shapehd_amd.toolbox.nndistance._ext import my_lib
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        my_lib.nnd_forward(None)
+    x = torch.rand(1, 5, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        my_lib.nnd_forward_cuda(x, x, torch.empty(1, 5), torch.empty(1, 5), torch.empty(1, 5, dtype=torch.int32),
+                                torch.empty(1, 5, dtype=torch.int32))
 
 
 def test_reference_import_lines_work_unchanged(genre):

@@ -269,3 +269,25 @@ def test_shape_errors_raise(genre, dev):
         cam_bp_lib.back_projection_forward(d, torch.zeros((2, 1), device=dev), p, v, v.clone())
     with pytest.raises(RuntimeError, match="no CPU path"):
         cam_bp_lib.back_projection_forward(d.cpu(), p, p, v, v.clone())
+
+
+def test_point_exactly_on_a_voxel_centre(genre, oracle, dev):
+    """a single point whose distance to its voxel's centre is exactly 0 leaves a raw sum of (-)0: the normalise pass
+    must still recognise the voxel as un-normalised -- in the shifted modes (1 - res*tdf of the camera layer,
+    (-tdf + 1/res)*res of GenRe's spherical glue) such a voxel holds 1, not 0"""
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    res = 128
+    c = (64 + 0.5) / res - 0.5                                            # centre of voxel 64: 0.00390625, exact in fp32
+    sph = torch.full((1, 1, 4, 4), -1.0, device=dev)                      # every other direction is skipped (d < 0)
+    sph[0, 0, 1, 2] = c
+    grid = torch.ones((1, 1, 4, 4, 3), device=dev)                        # direction (1,1,1): the point is (c,c,c)
+    for shifted in (False, True):
+        out = torch.empty((1, 1, res, res, res), device=dev)
+        cnt = torch.empty_like(out)
+        (cam_bp_lib.spherical_back_proj_forward_shifted if shifted else cam_bp_lib.spherical_back_proj_forward)(
+            sph, grid, out, cnt)
+        tdf_o, cnt_o = oracle.spherical_back_proj_forward(sph.cpu().numpy(), grid.cpu().numpy(), res)
+        assert cnt[0, 0, 64, 64, 64].item() == 1.0 and cnt.sum().item() == 1.0 and np.array_equal(cnt.cpu().numpy(), cnt_o)
+        want = ((-tdf_o + 1.0 / res) * res * np.clip(cnt_o, 0, 1)) if shifted else tdf_o
+        assert np.array_equal(out.cpu().numpy(), want.astype(np.float32))
+        assert out[0, 0, 64, 64, 64].item() == (1.0 if shifted else 0.0)
