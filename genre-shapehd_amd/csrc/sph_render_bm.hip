@@ -88,6 +88,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     float *tile = lds_f;                                               // [kLinesF][32]
     int *recs = reinterpret_cast<int *>(lds_f + kLinesF * kImgs);      // [(NT / 64)][kMaxSeg * kRec]
     const int4 row = rows[blockIdx.x];
+    if (row.w == 2) return;                                            // padding row of the XCD interleave
     const int g = blockIdx.y, n0 = g * kImgs;
     int ox, oy, oz;
     brick_origin(D, row.x, ox, oy, oz);
@@ -339,7 +340,7 @@ template <int PX, int PY, int PZ>
 __global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, float *__restrict__ gvox)
 {
     const int4 row = rows[blockIdx.x];
-    if (row.w == 0) return;
+    if (row.w != 1) return;
     int ox, oy, oz;
     brick_origin<PX, PY, PZ>(D, row.x, ox, oy, oz);
     const int n0 = blockIdx.y * kImgs;
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(kThreadsB) void bm_scatter_kernel(BmDims D, const i
     int *recs = reinterpret_cast<int *>(lds_d + kLinesB * kImgs);       // [kWavesB][kMaxSeg * kRec]
     unsigned *mlds = reinterpret_cast<unsigned *>(recs + kWavesB * kMaxSeg * kRec);     // [kLinesB] clamp masks
     const int4 row = rows[blockIdx.x];
+    if (row.w == 2) return;                                             // padding row of the XCD interleave
     const int g = blockIdx.y, n0 = g * kImgs;
     int ox, oy, oz;
     brick_origin<PX, PY, PZ>(D, row.x, ox, oy, oz);

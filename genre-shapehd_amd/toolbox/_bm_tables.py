@@ -19,7 +19,7 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
   segs      int32 [nseg,4]   (ray q, first sample k0, length L, slot of the first sample)   sorted by (brick, q, k0)
   rec_f     int32 [S,12]     per sample slot: (tile byte offset, depth_weight[k] bits, 0, 0,
                               w(x0y0z0), w(x1y0z0), w(x0y1z0), w(x1y1z0), w(x0y0z1), w(x1y0z1), w(x0y1z1), w(x1y1z1))
-  fwd_rows  int32 [rows,4]   (brick, seg begin, seg end, 0), heaviest first
+  fwd_rows  int32 [rows,4]   (brick, seg begin, seg end, flag); flag 2 = padding row (skipped); order: see _xcd_order
   ray_ptr   int32 [RR+1], ray_seg int32 [nseg]   the segments of every ray in sample order
   ray_pre   float64 [RR,2]   (P0, S0) of the samples before the ray enters the volume (p = 1e-5 each)
   ent       int32 [E,4]      backward listing: (segment, slot of the segment's first sample,
@@ -27,7 +27,7 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
                               segment touch the brick of the row
   rec_b     int32 [SB,12]    (tile byte offset in the brick's own fp64 tile -- may point outside it for corners the
                               brick does not own --, ownership bits (corner c, z half h) -> bit c + 4h, 0, 0, 8 weights)
-  bwd_rows  int32 [rows,4]   (pull brick, ent begin, ent end, shared), heaviest first; shared = 1: the brick is split
+  bwd_rows  int32 [rows,4]   (pull brick, ent begin, ent end, shared); shared = 1: the brick is split
                               over several rows, which add their tiles atomically onto pre-zeroed voxels.  The backward's
                               ("pull") bricks are PULL = 8x8x8 voxels by default -- a segment then touches fewer bricks (each
                               of which re-reads its saved samples) than with the forward's 4x8x8
@@ -231,5 +231,38 @@ def _split_rows(begin, end, cum, split, shared_mode):
             cuts.append(nxt)
         for c0, c1 in zip(cuts[:-1], cuts[1:]):
             rows.append((b, c0, c1, shared_mode, int(cum[c1] - cum[c0])))
-    rows.sort(key=lambda r: -r[4])
-    return np.asarray([r[:4] for r in rows], np.int32).reshape(-1, 4)
+    if ROW_ORDER == "heaviest":
+        rows.sort(key=lambda r: -r[4])
+        return np.asarray([r[:4] for r in rows], np.int32).reshape(-1, 4)
+    return _xcd_order(rows)
+
+
+# Row order.  "heaviest": rows sorted by weight, heaviest first (best tail).  "xcd": weight classes, brick order inside a
+# class, interleaved so that each XCD walks a contiguous slab (_xcd_order) -- measured SLOWER on MI355X at batch 32
+# (forward 221 -> 236 us, backward 630 -> 820 us; a pure brick-order interleave: 244 / 857 us), so it is not the default.
+ROW_ORDER = "heaviest"
+SKIP = 2                        # row flag: padding, the workgroup returns at once
+FIXED_COST = 256                # weight of a row beyond its samples (tile staging / zeroing / flush), in samples
+
+
+def _xcd_order(rows):
+    """MI355X deals the workgroups of a launch to its 8 XCDs round-robin by linear id, and each XCD has its own L2.
+    Neighbouring bricks share voxel lines (the forward's halo) and saved samples (a segment is pulled by every brick it
+    touches).  Rows are grouped into weight classes (powers of two), heaviest class first -- so the launch still ends
+    on its lightest rows -- and inside a class they stay in BRICK order, cut into 8 consecutive parts that are
+    interleaved: within a class, row 8 i + x is the i-th row of part x, i.e. XCD x walks a contiguous slab of the
+    volume and meets the shared lines in its own L2.  Classes are padded to a multiple of 8 rows with SKIP rows."""
+    classes = {}
+    for r in rows:
+        classes.setdefault(int(np.log2(r[4] + 1)), []).append(r)
+    out = []
+    for c in sorted(classes, reverse=True):
+        part = classes[c]                                                  # already in brick order
+        depth = -(-len(part) // 8)
+        block = np.zeros((depth * 8, 4), np.int32)
+        block[:, 3] = SKIP
+        for j, r in enumerate(part):
+            x, i = divmod(j, depth)
+            block[i * 8 + x] = r[:4]
+        out.append(block)
+    return np.concatenate(out) if out else np.zeros((0, 4), np.int32)

@@ -56,4 +56,6 @@ def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, pu
     assert (((pk >> 6) & 63) - (pk & 63)).sum() == t["rec_b"].shape[0]
     nb = -(-res // m.BX) * -(-res // m.BY) * -(-res // m.BZ)
     pnb = -(-res // pull[0]) * -(-res // pull[1]) * -(-res // pull[2])
-    assert set(t["fwd_rows"][:, 0]) == set(range(nb)) and set(t["bwd_rows"][:, 0]) == set(range(pnb))
+    fr, br = t["fwd_rows"], t["bwd_rows"]
+    assert set(fr[fr[:, 3] != m.SKIP, 0]) == set(range(nb)) and set(br[br[:, 3] != m.SKIP, 0]) == set(range(pnb))
+    assert len(fr) % 8 == 0 and len(br) % 8 == 0                         # interleaved in groups of 8 (one row per XCD)
