@@ -459,8 +459,17 @@ def cpu_baseline(budget_s):
         for _ in range(5):
             backend.nnd_forward(x1, x2)
         res["nnd_cfg0_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+        # the same pair through the PRODUCT's host entry points (csrc/nnd_host.hip = the reference's my_lib.nnd_forward,
+        # the path its NNDFunction takes for CPU tensors), multi-threaded
+        import genre_shapehd_amd as G
+        a, b = torch.from_numpy(x1), torch.from_numpy(x2)
+        G.nndistance_w_idx(a, b)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            G.nndistance_w_idx(a, b)
+        res["nnd_cfg0_product_host_ms"] = (time.perf_counter() - t1) / 20 * 1e3
     except Exception as e:      # pragma: no cover
-        res["nnd_cfg0_ms"] = None
+        res.setdefault("nnd_cfg0_ms", None)
     return res
 
 

@@ -29,8 +29,8 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
                               brick does not own --, ownership bits (corner c, z half h) -> bit c + 4h, 0, 0, 8 weights)
   bwd_rows  int32 [rows,4]   (pull brick, ent begin, ent end, shared); shared = 1: the brick is split
                               over several rows, which add their tiles atomically onto pre-zeroed voxels.  The backward's
-                              ("pull") bricks are PULL = 8x8x8 voxels by default -- a segment then touches fewer bricks (each
-                              of which re-reads its saved samples) than with the forward's 4x8x8
+                              ("pull") bricks are PULL = 4x8x8 voxels like the forward's; 8x8x8 (a segment then touches fewer bricks,
+                              each of which re-reads its saved samples, but only one workgroup fits a CU) measured slower
 """
 import numpy as np
 
@@ -56,7 +56,7 @@ def _axis(d2a, a, size):
     return i0, w0.astype(np.float32), w1.astype(np.float32)
 
 
-PULL = (8, 8, 8)                # the backward's bricks (csrc/sph_render_bm.hip: pull_brick 488 or 888)
+PULL = (4, 8, 8)                # the backward's bricks (csrc/sph_render_bm.hip: pull_brick 488 or 888; 8x8x8 measured slower)
 
 
 def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split_b=SPLIT_B, pull=PULL):

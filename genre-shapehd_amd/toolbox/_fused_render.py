@@ -124,11 +124,14 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
     device; the float64 per-ray prefix table travels as its fp32 words"""
     import os
     from . import _bm_tables
-    dw = depth_weight.detach().cpu().numpy()
-    pull = {"488": (4, 8, 8), "888": (8, 8, 8)}[os.environ.get("GENRE_BM_PULL", "888")]      # backward brick (A/B switch)
-    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], dw.shape[0], hash(dw.tobytes()), str(device), pull)
+    pull = {"488": (4, 8, 8), "888": (8, 8, 8)}[os.environ.get("GENRE_BM_PULL", "488")]      # backward brick (A/B switch)
+    # keyed on the identity + version of the depth_weight buffer, not on its contents: no device -> host copy (and no
+    # stream synchronisation, which HIP-graph capture forbids) on the hot path
+    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], depth_weight.data_ptr(),
+           depth_weight._version, str(device), pull)
     t = _TABLES.get(key)
     if t is None:
+        dw = depth_weight.detach().cpu().numpy()
         np_t = _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), dw.shape[0], dw,
                                           pull=pull)
         t = {"pull_code": int(np_t["pull"][0]) * 100 + int(np_t["pull"][1]) * 10 + int(np_t["pull"][2])}
