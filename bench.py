@@ -249,7 +249,7 @@ def kernel_table(G, dev, B):
                     TB["bwd_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0, TB["pull_code"]), iters, 5),
                 bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
                 kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+bm_scatter_kernel",
-                pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel", "bm_scatter_kernel<true>"])
+                pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel<4, 8, 8>", "bm_scatter_kernel<true, 4, 8, 8, 768>"])
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3
     # forward-only chain (inference) at this batch size, standard layout and batch-minor layout
