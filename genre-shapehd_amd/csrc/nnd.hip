@@ -199,6 +199,86 @@ __global__ __launch_bounds__(kSlices * 64) void nnd_forward_kernel(int n, int m,
     }
 }
 
+// ---- small problems: a lone cloud pair ----------------------------------------------------------------------
+// With 128 queries per workgroup a single 2048 x 2048 pair (BASELINE.json configs[0]) is 32 workgroups = 32 of the
+// 256 CUs (15.6 us).  Here the roles are turned round: a workgroup owns kSQ = 16 queries, held in SCALAR registers,
+// the 256 lanes stride over the targets, and the per-lane minima are merged lexicographically on the 64-bit key
+// (distance bits << 32 | index) -- a non-negative float orders like its bit pattern, and the smaller index wins among
+// equal distances, which is the reference's "first strict minimum" (my_lib.c:19).  256 workgroups for that pair:
+// 7.8 us instead of 15.6 (HIP-graph replay; ~2.5 us of it is the launch).
+constexpr int kSQ = 16;
+
+__global__ __launch_bounds__(256) void nnd_forward_small_kernel(int n, int m, int qblocks1, const float *__restrict__ xyz1,
+                                                                 const float *__restrict__ xyz2, float *__restrict__ dist1,
+                                                                 int *__restrict__ idx1, float *__restrict__ dist2,
+                                                                 int *__restrict__ idx2)
+{
+    __shared__ unsigned long long s_key[kSQ][256];
+    const int b = blockIdx.y;
+    int qb = blockIdx.x;
+    const bool second = qb >= qblocks1;                        // direction 2 -> 1
+    if (second) qb -= qblocks1;
+    const int nq = second ? m : n, nt = second ? n : m;
+    const float *__restrict__ q = (second ? xyz2 : xyz1) + (size_t)b * nq * 3;
+    const float *__restrict__ t = (second ? xyz1 : xyz2) + (size_t)b * nt * 3;
+    float *__restrict__ dout = (second ? dist2 : dist1) + (size_t)b * nq;
+    int *__restrict__ iout = (second ? idx2 : idx1) + (size_t)b * nq;
+    float qx[kSQ], qy[kSQ], qz[kSQ], best[kSQ];
+    int bi[kSQ];
+#pragma unroll
+    for (int u = 0; u < kSQ; u++) {
+        const int j = min(qb * kSQ + u, nq - 1);              // uniform: scalar loads
+        qx[u] = q[j * 3 + 0]; qy[u] = q[j * 3 + 1]; qz[u] = q[j * 3 + 2];
+        bi[u] = -1;
+        best[u] = 0.f;
+    }
+    // eight targets per lane in flight (all of a 2048-point cloud): their loads are issued before the first is used
+    constexpr int kT = 8;
+    for (int k0 = threadIdx.x; k0 < nt; k0 += 256 * kT) {
+        float tx[kT], ty[kT], tz[kT];
+#pragma unroll
+        for (int i = 0; i < kT; i++) {
+            const int k = min(k0 + i * 256, nt - 1);
+            tx[i] = t[k * 3 + 0]; ty[i] = t[k * 3 + 1]; tz[i] = t[k * 3 + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < kT; i++) {
+            const int k = k0 + i * 256;
+            if (k < nt) {
+#pragma unroll
+                for (int u = 0; u < kSQ; u++) {
+                    const float d = sqdist(qx[u], qy[u], qz[u], tx[i], ty[i], tz[i]);
+                    if (bi[u] < 0 || d < best[u]) { best[u] = d; bi[u] = k; }  // my_lib.c:19 (k ascending per lane)
+                }
+            }
+        }
+    }
+    // merge: keys through LDS, transposed -- thread (u, r) takes 16 of query u's 256 keys, then a 16-lane DPP row
+    // minimum; no dependent chain of cross-lane operations
+#pragma unroll
+    for (int u = 0; u < kSQ; u++)
+        s_key[u][threadIdx.x] = bi[u] < 0 ? ~0ull : (((unsigned long long)__float_as_uint(best[u])) << 32) | (unsigned)bi[u];
+    __syncthreads();
+    const int u = threadIdx.x >> 4, r = threadIdx.x & 15;
+    unsigned long long key = ~0ull;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const unsigned long long o = s_key[u][i * 16 + r];                       // lanes of a row read 16 consecutive keys
+        key = o < key ? o : key;
+    }
+#pragma unroll
+    for (int sh = 1; sh < 16; sh <<= 1) {                                         // xor butterfly inside the 16-lane row
+        const unsigned long long o = __shfl_xor(key, sh, 16);
+        key = o < key ? o : key;
+    }
+    const int j = qb * kSQ + u;
+    if (r == 0 && j < nq) {
+        const bool none = key == ~0ull;                         // nt == 0 leaves (0, 0) like my_lib.c:12-13
+        dout[j] = none ? 0.f : __uint_as_float((unsigned)(key >> 32));
+        iout[j] = none ? 0 : (int)(unsigned)key;
+    }
+}
+
 // Backward, pass A: each point's own term (plain store, initialises the outputs;
 // replaces the two cudaMemset + atomicAdd-onto-zero of nnd_cuda.cu:150-155,164-165).
 __global__ __launch_bounds__(256) void nnd_backward_own_kernel(int n, int m,
@@ -291,6 +371,14 @@ extern "C" int genre_nnd_forward(const genre_tensor *xyz1, const genre_tensor *x
     if (B == 0 || qb1 + qb2 == 0) return 1;
     // slices per workgroup: as few as still put ~8 waves on each of the 1024 SIMDs
     const int64_t groups = (int64_t)B * (qb1 + qb2);
+    if (groups <= 128 && n >= 1 && m >= 1) {        // too few 128-query workgroups for 256 CUs: 16-query workgroups
+        const int sq1 = ceil_div(n, kSQ), sq2 = ceil_div(m, kSQ);
+        nnd_forward_small_kernel<<<dim3(sq1 + sq2, (unsigned)B), 256, 0, (hipStream_t)stream>>>(
+            (int)n, (int)m, sq1, (const float *)xyz1->data, (const float *)xyz2->data, (float *)dist1->data,
+            (int *)idx1->data, (float *)dist2->data, (int *)idx2->data);
+        GENRE_LAUNCH_CHECK("nnd updateOutput (small)");
+        return 1;
+    }
     int slices = kMaxSlices;
     while (slices > 2 && groups * (slices / 2) >= 8192) slices /= 2;
     const dim3 grid(qb1 + qb2, (unsigned)B);

@@ -77,3 +77,16 @@ def test_self_distance_zero(genre, dev):
     assert (d1 == 0).all() and (d2 == 0).all()
     ar = torch.arange(8192, device=dev, dtype=torch.int32).expand(4, -1)
     assert (i1 == ar).all() and (i2 == ar).all()
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 2048, 2048), (2, 300, 1000), (1, 17, 2048), (5, 33, 16)])
+def test_small_problem_kernel_with_exact_ties(b, n, m, genre, oracle, dev):
+    """few 128-query workgroups (a lone cloud pair, configs[0]) take the 16-queries-per-workgroup kernel whose minima
+    are merged on (distance bits, index) keys: the lowest index among equal distances must win, as in my_lib.c:19"""
+    x1, x2 = inputs.clouds(b, n, m, seed1=3 * n + b, seed2=5 * m + b)
+    x1 = (np.round(x1 * 6) / 6).astype(np.float32)             # coarse lattice: many exactly equal distances
+    x2 = (np.round(x2 * 6) / 6).astype(np.float32)
+    d1o, d2o, i1o, i2o = oracle.nnd_forward(x1, x2)
+    d1, d2, i1, i2 = genre.nndistance_w_idx(t(x1, dev), t(x2, dev))
+    assert np.array_equal(i1.cpu().numpy(), i1o) and np.array_equal(i2.cpu().numpy(), i2o)
+    assert np.array_equal(d1.cpu().numpy(), d1o) and np.array_equal(d2.cpu().numpy(), d2o)

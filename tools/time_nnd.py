@@ -3,7 +3,7 @@ sys.path.insert(0,os.environ.get("GRAFT_REPO_ROOT","/root/repo"))
 import torch
 from genre_shapehd_amd.toolbox.nndistance._ext import my_lib
 dev=torch.device("cuda:0")
-for B in (8,16,32,64,128):
+for B in (1,2,3,4,8,16,32,64,128):
     n=2048
     a=torch.rand((B,n,3),device=dev); b=torch.rand((B,n,3),device=dev)
     d1=torch.empty((B,n),device=dev); d2=torch.empty_like(d1); i1=torch.empty((B,n),device=dev,dtype=torch.int32); i2=torch.empty_like(i1)
