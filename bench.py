@@ -39,39 +39,49 @@ BYTES_CP_BWD_FUSED = 4 * 128 * 128 * 256 * 4              # p, s, grad in + grad
 BYTES_RENDER_FUSED = 128 ** 3 * 4 + 128 * 128 * 4         # vox in + map out           =  8 454 144
 
 
-def source_sha():
-    """sha256 over the kernel sources: identifies the code a PMC table was measured on (the GPU box has no .git)"""
+def source_sha(files=None):
+    """sha256 of kernel sources: identifies the code a PMC table was measured on (the GPU box has no .git).
+    files=None: one hash over all of csrc/*.hip|*.hpp; else {file: hash} for the named files"""
     import hashlib
-    h = hashlib.sha256()
     csrc = os.path.join(ROOT, "genre-shapehd_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".hpp")):
-            with open(os.path.join(csrc, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
+    names = sorted(n for n in os.listdir(csrc) if n.endswith((".hip", ".hpp")))
+    if files is not None:
+        out = {}
+        for n in files:
+            with open(os.path.join(csrc, n), "rb") as f:
+                out[n] = hashlib.sha256(f.read()).hexdigest()[:16]
+        return out
+    h = hashlib.sha256()
+    for name in names:
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_names, batch):
+def pmc_traffic(kernel_names, batch, sources=("common.hpp",)):
     """HBM bytes per launch of a kernel group from the newest committed PMC table (profiles/*_pmc_hbm_traffic.json,
     written by profiles/collect_pmc.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, corrected as
-    MI355X_MICROARCH.md prescribes).  None -- never a stale number -- unless the table was measured on exactly these
-    kernel sources and this batch size."""
+    MI355X_MICROARCH.md prescribes).  None -- never a stale number -- unless the table was measured on exactly the
+    source files that define these kernels (`sources`) and on this batch size."""
     import glob
     tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
     if not tables:
         return None, None
     with open(tables[-1]) as f:
         t = json.load(f)
-    if t.get("source_sha") != source_sha() or t.get("batch") != batch:
-        return None, "%s is for sources %s / batch %s, not %s / %d" % (
-            os.path.basename(tables[-1]), t.get("source_sha"), t.get("batch"), source_sha(), batch)
+    name = os.path.basename(tables[-1])
+    mine = source_sha(sources)
+    theirs = t.get("source_sha_by_file", {})
+    stale = [n for n in sources if theirs.get(n) != mine[n]]
+    if stale or t.get("batch") != batch:
+        return None, "%s was measured on other versions of %s / batch %s" % (name, stale, t.get("batch"))
     total = 0.0
     for k in kernel_names:
         row = t["kernels"].get(k)
         if row is None:
-            return None, "%s has no row for %s" % (os.path.basename(tables[-1]), k)
+            return None, "%s has no row for %s" % (name, k)
         total += row["hbm_bytes"]
-    return total, "profiles/" + os.path.basename(tables[-1])
+    return total, "profiles/" + name
 
 
 def parse():
@@ -189,12 +199,14 @@ def kernel_table(G, dev, B):
     rows = {}
     t = event_time_us(lambda: cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt), iters, 5)
     rows["cam_bp_fwd"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="fill2_vec4+scatter_tile+normalise_tile",
-                              pmc=["fill2_vec4_kernel", "scatter_tile_kernel<false>", "normalise_tile_kernel<false>"])
+                              pmc=["fill2_vec4_kernel", "scatter_tile_kernel<false>", "normalise_tile_kernel<false>"],
+                              src=("common.hpp", "cam_bp.hip"))
     t = event_time_us(lambda: calc_prob_lib.calc_prob_forward(p, s), iters, 5)
-    rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel", pmc=["stop_fwd_vec4_kernel"])
+    rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel", pmc=["stop_fwd_vec4_kernel"],
+                                 src=("common.hpp", "wave_scan.hpp", "calc_prob.hip"))
     t = event_time_us(lambda: calc_prob_lib.calc_prob_backward_fused(p, s, g, o), iters, 5)
     rows["calc_prob_bwd_fused"] = dict(us=t, bytes=B * BYTES_CP_BWD_FUSED, kernels="stop_bwd_vec4_kernel<fused>",
-                                       pmc=["stop_bwd_vec4_kernel<true>"])
+                                       pmc=["stop_bwd_vec4_kernel<true>"], src=("common.hpp", "wave_scan.hpp", "calc_prob.hip"))
     from genre_shapehd_amd.toolbox import _fused_render
     fused_ok = _fused_render.available()
     if fused_ok:
@@ -213,13 +225,15 @@ def kernel_table(G, dev, B):
             proj, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0), iters, 5)
         rows["render_fwd_fused"] = dict(us=t, bytes=B * BYTES_RENDER_FUSED,
                                         kernels="render_sample_brick_group_kernel+render_scan_fwd_kernel",
-                                        pmc=["render_sample_brick_group_kernel<2, 512>", "render_scan_fwd_kernel"])
+                                        pmc=["render_sample_brick_group_kernel<2, 512>", "render_scan_fwd_kernel"],
+                                        src=("common.hpp", "wave_scan.hpp", "sph_render.hip"))
         t = event_time_us(lambda: render_lib.render_spherical_backward(
             proj, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"], vbuf, T["kin"], 50.0),
             iters, 5)
         rows["render_bwd_fused"] = dict(us=t, bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
                                         kernels="render_scan_bwd_kernel+zero_shared_bricks_kernel+render_bwd_brick_kernel",
-                                        pmc=["render_scan_bwd_kernel", "zero_shared_bricks_kernel", "render_bwd_brick_kernel"])
+                                        pmc=["render_scan_bwd_kernel", "zero_shared_bricks_kernel", "render_bwd_brick_kernel"],
+                                        src=("common.hpp", "wave_scan.hpp", "sph_render.hip"))
         if B >= 16:     # batch-minor tile renderer (csrc/sph_render_bm.hip): the volume with the image index fastest
             layer = G.Camera_back_projection_layer(batch_minor=True).to(dev)
             with torch.no_grad():
@@ -240,7 +254,8 @@ def kernel_table(G, dev, B):
                                              mask if save else None, 50.0)
             rows["render_fwd_bm"] = dict(us=event_time_us(lambda: bm_fwd(True), iters, 5), bytes=B * BYTES_RENDER_FUSED,
                                          kernels="bm_sample_kernel+bm_combine_fwd_kernel",
-                                         pmc=["bm_sample_kernel<true, true, 1024>", "bm_combine_fwd_kernel"])
+                                         pmc=["bm_sample_kernel<true, true, 1024>", "bm_combine_fwd_kernel"],
+                                         src=("common.hpp", "sph_render_bm.hip"))
             rows["render_fwd_bm_nosave"] = dict(us=event_time_us(lambda: bm_fwd(False), iters, 5),
                                                 bytes=B * BYTES_RENDER_FUSED, kernels="bm_sample_kernel (no saved state)")
             rows["render_bwd_bm"] = dict(
@@ -249,7 +264,8 @@ def kernel_table(G, dev, B):
                     TB["bwd_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0, TB["pull_code"]), iters, 5),
                 bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
                 kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+bm_scatter_kernel",
-                pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel<4, 8, 8>", "bm_scatter_kernel<true, 4, 8, 8, 768>"])
+                pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel<4, 8, 8>", "bm_scatter_kernel<true, 4, 8, 8, 768>"],
+                src=("common.hpp", "sph_render_bm.hip"))
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3
     # forward-only chain (inference) at this batch size, standard layout and batch-minor layout
@@ -553,7 +569,7 @@ def main():
             in_step = ["cam_bp_fwd", "render_fwd_fused", "render_bwd_fused"]
         dom_name = max(in_step, key=lambda k: rows[k]["us"])
         dom = rows[dom_name]
-        traffic, traffic_src = pmc_traffic(dom.get("pmc", []), B)
+        traffic, traffic_src = pmc_traffic(dom.get("pmc", []), B, dom.get("src", ("common.hpp",)))
         m2_us = rows["cam_bp_fwd"]["us"] + rows["calc_prob_fwd"]["us"]
         m2_bytes = rows["cam_bp_fwd"]["bytes"] + rows["calc_prob_fwd"]["bytes"]
         b1 = batch1_graph(G, dev)

@@ -52,6 +52,8 @@ if len(sys.argv) > 3:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     with open(sys.argv[3], "w") as fh:
-        json.dump(dict(source_sha=bench.source_sha(), batch=int(sys.argv[4]), kernels=table,
+        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "genre-shapehd_amd", "csrc")
+        names = sorted(n for n in os.listdir(csrc) if n.endswith((".hip", ".hpp")))
+        json.dump(dict(source_sha=bench.source_sha(), source_sha_by_file=bench.source_sha(names), batch=int(sys.argv[4]), kernels=table,
                        how="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over profiles/pmc_targets.py"),
                   fh, indent=1, sort_keys=True)
