@@ -773,13 +773,14 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
 // needs so that the XCDs' L2s agree; a kernel boundary inside a HIP graph costs ~1 us.)
 // The spherical path always scatters.
 enum CamMode { kScatter, kGather };
+// The only process-level setting the library reads: the environment variable GENRE_CAMBP_MODE (scatter | gather), looked up
+// ONCE at the first camera forward and constant afterwards -- a read-only configuration value, not mutable state: calls
+// stay re-entrant and independent of one another (include/genre_hip.h: "keeps no global state").
 inline CamMode cam_mode()
 {
     static const CamMode m = [] {
         const char *e = getenv("GENRE_CAMBP_MODE");
-        if (e) return e[0] == 'g' ? kGather : kScatter;
-        const char *g = getenv("GENRE_CAMBP_GATHER");
-        return (g && g[0] == '1') ? kGather : kScatter;
+        return (e && e[0] == 'g') ? kGather : kScatter;
     }();
     return m;
 }

@@ -9,7 +9,8 @@
  * `hipStream_t` (passed as void*) is appended.  Conventions kept from the
  * reference:
  *   - the caller allocates every output (cam_back_projection.py:22-25,39-45);
- *     the library never allocates device memory and keeps no global state;
+ *     the library never allocates device memory and keeps no mutable global state (one
+ *     read-only environment setting, GENRE_CAMBP_MODE=scatter|gather, is looked up once);
  *   - return 1 on success, 0 on failure (back_projection.c:13-15 turns 0 into
  *     THError("aborting")); on 0, genre_last_error() returns a thread-local
  *     message -- shape/dtype violations that THArgCheck / THCUNN_check_dim_size

@@ -62,7 +62,7 @@ def _odd_cases():
 
 
 def check_forward_cases(oracle, dev, exact):
-    """shared by the in-process (scatter) test and the GENRE_CAMBP_GATHER=1 subprocess: cnt exact always;
+    """shared by the in-process (scatter) test and the GENRE_CAMBP_MODE=gather subprocess: cnt exact always;
     tdf bit-exact on every voxel when `exact`, else <= 1e-5 and bit-exact where a voxel has one point"""
     from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
     fl1, cd1 = inputs.cam_params(1)

@@ -133,26 +133,37 @@ def test_non_finite_upstream_gradient_is_not_swallowed(layout, genre, dev):
     assert torch.isnan(grad[3]).any() and torch.isnan(grad[5]).any()
 
 
-@pytest.mark.parametrize("n", [16, 32])
-def test_batch_minor_small_geometry_against_oracle(n, genre, oracle, dev):
-    """the batch-minor kernels (forward and backward) directly against the CPU reference chain at a size the oracle
-    finishes in a second: 32^3 volume, 24x24 rays x 64 samples, every image checked"""
-    from oracle.torch_oracle import RenderSphericalCPU
-    res, sph, zr = 32, 24, 64
-    rng = np.random.default_rng(90 + n)
+@pytest.mark.parametrize("n,res,sph,zr,pre_scale,pad", [(16, 32, 24, 64, None, 0), (32, 32, 24, 64, None, 0),
+                                                       (17, 33, 20, 100, 3.0, 4), (40, 24, 16, 32, None, 8),
+                                                       (16, 13, 8, 12, 2.0, 0)])
+def test_batch_minor_small_geometry_against_oracle(n, res, sph, zr, pre_scale, pad, genre, oracle, dev):
+    """the batch-minor kernels (forward and backward) directly against the CPU reference chain at sizes the oracle
+    finishes in a second, every image checked: volumes that are not a multiple of the 4x8x8 brick (partial bricks,
+    tiles that stick out of the volume), batches that are not a multiple of 32 (a partly filled image group, two
+    groups), short rays, the folded clamp and the padded map"""
+    from oracle.torch_oracle import RenderSphericalCPU, RenderSphericalExact, sph_pad
+    rng = np.random.default_rng(90 + n + res)
     ax = (np.arange(res) + 0.5) / res - 0.5
     vols = np.empty((n, 1, res, res, res), np.float32)
     for i in range(n):
         c = (rng.random(3) - 0.5) * 0.3
         r2 = (ax[:, None, None] - c[0]) ** 2 + (ax[None, :, None] - c[1]) ** 2 + (ax[None, None, :] - c[2]) ** 2
         vols[i, 0] = np.clip(0.002 + 0.95 * (r2 < (0.12 + 0.1 * rng.random()) ** 2) + rng.uniform(0, 0.01, r2.shape), 2e-5, 1 - 2e-5)
+    if pre_scale:
+        vols = (vols / np.float32(pre_scale) * np.float32(1.2)).astype(np.float32)   # some voxels clamp at the top
     vc = torch.from_numpy(vols).requires_grad_(True)
-    ref = RenderSphericalCPU(oracle, sph, zr)(vc)
+    vin = vc if not pre_scale else torch.clamp(vc * pre_scale, 1e-5, 1 - 1e-5)
+    ref = RenderSphericalCPU(oracle, sph, zr)(vin)
+    if pad:
+        ref = sph_pad(ref, pad)
     g = torch.from_numpy(rng.standard_normal(ref.shape).astype(np.float32))
-    ref.backward(g)
+    # gradient yardstick: the exact value of the operator (the fp32 chain itself is ~1e-4 off, see the module docstring)
+    ex = RenderSphericalExact(sph, zr)(vin)
+    (sph_pad(ex, pad) if pad else ex).backward(g.double())
     xb = _batch_minor(torch.from_numpy(vols).to(dev)).requires_grad_(True)
-    out = genre.render_spherical(sph, zr, fused=True).to(dev)(xb)
+    out = genre.render_spherical(sph, zr, fused=True).to(dev)(xb, pre_scale=pre_scale, pad=pad)
     out.backward(g.to(dev))
+    assert xb.grad.stride(0) == 1
     assert (out.detach().cpu() - ref.detach()).abs().max().item() <= TOL
-    err = ((xb.grad.cpu() - vc.grad).abs() / vc.grad.abs().clamp(min=1.0)).max().item()
+    err = ((xb.grad.cpu() - vc.grad).abs() / vc.grad.abs().clamp(min=max(1.0, pre_scale or 1.0))).max().item()
     assert err <= TOL, err
