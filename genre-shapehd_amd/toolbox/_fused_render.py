@@ -107,16 +107,55 @@ def build_brick_tables(X, Y, Z, dirs64, z_res, split=SPLIT_BWD, split_fwd=SPLIT_
     return dict(bwd_table=bwd_table, bwd_chunks=bwd_chunks, fwd_table=fwd_table, fwd_chunks=fwd_chunks, kin=kin)
 
 
+def _disk_cached(kind, key, arrays_for_hash, build):
+    """geometry tables cost seconds of numpy on first use; they depend on the geometry only, so they are kept under
+    $GENRE_TABLE_CACHE (default ~/.cache/genre_shapehd_amd; "0" disables) as .npz, keyed by a hash of every input
+    and of the builder's source.  Never fatal: any cache problem falls back to building."""
+    import hashlib
+    import inspect
+    import os
+    root = os.environ.get("GENRE_TABLE_CACHE", os.path.join(os.path.expanduser("~"), ".cache", "genre_shapehd_amd"))
+    if root == "0":
+        return build()
+    h = hashlib.sha256(repr(key).encode())
+    for a in arrays_for_hash:
+        h.update(np.ascontiguousarray(a).tobytes())
+    h.update(inspect.getsource(inspect.getmodule(build)).encode())
+    path = os.path.join(root, "%s_%s.npz" % (kind, h.hexdigest()[:20]))
+    try:
+        if os.path.exists(path):
+            with np.load(path) as z:
+                return {k: z[k] for k in z.files}
+    except Exception:
+        pass
+    t = build()
+    try:
+        os.makedirs(root, exist_ok=True)
+        tmp = "%s.%d.tmp.npz" % (path, os.getpid())
+        np.savez(tmp, **t)
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return t
+
+
 def tables_for(vox_shape, device, dirs64, z_res):
     small = vox_shape[0] * vox_shape[1] < SMALL_BATCH
     key = (tuple(vox_shape[2:]), dirs64.shape[0], z_res, str(device), small)
     t = _TABLES.get(key)
     if t is None:
-        np_t = build_brick_tables(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), z_res,
-                                  split_fwd=SPLIT_FWD_SMALL if small else SPLIT_FWD)
+        d64 = dirs64.cpu().numpy()
+        sf = SPLIT_FWD_SMALL if small else SPLIT_FWD
+        np_t = _disk_cached("brick", (tuple(vox_shape[2:]), z_res, sf, SPLIT_BWD, BRICK), [d64],
+                            lambda: build_brick_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, z_res, split_fwd=sf))
         t = {k: torch.from_numpy(v).to(device) for k, v in np_t.items()}
         _TABLES[key] = t
     return t
+
+
+def _bm_tables_module():
+    from . import _bm_tables
+    return _bm_tables
 
 
 def bm_tables_for(vox_shape, device, dirs64, depth_weight):
@@ -132,8 +171,13 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
     t = _TABLES.get(key)
     if t is None:
         dw = depth_weight.detach().cpu().numpy()
-        np_t = _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], dirs64.cpu().numpy(), dw.shape[0], dw,
-                                          pull=pull)
+        d64 = dirs64.cpu().numpy()
+
+        def build():
+            return _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, pull=pull)
+        build.__module__ = _bm_tables.__name__
+        np_t = _disk_cached("bm", (tuple(vox_shape[2:]), pull, _bm_tables.ROW_ORDER, _bm_tables.SPLIT_F,
+                                   _bm_tables.SPLIT_B, _bm_tables.MAXSEG), [d64, dw], build)
         t = {"pull_code": int(np_t["pull"][0]) * 100 + int(np_t["pull"][1]) * 10 + int(np_t["pull"][2])}
         for k, v in np_t.items():
             if k == "pull":

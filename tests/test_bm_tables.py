@@ -59,3 +59,23 @@ def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, pu
     pnb = -(-res // pull[0]) * -(-res // pull[1]) * -(-res // pull[2])
     fr, br = t["fwd_rows"], t["bwd_rows"]
     assert set(fr[fr[:, 3] != m.SKIP, 0]) == set(range(nb)) and set(br[br[:, 3] != m.SKIP, 0]) == set(range(pnb))
+
+
+def test_tables_are_cached_on_disk(tmp_path, monkeypatch):
+    """geometry tables depend on the geometry only: built once, then read back from $GENRE_TABLE_CACHE"""
+    import genre_shapehd_amd as G
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    monkeypatch.setenv("GENRE_TABLE_CACHE", str(tmp_path))
+    mod = G.render_spherical(sph_res=8, z_res=16, fused=False)
+    args = ((16, 1, 12, 12, 12), torch.device("cpu"), mod._dirs64, mod.depth_weight)
+    monkeypatch.setattr(F, "_TABLES", {})
+    a = F.bm_tables_for(*args)
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert len(files) == 1 and files[0].startswith("bm_") and files[0].endswith(".npz")
+    monkeypatch.setattr(F, "_TABLES", {})
+    calls = []
+    monkeypatch.setattr(F._bm_tables_module(), "build_bm_tables", lambda *x, **k: calls.append(1))
+    b = F.bm_tables_for(*args)                                           # served from the file: the builder is not called
+    assert not calls and set(a) == set(b)
+    for k in a:
+        assert a[k] == b[k] if isinstance(a[k], int) else torch.equal(a[k], b[k]), k
