@@ -198,9 +198,8 @@ def kernel_table(G, dev, B):
     iters = 20
     rows = {}
     t = event_time_us(lambda: cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt), iters, 5)
-    rows["cam_bp_fwd"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="fill2_vec4+scatter_tile+normalise_tile",
-                              pmc=["fill2_vec4_kernel", "scatter_tile_kernel<false>", "normalise_tile_kernel<false>"],
-                              src=("common.hpp", "cam_bp.hip"))
+    rows["cam_bp_fwd"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="cam_brick_kernel (dense NCXYZ outputs: one launch)",
+                              pmc=["cam_brick_kernel"], src=("common.hpp", "cam_bp.hip"))
     t = event_time_us(lambda: calc_prob_lib.calc_prob_forward(p, s), iters, 5)
     rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel", pmc=["stop_fwd_vec4_kernel"],
                                  src=("common.hpp", "wave_scan.hpp", "calc_prob.hip"))
@@ -337,9 +336,9 @@ def batch1_graph(G, dev):
     us = event_time_us(graph.replay, 20, 3) / reps
     nbytes = BYTES_CAM_FWD + BYTES_CP_FWD
     res = dict(us_per_image=us, GBs=nbytes / us / 1e3, frac=nbytes / us / 1e3 / HBM_PEAK_GBS,
-               launches_per_image=4, note="HIP-graph replay of 20x(cam_bp fwd + calc_prob fwd), batch 1")
+               launches_per_image=2, note="HIP-graph replay of 20x(cam_bp fwd [cam_brick_kernel] + calc_prob fwd), batch 1")
     try:
-        # The same 20 + 20 calls as TWO request streams inside one graph: cam_bp's three launch-bound kernels of image
+        # The same 20 + 20 calls as TWO request streams inside one graph: cam_bp's latency-bound kernel of image
         # i+1 run beside calc_prob's bandwidth-bound kernel of image i (a server pipelining consecutive batch-1
         # requests over two HIP streams).  Reported beside the serial figure, never instead of it.
         s2 = torch.cuda.Stream()

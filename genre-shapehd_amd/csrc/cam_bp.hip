@@ -38,11 +38,22 @@ __device__ __forceinline__ int floor_i(float a) { return (a < 0.0f) ? (int)a - 1
 __device__ __forceinline__ int vox_index(float g, int res) { return floor_i((g + 0.5f) * (float)res); }
 // :195-196 (vec3d_norm): left-to-right sum, correctly rounded sqrt
 __device__ __forceinline__ float norm3(float a, float b, float c) { return sqrtf(a * a + b * b + c * c); }
-// fp32 centre (:258-260) and the fp64-literal variant used by K3/K4/K6 (:336-338,:428-430,:596-598)
-__device__ __forceinline__ float centre_f(int i, int R) { return (((float)i + 0.5f) / (float)R) - 0.5f; }
+// fp32 centre (:258-260) and the fp64-literal variant used by K3/K4/K6 (:336-338,:428-430,:596-598).  Dividing by a
+// power-of-two resolution (the reference's 128) is an exact scaling: multiplying by 2^-k -- built from its exponent bits on
+// the scalar unit -- gives the identical bits without the ~30-instruction correctly rounded division (three per point).
+__device__ __forceinline__ bool pow2(int R) { return R > 0 && (R & (R - 1)) == 0; }
+__device__ __forceinline__ float centre_f(int i, int R)
+{
+    const float n = (float)i + 0.5f;
+    const float q = pow2(R) ? n * __int_as_float((127 - __builtin_ctz((unsigned)R)) << 23) : n / (float)R;
+    return q - 0.5f;
+}
 __device__ __forceinline__ float centre_d(int i, int R)
 {
-    return (float)((((double)(float)i + 0.5) / (double)(float)R) - 0.5);
+    const double n = (double)(float)i + 0.5;
+    const double q = pow2(R) ? n * __longlong_as_double((long long)(1023 - __builtin_ctz((unsigned)R)) << 52)
+                             : n / (double)(float)R;
+    return (float)(q - 0.5);
 }
 
 struct Dims { int N, NC, H, W, X, Y, Z; };
@@ -510,6 +521,176 @@ __global__ __launch_bounds__(kBlock) void cam_gather_kernel(Dims D, View4 depth,
     }
 }
 
+// ---- camera forward, single-launch BRICK formulation (small batches) ---------------------------------
+// At batch 1 the three launches above are bound by their boundaries, not by their 17 MB of traffic.  Here a
+// workgroup owns an 8x8x32 voxel brick (1024 workgroups per 128^3 image: four per CU, so the 16 MB of stores have
+// the memory parallelism the 256-workgroup gather kernel lacks) and does all three phases for it:
+//   (a) every thread fetches its share of the depth pixels under the brick's footprint (~23 x 71 px: 6 loads per
+//       thread, all in flight together) -- the wave/workgroup min/max of those depths rejects the ~90 % of bricks no
+//       point can reach, which then cost only their float4 stores;
+//   (b) live bricks: every footprint pixel is evaluated ONCE, by the thread that fetched it, with the reference's
+//       arithmetic (pixel_voxel); a point that lands inside the brick is added to the brick's LDS tile --
+//       ds_add_f64 for the distance (8.7 clk per wave-instruction on gfx950 against 193 for ds_add_f32,
+//       tools/bm_tile_bench.hip), ds_add_u32 for the count;
+//   (c) the tile is normalised (K2, :291-305) and written with one float4 per thread and array.
+// A voxel hit by one point is bit-exact: its double sum IS that distance, and fl(fl(prefill + dist) - bias) is the
+// reference's sequence.  Voxels hit more than once add their (exact) distances in double instead of in the
+// reference's undefined fp32 atomic order: <= 1 ulp of 1/res from any of its orders, and deterministic.
+// wave-wide min / max / or with DPP (row shifts + row broadcasts, as wave_scan.hpp): the total lands in lane 63 and
+// is broadcast through a scalar register -- ~20 vector instructions instead of 18 dependent ds_bpermute round trips
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_keep(int identity, int v)
+{
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <typename F>
+__device__ __forceinline__ int wave_reduce_bits(int v, int identity, F op)
+{
+    v = op(v, dpp_keep<0x111, 0xf>(identity, v));       // row_shr:1
+    v = op(v, dpp_keep<0x112, 0xf>(identity, v));       // row_shr:2
+    v = op(v, dpp_keep<0x114, 0xf>(identity, v));       // row_shr:4
+    v = op(v, dpp_keep<0x118, 0xf>(identity, v));       // row_shr:8
+    v = op(v, dpp_keep<0x142, 0xa>(identity, v));       // row_bcast:15 into rows 1, 3
+    v = op(v, dpp_keep<0x143, 0xc>(identity, v));       // row_bcast:31 into rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+constexpr int kQX = 8, kQY = 8, kQZ = 32;
+constexpr int kQVox = kQX * kQY * kQZ;
+constexpr int kQDeep = 8;                          // footprint pixels a thread keeps in registers
+
+// t = r * d + q, 0 <= q < d: a float multiply and one correction step instead of an integer division (the quotient
+// estimate is within one of the truth for t < 2^22: both roundings together stay below half a unit)
+__device__ __forceinline__ void divmod_px(int t, int d, float inv_d, int &r, int &q)
+{
+    if (t >= (1 << 22)) { r = t / d; q = t - r * d; return; }
+    r = (int)((float)t * inv_d);
+    q = t - r * d;
+    if (q < 0) { r--; q += d; }
+    else if (q >= d) { r++; q -= d; }
+}
+
+__global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, View2 camdist, View2 fl, View5 vox,
+                                                            View5 cnt, float prefill, float bias, float post_scale,
+                                                            float post_bias, float fill_val, int vec_ok)
+{
+    __shared__ double s_sum[kQVox];
+    __shared__ unsigned s_cnt[kQVox];
+    __shared__ float s_min[kBlock / 64], s_max[kBlock / 64];
+    __shared__ int s_any[kBlock / 64];
+    const int nbz = (D.Z + kQZ - 1) / kQZ, nby = (D.Y + kQY - 1) / kQY;
+    const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
+    const int img = blockIdx.y, n = img / D.NC, c = img % D.NC;
+    const float f = fl.p[n * fl.s0 + c * fl.s1];
+    const float cam_dist = camdist.p[n * camdist.s0 + c * camdist.s1];
+    const float *dimg = depth.p + n * depth.s0 + c * depth.s1;
+    float *vimg = vox.p + n * vox.s0 + c * vox.s1, *cimg = cnt.p + n * cnt.s0 + c * cnt.s1;
+    const int x0 = bx * kQX, y0 = by * kQY, z0 = bz * kQZ;
+    const int x1 = min(x0 + kQX, D.X), y1 = min(y0 + kQY, D.Y), z1 = min(z0 + kQZ, D.Z);
+    const float rX = 1.0f / (float)D.X, rY = 1.0f / (float)D.Y, rZ = 1.0f / (float)D.Z;
+    const float bxlo = (float)x0 * rX - 0.5f, bxhi = (float)x1 * rX - 0.5f;
+    const Win bw = project_box(D, bxlo, bxhi, (float)y0 * rY - 0.5f, (float)y1 * rY - 0.5f, (float)z0 * rZ - 0.5f,
+                               (float)z1 * rZ - 0.5f, cam_dist, f, 1.0f);
+    const int bww = bw.w1 - bw.w0 + 1, bwh = bw.h1 - bw.h0 + 1;
+    const int area = (bww > 0 && bwh > 0) ? bww * bwh : 0;
+    // ---- (a) footprint: the first kQDeep x 256 pixels stay in registers for (b); larger footprints (camera inside
+    // the grid) are screened here and fetched again there
+    Band bb{3.0e38f, 0.0f, 0};
+    const float inv_bww = 1.0f / (float)(bww > 0 ? bww : 1);
+    auto fetch = [&](int t) {
+        int r, q;
+        divmod_px(t, bww, inv_bww, r, q);
+        return dimg[(bw.h0 + r) * depth.s2 + (bw.w0 + q) * depth.s3];
+    };
+    float dv[kQDeep];
+#pragma unroll
+    for (int u = 0; u < kQDeep; u++) {
+        const int t = threadIdx.x + u * kBlock;
+        dv[u] = t < area ? fetch(t) : -1.0f;
+    }
+    auto screen = [&](float d) {
+        if (d > 0.0f) { bb.dmin = fminf(bb.dmin, d); bb.dmax = fmaxf(bb.dmax, d); }
+        else if (!(d < 0.0f)) bb.any_zero = 1;          // d == 0 (or NaN): lands at x = -cam_dist
+    };
+#pragma unroll
+    for (int u = 0; u < kQDeep; u++)
+        if ((int)threadIdx.x + u * kBlock < area) screen(dv[u]);
+    for (int t = threadIdx.x + kQDeep * kBlock; t < area; t += kBlock) screen(fetch(t));
+    // positive floats order like their bit patterns: min / max of the depths as integers (dmin starts at 3e38, dmax at 0)
+    bb.dmin = __int_as_float(wave_reduce_bits(__float_as_int(bb.dmin), 0x7f7fffff, [](int a, int b) { return a < b ? a : b; }));
+    bb.dmax = __int_as_float(wave_reduce_bits(__float_as_int(bb.dmax), 0, [](int a, int b) { return a > b ? a : b; }));
+    bb.any_zero = wave_reduce_bits(bb.any_zero, 0, [](int a, int b) { return a | b; });
+    if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = bb.dmin; s_max[threadIdx.x >> 6] = bb.dmax; s_any[threadIdx.x >> 6] = bb.any_zero; }
+    // the tile is cleared before the brick is known to be live: the stores ride under the reduction's barrier
+    for (int e = threadIdx.x; e < kQVox; e += kBlock) { s_sum[e] = 0.0; s_cnt[e] = 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; i++) { bb.dmin = fminf(bb.dmin, s_min[i]); bb.dmax = fmaxf(bb.dmax, s_max[i]); bb.any_zero |= s_any[i]; }
+    float blo, bhi;
+    bool bspecial;
+    const bool live = slab_live(bb, bw, bxlo, bxhi, cam_dist, f, blo, bhi, bspecial);
+    if (live) {
+        // ---- (b) every footprint pixel once, by the thread that fetched it: a cheap plane-depth test first (1-ulp
+        // rsqrt, generous margin, as in cam_gather_kernel -- only ~1/16 of the footprint's points lie in this brick's x
+        // range), the reference's arithmetic (pixel_voxel) for the survivors
+        const float xlo_t = bxlo - 1e-5f, xhi_t = bxhi + 1e-5f;
+        auto pixel = [&](int t, float d_raw) {
+            if (d_raw < 0.0f) return;                                       // :225
+            int r, q;
+            divmod_px(t, bww, inv_bww, r, q);
+            const int h = bw.h0 + r, w = bw.w0 + q;
+            if (!bspecial) {
+                const float u_h = (float)h - ((float)D.H - 1.0f) / 2.0f, u_w = (float)w - ((float)D.W - 1.0f) / 2.0f;
+                const float xp = d_raw * f * __frsqrt_rn(u_h * u_h + u_w * u_w + f * f) - cam_dist;
+                if (xp < xlo_t || xp > xhi_t) return;
+            }
+            int ix, iy, iz;
+            float dist;
+            if (pixel_voxel<false>(D, true, d_raw, 0.f, 0.f, 0.f, f, cam_dist, h, w, ix, iy, iz, dist) < 0) return;
+            if (ix < x0 || ix >= x1 || iy < y0 || iy >= y1 || iz < z0 || iz >= z1) return;
+            const int l = ((ix - x0) * kQY + (iy - y0)) * kQZ + (iz - z0);
+            unsafeAtomicAdd(&s_sum[l], (double)dist);                       // :273
+            atomicAdd(&s_cnt[l], 1u);                                       // :274
+        };
+#pragma unroll
+        for (int u = 0; u < kQDeep; u++)
+            if ((int)threadIdx.x + u * kBlock < area) pixel(threadIdx.x + u * kBlock, dv[u]);
+        for (int t = threadIdx.x + kQDeep * kBlock; t < area; t += kBlock) pixel(t, fetch(t));
+        __syncthreads();
+    }
+    // ---- (c) normalise (:291-305) and write the brick; a dead brick streams the fill values ---------------------
+    auto value = [&](int l, float &k) {
+        k = (float)s_cnt[l];
+        // (sum - bias) / k  (:304) as a multiplication by 1/k: exact for the voxels hit once (and 2, 4, ... times), within an
+        // ulp of the division otherwise -- the summation order of such voxels is already free
+        return k > 0.0f ? post_bias + post_scale * (((prefill + (float)s_sum[l]) - bias) * __frcp_rn(k)) : fill_val;
+    };
+    if (vec_ok && z1 - z0 == kQZ) {
+        const int z4 = (threadIdx.x & (kQZ / 4 - 1)) * 4;
+        for (int xy = threadIdx.x / (kQZ / 4); xy < kQX * kQY; xy += kBlock / (kQZ / 4)) {
+            const int ix = x0 + xy / kQY, iy = y0 + xy % kQY;
+            if (ix >= D.X || iy >= D.Y) continue;
+            float4 tv = make_float4(fill_val, fill_val, fill_val, fill_val), kv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                const int l = xy * kQZ + z4;
+                tv.x = value(l, kv.x); tv.y = value(l + 1, kv.y); tv.z = value(l + 2, kv.z); tv.w = value(l + 3, kv.w);
+            }
+            *reinterpret_cast<float4 *>(vimg + ix * vox.s2 + iy * vox.s3 + (z0 + z4)) = tv;
+            *reinterpret_cast<float4 *>(cimg + ix * cnt.s2 + iy * cnt.s3 + (z0 + z4)) = kv;
+        }
+    } else {
+        const int lz = threadIdx.x & (kQZ - 1), iz = z0 + lz;
+        for (int xy = threadIdx.x / kQZ; xy < kQX * kQY; xy += kBlock / kQZ) {
+            const int ix = x0 + xy / kQY, iy = y0 + xy % kQY;
+            if (ix >= D.X || iy >= D.Y || iz >= D.Z) continue;
+            float k = 0.0f;
+            const float tval = live ? value(xy * kQZ + lz, k) : fill_val;
+            vimg[ix * vox.s2 + iy * vox.s3 + iz * vox.s4] = tval;
+            cimg[ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4] = k;
+        }
+    }
+}
+
 // ---- K3: surface mask (:324-357), one lane per voxel, z fastest -----------------
 __device__ __forceinline__ int floor_i_d(double a) { return (a < 0) ? (int)a - 1 : (int)a; }
 __device__ __forceinline__ int round_i_d(double a)
@@ -757,30 +938,39 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
     return 1;
 }
 
-// The camera forward has two implementations (GENRE_CAMBP_MODE = scatter | gather):
-//  scatter  (default) fill + scatter + normalise: three launches, hardware float atomics; 5.5-6.4 us/image at
-//           batch 32, ~13 us at batch 1; sums of voxels hit more than once depend on atomic order, as in the
-//           reference.
+// The camera forward has three implementations.  By default the output layout picks one: the single-launch brick kernel
+// when both volumes have contiguous, 16-byte aligned z rows (the reference's dense NCXYZ tensors), fill + scatter +
+// normalise otherwise (e.g. the image-minor volumes of the batch-minor renderer).  The environment variable
+// GENRE_CAMBP_MODE = scatter | brick | gather pins one of them for every call.  Measured on MI355X (HIP-graph replay,
+// tools/ab_round2.py, per image at batch 1 / 8 / 32):
+//  brick    cam_brick_kernel: one launch, 8x8x32 bricks accumulated in LDS (fp64 sums), deterministic:
+//           9.7-10.1 / 4.7-4.9 / 4.0-4.2 us.  Timestamps inside the kernel put ~3 us of the batch-1 figure into the
+//           dependent chain every workgroup runs before it knows whether it is live (scalar loads -> footprint -> pixel
+//           loads -> reduction -> barrier) and ~3 us into the live bricks' pixel and normalise phases; queueing the
+//           screened pixels (in LDS or in-wave), pairing pixels for instruction-level parallelism, 8x8x16 bricks, 512
+//           threads and a speculative fill ahead of the screen were all measured within +-0.4 us of this version.
+//  scatter  fill + scatter + normalise: three launches, hardware float atomics: 11.9 / 5.5-5.7 / 4.3-4.5 us; sums of
+//           voxels hit more than once depend on atomic order, as in the reference.
 //  gather   cam_gather_kernel: one launch, deterministic and bit-identical to the serial reference order;
-//           6.6 us/image at batch 32, ~42 us at batch 1 (in a live brick the exact arithmetic runs on almost
-//           every candidate iteration of a wave, because lanes find their hits at different iterations).
-// (A third, slab-owned single-launch variant -- one x-plane quarter per workgroup accumulated in LDS -- was
-// measured at 9-11 us/image at batch 32 and 18 us at batch 1: its pixel screen is one exposed global-load
-// latency per batch of loads and never beat the three short launches, so it was dropped.  A fourth -- the three
-// phases in ONE launch of co-resident workgroups separated by two device-wide barriers -- was 44 us at batch 1:
+//           6.6 us/image at batch 32, ~42 us at batch 1 (256 workgroups per image: too few stores in flight, and in a
+//           live brick the exact arithmetic runs on almost every candidate iteration of a wave).
+// (Also measured and dropped: a slab-owned single-launch variant -- one x-plane quarter per workgroup accumulated in
+// LDS, whose footprint is a quarter of the IMAGE -- at 9-11 us/image at batch 32 and 18 us at batch 1; and the three
+// phases in ONE launch of co-resident workgroups separated by two device-wide barriers, 44 us at batch 1:
 // tools/grid_barrier_bench.hip measures 3.9 us per barrier on 256 workgroups before any fence (256 same-address
 // arrivals at ~10 ns each + the polling), +1.9 us for the L2 write-back and +1.7 us for the invalidate each side
 // needs so that the XCDs' L2s agree; a kernel boundary inside a HIP graph costs ~1 us.)
 // The spherical path always scatters.
-enum CamMode { kScatter, kGather };
-// The only process-level setting the library reads: the environment variable GENRE_CAMBP_MODE (scatter | gather), looked up
-// ONCE at the first camera forward and constant afterwards -- a read-only configuration value, not mutable state: calls
-// stay re-entrant and independent of one another (include/genre_hip.h: "keeps no global state").
+enum CamMode { kAuto, kScatter, kGather, kBrick };
+// The only process-level setting the library reads: the environment variable GENRE_CAMBP_MODE, looked up ONCE at the first
+// camera forward and constant afterwards -- a read-only configuration value, not mutable state: calls stay re-entrant
+// and independent of one another (include/genre_hip.h: "keeps no global state").
 inline CamMode cam_mode()
 {
     static const CamMode m = [] {
         const char *e = getenv("GENRE_CAMBP_MODE");
-        return (e && e[0] == 'g') ? kGather : kScatter;
+        if (!e) return kAuto;
+        return e[0] == 'g' ? kGather : e[0] == 'b' ? kBrick : e[0] == 's' ? kScatter : kAuto;
     }();
     return m;
 }
@@ -824,22 +1014,32 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
             fill_val = 1.0f - (float)mx * empty_val;
         }
     }
-    const CamMode mode = SPH ? kScatter : cam_mode();
+    // float4 rows (brick kernel; dead bricks of the gather kernel) need unit z stride and 16-byte aligned z-rows in both outputs
+    auto rows_aligned = [&](const genre_tensor *t) {
+        if (t->stride[4] != 1 || !aligned16(t->data) || (D.Z % 4) != 0) return false;
+        for (int i = 0; i < 4; i++)
+            if (t->size[i] != 1 && (t->stride[i] % 4) != 0) return false;
+        return true;
+    };
+    const int vec_ok = rows_aligned(voxel) && rows_aligned(cnt);
+    CamMode mode = SPH ? kScatter : cam_mode();
+    if (mode == kAuto) mode = (vec_ok && D.N * D.NC <= 65535) ? kBrick : kScatter;
     if (mode != kScatter) {
         const int64_t nvox = (int64_t)D.X * D.Y * D.Z;
         if (nvox == 0 || D.N * D.NC == 0) return 1;
         GENRE_REQUIRE(D.N * D.NC <= 65535, "%s: N*NC must be <= 65535", op);
         const float prefill = (float)(1.0 / (double)D.X);               // cam_back_projection.py:23-24 (res = X)
         const float bias = 1.0f / (float)mx;                             // K2: dist_bias / max(res)  (:304,:829)
+        if (mode == kBrick) {
+            const int64_t bricks = (int64_t)((D.X + kQX - 1) / kQX) * ((D.Y + kQY - 1) / kQY) * ((D.Z + kQZ - 1) / kQZ);
+            GENRE_REQUIRE(bricks < ((int64_t)1 << 31), "%s: volume too large", op);
+            cam_brick_kernel<<<dim3((unsigned)bricks, D.N * D.NC), kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel),
+                                                                                   view5(cnt), prefill, bias, post_scale,
+                                                                                   post_bias, fill_val, vec_ok);
+            GENRE_LAUNCH_CHECK("projection forward (bricks)");
+            return 1;
+        }
         const int bricks = ((D.X + kGX - 1) / kGX) * ((D.Y + kGY - 1) / kGY) * ((D.Z + kGZ - 1) / kGZ);
-        // float4 fill of dead bricks needs unit z stride and 16-byte aligned z-rows in both outputs
-        auto rows_aligned = [&](const genre_tensor *t) {
-            if (t->stride[4] != 1 || !aligned16(t->data) || (D.Z % 4) != 0) return false;
-            for (int i = 0; i < 4; i++)
-                if (t->size[i] != 1 && (t->stride[i] % 4) != 0) return false;
-            return true;
-        };
-        const int vec_ok = rows_aligned(voxel) && rows_aligned(cnt);
         cam_gather_kernel<<<dim3(bricks, D.N * D.NC), kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel),
                                                                       view5(cnt), prefill, bias, post_scale, post_bias,
                                                                       fill_val, vec_ok);

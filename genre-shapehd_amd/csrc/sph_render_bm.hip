@@ -22,7 +22,8 @@
 //    cancellation.  bm_combine_bwd_kernel leaves g*T at the start and R behind the end of every segment;
 //    bm_scatter_kernel: every brick PULLS the segments that touch one of its voxels, re-runs their (cheap) serial
 //    scans from the saved clamped samples p (the only per-sample stream: 4 B per sample and image, written by the
-//    forward when a gradient is wanted), and accumulates the trilinear adjoint of the samples it owns corners of in an
+//    forward when a gradient is wanted; ownership of a corner is a scalar-unit execution mask, not a vector compare),
+//    and accumulates the trilinear adjoint of the samples it owns corners of in an
 //    fp64 LDS tile it alone owns -- ds_add_f64 runs at 8.7 clk per 64-lane instruction on gfx950 against 193 for
 //    ds_add_f32 (tools/bm_tile_bench.hip) -- then writes every voxel of grad_vox exactly once with plain stores.
 //    fp64 accumulation needs no scale (sph_render.hip's 64-bit fixed point needs a batch-global max |dL/dp| pass),
@@ -45,7 +46,7 @@ constexpr int kThreads = 512;
 
 struct BmDims {
     int N, X, Y, Z, R, pad;
-    int nseg, groups;
+    int nseg, groups, ZR;
     int64_t nslot;
     int64_t sx, sy, sz;                                  // element strides of vox (image stride == 1)
     int64_t gx, gy, gz;                                  // ... of grad_vox
@@ -360,9 +361,30 @@ __device__ __forceinline__ void both_halves(float v, float &lower, float &upper)
 }
 
 constexpr int kHalfSeg = kMaxSeg / 2;
+constexpr int kRecL = 16;                                // words per record slot in the scatter kernel's LDS (see there)
 
+// A lane-uniform ownership bit pair (lower half-wave, upper half-wave) as an execution mask: two s_bfe_i32 and the
+// s_and_saveexec of the `if` -- no vector instruction and no branch, so the compiler counts the LDS operations in flight
+// exactly and the next sample's record read can stay queued behind this sample's atomics.
+__device__ __forceinline__ bool owned(unsigned own, int c)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)own, c, 1);
+    const unsigned hi = (unsigned)__builtin_amdgcn_sbfe((int)own, c + 4, 1);
+    return __builtin_amdgcn_inverse_ballot_w64((unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+
+// What a wave holds of one entry before it works on it: the saved samples (split over the half-waves: the lower half keeps
+// samples 0, 2, 4, ..., the upper half 1, 3, 5, ...), the two ray scalars of the segment, the depth weight of sample
+// `lane` (lanes 0-15) and the lane's 16 bytes of the entry's records.
+struct BmEntryRegs {
+    float p[kHalfSeg];
+    float T, R, wk;
+    int4 rq;
+};
+
+// 768 threads: two workgroups per CU = 6 waves per SIMD, which the register allocation must respect (<= 80 VGPRs)
 template <bool PS, int PX, int PY, int PZ, int kThreadsB>
-__global__ __launch_bounds__(kThreadsB) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
+__global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
                                                                const int4 *__restrict__ rows, const float *__restrict__ dw,
                                                                const float *__restrict__ tr, const float *__restrict__ stash,
                                                                const unsigned *__restrict__ mask, float *__restrict__ gvox)
@@ -370,8 +392,8 @@ __global__ __launch_bounds__(kThreadsB) void bm_scatter_kernel(BmDims D, const i
     constexpr int kLinesB = PX * PY * PZ, kWavesB = kThreadsB / 64;
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     double *tile = lds_d;                                               // [kLinesB][32]
-    int *recs = reinterpret_cast<int *>(lds_d + kLinesB * kImgs);       // [kWavesB][kMaxSeg * kRec]
-    unsigned *mlds = reinterpret_cast<unsigned *>(recs + kWavesB * kMaxSeg * kRec);     // [kLinesB] clamp masks
+    int *recs = reinterpret_cast<int *>(lds_d + kLinesB * kImgs);       // [kWavesB][kMaxSeg * kRecL]
+    unsigned *mlds = reinterpret_cast<unsigned *>(recs + kWavesB * kMaxSeg * kRecL);    // [kLinesB] clamp masks
     const int4 row = rows[blockIdx.x];
     if (row.w == 2) return;                                             // padding row of the XCD interleave
     const int g = blockIdx.y, n0 = g * kImgs;
@@ -381,94 +403,176 @@ __global__ __launch_bounds__(kThreadsB) void bm_scatter_kernel(BmDims D, const i
         const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
         mlds[line] = (x < D.X && y < D.Y && z < D.Z) ? mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] : 0u;
     }
-    for (int e = threadIdx.x; e < kLinesB * kImgs; e += kThreadsB) tile[e] = 0.0;
+    for (int e = threadIdx.x; e < kLinesB * kImgs / 2; e += kThreadsB) reinterpret_cast<double2 *>(tile)[e] = make_double2(0.0, 0.0);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int half = lane >> 5, l = lane & 31;
-    int *myrec = recs + wave * (kMaxSeg * kRec);
+    // A wave's records in LDS: slot = sample index inside the segment, 64 bytes per slot = one 32-byte part per half-wave,
+    //   (tile byte offset, ownership bits, depth weight w_k, -)  (this half's four corner weights)
+    // so that a lane reads its sample with two 16-byte reads at compile-time offsets from ONE per-lane base (no address
+    // arithmetic per sample).  The 48-byte table record (header, weights z0, weights z0+1) is spread out when it is staged:
+    // the lanes holding a header write it into both parts.
+    int *myrec = recs + wave * (kMaxSeg * kRecL);
+    const int *myh = myrec + half * 8;
+    const int stage_rec = lane / 3, stage_part = lane - stage_rec * 3;   // staging: lane -> (record, 16-byte chunk)
+    int *stage_to = myrec + stage_rec * kRecL + (stage_part == 0 ? 0 : stage_part == 1 ? 4 : 12);
     char *tl = reinterpret_cast<char *>(tile + half * kImgs + l);
     constexpr int kXS = PY * PZ * kImgs, kYS = PZ * kImgs;           // doubles between x / y neighbours
     // entry = (segment, stash slot of its first sample, i0 | i1 << 6 | L << 12 | k0 << 18, rec_b slot of sample i0).
-    // Software pipeline: while entry e is scattered, the saved samples, the two ray scalars and the records of entry
-    // e + 16 are in flight to registers and the header of e + 32 is being fetched.  The per-sample arrays are SPLIT over
-    // the two half-waves (lanes l and l + 32 are the same image): the lower half keeps the even samples, the upper half
-    // the odd ones, exchanged with v_permlane32_swap when needed -- 24 registers instead of 48, which is what lets
-    // 16 waves per workgroup (8 per SIMD) hide the latency of this kernel's gathers.
-    const int4 none = make_int4(0, 0, 0, 0);
-    int e = row.y + wave;
-    int4 en = none;
-    if (e < row.z) en = ents[e];
-    int4 en1 = none;
-    if (e + kWavesB < row.z) en1 = ents[e + kWavesB];
-    float pn[kHalfSeg];
-    float Tn = 0.f, Rn = 0.f;
-    int4 rq = none;
-    auto fetch = [&](const int4 &h) {
-        const int Lh = (h.z >> 12) & 63;
-        const float *st = stash + ((size_t)g * D.nslot + h.y + half) * kImgs + l;
-#pragma unroll
-        for (int j = 0; j < kHalfSeg; j++) pn[j] = (2 * j + half < Lh) ? st[(size_t)(2 * j) * kImgs] : 0.f;
-        const size_t to = ((size_t)(g * D.nseg + h.x) * 2) * kImgs + l;
-        Tn = tr[to]; Rn = tr[to + kImgs];
-        const int cnt = (((h.z >> 6) & 63) - (h.z & 63)) * 3;
-        if (lane < cnt) rq = reinterpret_cast<const int4 *>(rec_b + (int64_t)h.w * kRec)[lane];
+    // Software pipeline: while entry e is scattered, the saved samples, the two ray scalars, the depth weights and the
+    // records of entry e + kWavesB are in flight to registers (two register sets, used alternately: no copies) and the
+    // header of e + 2 kWavesB is being fetched and decoded.  (Measured on MI355X, batch 32: a prefetch distance of two
+    // entries -- three register sets -- was 4 % SLOWER: the fetch phase runs at its throughput, not its latency.)
+    // Global addresses = wave-uniform 64-bit base (scalar registers) + a 32-bit per-lane offset: three persistent
+    // vector registers instead of three address pairs.
+    const unsigned lo_st = (unsigned)(half * kImgs + l), lo_tr = (unsigned)l, lo_rq = (unsigned)lane * 4u;
+    const float *stash_g = stash + (size_t)g * D.nslot * kImgs;
+    const float *tr_g = tr + (size_t)g * D.nseg * 2 * kImgs;
+    // A decoded header: everything the prefetch of an entry needs, wave-uniform, on the scalar unit.  (Passed BY VALUE:
+    // a captured reference makes the compiler keep it in vector registers.)
+    struct Hdr { const float *st, *tp; const int *rq; int pk; };
+    auto decode = [&](const int4 h) {
+        Hdr r;
+        r.st = stash_g + (size_t)h.y * kImgs;
+        r.tp = tr_g + (size_t)h.x * 2 * kImgs;
+        r.rq = rec_b + (size_t)h.w * kRec;
+        r.pk = h.z;
+        return r;
     };
-    if (e < row.z) fetch(en);
-    for (; e < row.z; e += kWavesB) {
-        const int pk = __builtin_amdgcn_readfirstlane(en.z);
-        const int i0 = pk & 63, i1 = (pk >> 6) & 63, L = (pk >> 12) & 63, k0 = (pk >> 18) & 255;
-        float pv[kHalfSeg], cg[kHalfSeg];
+    auto fetch = [&](const Hdr h, BmEntryRegs &o) {
+        const int Lh = (h.pk >> 12) & 63;
+        // four samples at a time, decided on the scalar unit; the at most three slots read past the segment's end exist
+        // (the table builder pads the slot space) and are never used
 #pragma unroll
-        for (int j = 0; j < kHalfSeg; j++) pv[j] = pn[j];
-        float Tg = Tn, Rr = Rn;
-        if (lane < (i1 - i0) * 3) reinterpret_cast<int4 *>(myrec)[lane] = rq;
-        wave_lds_fence();
-        int4 en2 = none;
-        if (e + 2 * kWavesB < row.z) en2 = ents[e + 2 * kWavesB];
-        if (e + kWavesB < row.z) fetch(en1);
-#pragma unroll
-        for (int j = 0; j < kHalfSeg; j++) {                            // forward: g T_k where the clamp passes the gradient
-            if (2 * j < L) {
-                float pe, po;
-                both_halves(pv[j], pe, po);                             // samples 2j, 2j + 1 (po = 0 beyond the end)
-                const float ce = pe > 0.f ? Tg : 0.f;
-                Tg *= 1.0f - fabsf(pe);
-                const float co = po > 0.f ? Tg : 0.f;
-                Tg *= 1.0f - fabsf(po);
-                cg[j] = half ? co : ce;
+        for (int jj = 0; jj < kHalfSeg / 2; jj++) {
+            if (4 * jj < Lh) {
+                o.p[2 * jj] = (h.st + (4 * jj) * kImgs)[lo_st];
+                o.p[2 * jj + 1] = (h.st + (4 * jj + 2) * kImgs)[lo_st];
             }
         }
-        auto sample = [&](int i, float pa, float c) {                   // reverse: R_k = p w + (1-p) R_{k+1}; dL/dp_k; scatter
-            const float wk = dw[k0 + i];
-            const float d = wk - Rr;
-            const float dp = c * d;
-            Rr = __builtin_fmaf(pa, d, Rr);
+        o.T = h.tp[lo_tr]; o.R = (h.tp + kImgs)[lo_tr];
+        const int cnt = (((h.pk >> 6) & 63) - (h.pk & 63)) * 3;
+        if (lane < cnt) o.rq = *reinterpret_cast<const int4 *>(h.rq + lo_rq);
+        if (lane < kMaxSeg) o.wk = dw[min(((h.pk >> 18) & 255) + lane, D.ZR - 1)];   // depth weight of sample `lane`
+    };
+    // One entry.  `h2raw` is the raw header of the entry after next, requested by the caller just before: it is decoded
+    // between the two scans, so that the scalar load is retired BEFORE the reverse loop -- a scalar load still in flight
+    // would force every wait of that loop down to "everything", atomics included (scalar loads return out of order).
+    auto entry = [&](const int pk, const bool has_next, const Hdr h1, const bool has_next2, const int4 h2raw, Hdr &h2,
+                     BmEntryRegs &cur, BmEntryRegs &nxt) {
+        const int i0 = pk & 63, i1 = (pk >> 6) & 63, L = (pk >> 12) & 63;
+        if (lane < (i1 - i0) * 3) {
+            int4 *to = reinterpret_cast<int4 *>(stage_to + i0 * kRecL);
+            *to = cur.rq;
+            if (stage_part == 0) to[2] = cur.rq;                        // the header, again, for the upper half-wave
+        }
+        wave_lds_fence();                                               // (headers first: they carry zeros where w_k goes)
+        if (lane < kMaxSeg) {
+            myrec[lane * kRecL + 2] = __float_as_int(cur.wk);
+            myrec[lane * kRecL + 10] = __float_as_int(cur.wk);
+        }
+        wave_lds_fence();
+        if (has_next) fetch(h1, nxt);
+        float Tg = cur.T, Rr = cur.R;
+        float ce[kHalfSeg], co[kHalfSeg];                               // g T at samples 2j and 2j + 1
+#pragma unroll
+        for (int j = 0; j < kHalfSeg; j++) {                            // forward: g T_k
+            if (2 * j < L) {
+                float pe, po;
+                both_halves(cur.p[j], pe, po);                          // samples 2j, 2j + 1 (po unused beyond the end)
+                ce[j] = Tg;
+                Tg *= 1.0f - fabsf(pe);
+                co[j] = Tg;
+                Tg *= 1.0f - fabsf(po);
+            }
+        }
+        if (has_next2) h2 = decode(h2raw);
+        // Records: two register sets used by sample parity (compile-time after unrolling: no copies).  That of the sample
+        // the reverse loop meets first is the only one read with a run-time offset (into both sets).
+        int4 hd0 = *reinterpret_cast<const int4 *>(myh + (L - 1) * kRecL), hd1 = hd0;    // (tile byte offset, ownership, w_k, -)
+        float4 w0 = *reinterpret_cast<const float4 *>(myh + (L - 1) * kRecL + 4), w1 = w0;
+        auto sample = [&](const int i, float ps, float c) {            // reverse: R_k = p w + (1-p) R_{k+1}; dL/dp_k; scatter
+            const int4 hc = (i & 1) ? hd1 : hd0;
+            const float4 wc = (i & 1) ? w1 : w0;
+            const float d = __int_as_float(hc.z) - Rr;
+            Rr = __builtin_fmaf(fabsf(ps), d, Rr);
+            if (i > 0) {                                                // the next sample's record: queued before this one's atomics
+                const int4 hn = *reinterpret_cast<const int4 *>(myh + (i - 1) * kRecL);
+                const float4 wn = *reinterpret_cast<const float4 *>(myh + (i - 1) * kRecL + 4);
+                if (i & 1) { hd0 = hn; w0 = wn; } else { hd1 = hn; w1 = wn; }
+            }
             if (i < i1) {
-                const int *r = myrec + (i - i0) * kRec;
-                const int2 hd = *reinterpret_cast<const int2 *>(r);                   // (tile byte offset, ownership)
-                const float4 w = *reinterpret_cast<const float4 *>(r + 4 + half * 4);
-                double *a = reinterpret_cast<double *>(tl + hd.x);
-                const unsigned own = (unsigned)hd.y >> (4 * half);
-                if (own & 1u) unsafeAtomicAdd(a, (double)(w.x * dp));                 // ds_add_f64
-                if (own & 2u) unsafeAtomicAdd(a + kXS, (double)(w.y * dp));
-                if (own & 4u) unsafeAtomicAdd(a + kYS, (double)(w.z * dp));
-                if (own & 8u) unsafeAtomicAdd(a + kXS + kYS, (double)(w.w * dp));
+                const float dp = ps > 0.f ? c * d : 0.f;                // the clamp passes the gradient where the saved sample is > 0
+                const unsigned own = (unsigned)__builtin_amdgcn_readfirstlane(hc.y);
+                double *a = reinterpret_cast<double *>(tl + hc.x);
+                if (owned(own, 0)) unsafeAtomicAdd(a, (double)(wc.x * dp));                // ds_add_f64
+                if (owned(own, 1)) unsafeAtomicAdd(a + kXS, (double)(wc.y * dp));
+                if (owned(own, 2)) unsafeAtomicAdd(a + kYS, (double)(wc.z * dp));
+                if (owned(own, 3)) unsafeAtomicAdd(a + kXS + kYS, (double)(wc.w * dp));
             }
         };
 #pragma unroll
         for (int j = kHalfSeg - 1; j >= 0; j--) {
             if (2 * j < L && 2 * j + 1 >= i0) {
-                float pe, po, ce, co;
-                both_halves(pv[j], pe, po);
-                both_halves(cg[j], ce, co);
-                if (2 * j + 1 < L) sample(2 * j + 1, fabsf(po), co);
-                if (2 * j >= i0) sample(2 * j, fabsf(pe), ce);
+                float pe, po;
+                both_halves(cur.p[j], pe, po);
+                if (2 * j + 1 < L) sample(2 * j + 1, po, co[j]);
+                if (2 * j >= i0) sample(2 * j, pe, ce[j]);
             }
         }
         wave_lds_fence();
-        en = en1; en1 = en2;
+    };
+    int e = row.y + wave;
+    int pk0 = 0;
+    Hdr h1{nullptr, nullptr, nullptr, 0}, h2{nullptr, nullptr, nullptr, 0};
+    BmEntryRegs A, B;
+    A.rq = make_int4(0, 0, 0, 0); B.rq = make_int4(0, 0, 0, 0);
+    if (e < row.z) {
+        const Hdr h = decode(ents[e]);
+        pk0 = h.pk;
+        fetch(h, A);
     }
+    if (e + kWavesB < row.z) h1 = decode(ents[e + kWavesB]);
+#define GENRE_BM_STEP(CUR, NXT)                                                                                         \
+    {                                                                                                                   \
+        const bool n2_ = e + 2 * kWavesB < row.z;                                                                        \
+        int4 raw_ = make_int4(0, 0, 0, 0);                                                                               \
+        if (n2_) raw_ = ents[e + 2 * kWavesB];                                                                           \
+        entry(__builtin_amdgcn_readfirstlane(pk0), e + kWavesB < row.z, h1, n2_, raw_, h2, CUR, NXT);                    \
+        pk0 = h1.pk; h1 = h2;                                                                                            \
+        e += kWavesB;                                                                                                   \
+    }
+    while (e < row.z) {
+        GENRE_BM_STEP(A, B)
+        if (e >= row.z) break;
+        GENRE_BM_STEP(B, A)
+    }
+#undef GENRE_BM_STEP
     __syncthreads();
+    // Flush: every voxel of the brick exactly once.  Four images per thread (two 16-byte LDS reads, one 16-byte store) when
+    // the layout allows; rows that share their brick with other rows add atomically onto pre-zeroed voxels.
+    const bool vec4 = row.w == 0 && (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
+    if (vec4) {
+        for (int q = threadIdx.x; q < kLinesB * (kImgs / 4); q += kThreadsB) {
+            const int line = q >> 3, piece = (q & 7) * 4, n = n0 + piece;
+            const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
+            if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
+                const double2 t01 = *reinterpret_cast<const double2 *>(tile + line * kImgs + piece);
+                const double2 t23 = *reinterpret_cast<const double2 *>(tile + line * kImgs + piece + 2);
+                float4 v = make_float4((float)t01.x, (float)t01.y, (float)t23.x, (float)t23.y);
+                if (PS) {                                               // adjoint of clamp(x * pre_scale, lo, hi)
+                    const unsigned m = mlds[line] >> piece;
+                    v.x = (m & 1u) ? v.x * D.pre_scale : 0.f;
+                    v.y = (m & 2u) ? v.y * D.pre_scale : 0.f;
+                    v.z = (m & 4u) ? v.z * D.pre_scale : 0.f;
+                    v.w = (m & 8u) ? v.w * D.pre_scale : 0.f;
+                }
+                *reinterpret_cast<float4 *>(gvox + x * D.gx + y * D.gy + z * D.gz + n) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int e2 = threadIdx.x; e2 < kLinesB * kImgs; e2 += kThreadsB) {
         const int line = e2 >> 5, n = n0 + (e2 & 31);
@@ -612,7 +716,9 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
     GENRE_REQUIRE(is_i32(ent, 2) && ent->size[1] == 4 && is_contiguous(ent) && aligned16(ent->data), "%s: ent must be int32 [E,4]", op);
     GENRE_REQUIRE(is_i32(rec_b, 2) && rec_b->size[1] == kRec && is_contiguous(rec_b) && aligned16(rec_b->data),
                   "%s: rec_b must be a contiguous int32 [SB,12] tensor", op);
-    GENRE_REQUIRE(is_f32(depth_weight, 1) && is_contiguous(depth_weight), "%s: depth_weight must be fp32 [ZR]", op);
+    GENRE_REQUIRE(is_f32(depth_weight, 1) && is_contiguous(depth_weight) && depth_weight->size[0] >= 1 &&
+                      depth_weight->size[0] <= 256, "%s: depth_weight must be fp32 [ZR], 1 <= ZR <= 256", op);
+    D.ZR = (int)depth_weight->size[0];
     const int64_t per = (int64_t)D.groups * D.nseg * 2 * kImgs;
     GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ps_scratch->size[0] >= per &&
                       is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && tr_scratch->size[0] >= per,
@@ -639,7 +745,7 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
                                                                         (float *)grad_vox->data);                         \
             GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");                                                \
         }                                                                                                                 \
-        constexpr size_t lds = (size_t)PXV * 64 * kImgs * 8 + (size_t)(NTV / 64) * kMaxSeg * kRec * 4 + (size_t)PXV * 64 * 4; \
+        constexpr size_t lds = (size_t)PXV * 64 * kImgs * 8 + (size_t)(NTV / 64) * kMaxSeg * kRecL * 4 + (size_t)PXV * 64 * 4; \
         static const int ok_ = reserve_lds(op, &bm_scatter_kernel<PSV, PXV, 8, 8, NTV>, lds);                             \
         if (!ok_) return 0;                                                                                               \
         bm_scatter_kernel<PSV, PXV, 8, 8, NTV><<<grid, NTV, lds, st>>>(                                                   \

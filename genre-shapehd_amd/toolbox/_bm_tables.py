@@ -18,7 +18,9 @@ every brick PULLS the samples that touch one of its voxels and accumulates them 
 Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h, "batch-minor tile renderer":
   segs      int32 [nseg,4]   (ray q, first sample k0, length L, slot of the first sample)   sorted by (brick, q, k0)
   rec_f     int32 [S,12]     per sample slot: (tile byte offset, depth_weight[k] bits, 0, 0,
-                              w(x0y0z0), w(x1y0z0), w(x0y1z0), w(x1y1z0), w(x0y0z1), w(x1y0z1), w(x0y1z1), w(x1y1z1))
+                              w(x0y0z0), w(x1y0z0), w(x0y1z0), w(x1y1z0), w(x0y0z1), w(x1y0z1), w(x0y1z1), w(x1y1z1));
+                              S = samples + SLOT_PAD: the last SLOT_PAD slots belong to no sample (all zero) -- the backward
+                              fetches a segment's saved samples four at a time and may read up to three slots past its end
   fwd_rows  int32 [rows,4]   (brick, seg begin, seg end, flag); flag 2 = padding row (skipped); order: see _xcd_order
   ray_ptr   int32 [RR+1], ray_seg int32 [nseg]   the segments of every ray in sample order
   ray_pre   float64 [RR,2]   (P0, S0) of the samples before the ray enters the volume (p = 1e-5 each)
@@ -37,6 +39,7 @@ import numpy as np
 BX, BY, BZ = 4, 8, 8            # must match csrc/sph_render_bm.hip
 TX, TY, TZ = BX + 1, BY + 1, BZ + 1
 MAXSEG = 16
+SLOT_PAD = 16                   # unused slots behind the last sample (see rec_f)
 LINE_F = 128                    # bytes of one voxel line in the forward tile (32 images x fp32)
 LINE_B = 256                    # ... in the backward tile (32 images x fp64)
 SPLIT_F = 4096                  # samples per forward row
@@ -133,7 +136,7 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     for c in range(8):                                                      # ATen: (wx * wy) * wz, corner bit 0 = x
         wts[:, c] = (wx[c & 1] * wy[(c >> 1) & 1]) * wz[(c >> 2) & 1]
     lx, ly, lz = bxyz[0] % BX, bxyz[1] % BY, bxyz[2] % BZ
-    rec_f = np.zeros((ns, 12), np.int32)
+    rec_f = np.zeros((ns + SLOT_PAD, 12), np.int32)
     rec_f[samp_slot, 0] = ((lx * TY + ly) * TZ + lz) * LINE_F
     rec_f[samp_slot, 1] = dw[kk].view(np.int32)
     rec_f[samp_slot, 4:12] = wts.view(np.int32)

@@ -270,7 +270,9 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *                             consecutive samples of one ray whose base voxel lies in one 4x8x8-voxel brick (L <= 16);
  *                             sorted by (brick, ray, k0); slots number the in-volume samples in that order
  *   rec_f     int32 [S,12]    per slot: byte offset of the base voxel line in the brick's 5x9x9 x 32-image fp32 tile,
- *                             depth_weight[k] (fp32 bits), 0, 0, the 8 trilinear weights (x fastest, then y, then z)
+ *                             depth_weight[k] (fp32 bits), 0, 0, the 8 trilinear weights (x fastest, then y, then z);
+ *                             S = in-volume samples + 16 unused trailing slots (the backward fetches saved samples four
+ *                             at a time and may read up to three slots past a segment's end)
  *   fwd_rows  int32 [rows,4]  (brick, seg begin, seg end, 0): one workgroup each; every brick in >= 1 row
  *   ray_ptr   int32 [R*R+1], ray_seg int32 [nseg]: the segments of each ray in sample order
  *   ray_pre   float64 [R*R,2] viewed as fp32 [R*R,4]: (transmittance, partial sum) of the samples before the ray

@@ -52,7 +52,8 @@ def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, pu
     gr = vt.grad[0, 0].numpy()
     assert (np.abs(grad - gr) / np.maximum(1, np.abs(gr))).max() <= 2e-5
     # structure: segments partition the in-volume samples, rows cover all bricks
-    assert t["segs"][:, 2].sum() == t["rec_f"].shape[0] and t["segs"][:, 2].max() <= m.MAXSEG
+    assert t["segs"][:, 2].sum() + m.SLOT_PAD == t["rec_f"].shape[0] and t["segs"][:, 2].max() <= m.MAXSEG
+    assert not t["rec_f"][-m.SLOT_PAD:].any()
     pk = t["ent"][:, 2]
     assert (((pk >> 6) & 63) - (pk & 63)).sum() == t["rec_b"].shape[0]
     nb = -(-res // m.BX) * -(-res // m.BY) * -(-res // m.BZ)

@@ -61,9 +61,10 @@ def _odd_cases():
     return out
 
 
-def check_forward_cases(oracle, dev, exact):
-    """shared by the in-process (scatter) test and the GENRE_CAMBP_MODE=gather subprocess: cnt exact always;
-    tdf bit-exact on every voxel when `exact`, else <= 1e-5 and bit-exact where a voxel has one point"""
+def check_forward_cases(oracle, dev, exact, deterministic=False):
+    """shared by the in-process test (batch-size default: the single-launch brick kernel for these 1- and 2-image
+    cases) and the GENRE_CAMBP_MODE=scatter|brick|gather subprocesses: cnt exact always; tdf bit-exact on every voxel
+    when `exact`, else <= 1e-5 and bit-exact where a voxel has one point; `deterministic`: two runs agree bit for bit"""
     from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
     fl1, cd1 = inputs.cam_params(1)
     cases = [(d, fl1, cd1, 128) for d in depth_cases().values()] + _odd_cases()
@@ -83,14 +84,17 @@ def check_forward_cases(oracle, dev, exact):
         else:
             assert np.abs(tdf - tdf_o).max() <= TOL
             assert np.array_equal(tdf[cnt_o <= 1], tdf_o[cnt_o <= 1])
+            if deterministic:
+                assert np.array_equal(tdf, runs[1][0]) and np.array_equal(cnt, runs[1][1])
 
 
 def test_camera_forward_odd_sizes_and_cameras(genre, oracle, dev):
-    """non-power-of-two grids / images, several cameras, camera inside the grid (default scatter path)"""
+    """non-power-of-two grids / images, several cameras, camera inside the grid (default path: brick kernel at these
+    batch sizes)"""
     check_forward_cases(oracle, dev, exact=False)
 
 
-def _run_cases_in_subprocess(mode, exact):
+def _run_cases_in_subprocess(mode, exact, deterministic=False):
     import os
     import subprocess
     import sys
@@ -101,8 +105,8 @@ def _run_cases_in_subprocess(mode, exact):
         "from oracle.oracle import Oracle\n"
         "import genre_shapehd_amd\n"
         "import test_gpu_cam_bp as T\n"
-        "T.check_forward_cases(Oracle(), torch.device('cuda:0'), exact=%r)\n"
-        "print('ok')\n" % (root, os.path.join(root, "tests"), exact))
+        "T.check_forward_cases(Oracle(), torch.device('cuda:0'), exact=%r, deterministic=%r)\n"
+        "print('ok')\n" % (root, os.path.join(root, "tests"), exact, deterministic))
     env = dict(os.environ, GENRE_CAMBP_MODE=mode)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
@@ -112,6 +116,17 @@ def test_camera_forward_gather_bit_exact_subprocess(dev):
     """GENRE_CAMBP_MODE=gather: the single-launch gather kernel sums a voxel's points in the reference's serial
     pixel order -- tdf must equal the CPU oracle BIT FOR BIT on every voxel and repeat exactly"""
     _run_cases_in_subprocess("gather", True)
+
+
+def test_camera_forward_scatter_pinned_subprocess(dev):
+    """GENRE_CAMBP_MODE=scatter: fill + scatter + normalise on the 1- and 2-image cases the default now gives to the
+    brick kernel"""
+    _run_cases_in_subprocess("scatter", False)
+
+
+def test_camera_forward_brick_pinned_subprocess(dev):
+    """GENRE_CAMBP_MODE=brick: the single-launch LDS-brick kernel, pinned; its fp64 LDS sums make it deterministic"""
+    _run_cases_in_subprocess("brick", False, deterministic=True)
 
 
 def test_camera_forward_is_idempotent_on_dirty_outputs(genre, oracle, dev):
