@@ -10,7 +10,7 @@
  * reference:
  *   - the caller allocates every output (cam_back_projection.py:22-25,39-45);
  *     the library never allocates device memory and keeps no mutable global state (one
- *     read-only environment setting, GENRE_CAMBP_MODE=scatter|gather, is looked up once);
+ *     read-only environment setting, GENRE_CAMBP_MODE=scatter|brick|gather, is looked up once);
  *   - return 1 on success, 0 on failure (back_projection.c:13-15 turns 0 into
  *     THError("aborting")); on 0, genre_last_error() returns a thread-local
  *     message -- shape/dtype violations that THArgCheck / THCUNN_check_dim_size
@@ -66,7 +66,10 @@ const char *genre_last_error(void);
  * cam_back_projection.py:22-24.
  *   depth [N,NC,H,W]  camdist [N,NC]  fl [N,NC]  ->  voxel, cnt [N,NC,X,Y,Z]
  * voxel = mean distance of the back-projected points of a voxel to its centre,
- * 1/max(X,Y,Z) where no point fell; cnt = number of points (integer-valued). */
+ * 1/max(X,Y,Z) where no point fell; cnt = number of points (integer-valued).
+ * Volumes with contiguous, 16-byte aligned z rows (the reference's dense tensors) take one launch of the
+ * LDS-brick kernel (deterministic); other layouts take fill + scatter + normalise (float atomics).  cnt is exact
+ * and voxels hit by one point are bit-identical to the reference either way. */
 int genre_back_projection_forward(const genre_tensor *depth, const genre_tensor *camdist,
                                   const genre_tensor *fl, const genre_tensor *voxel,
                                   const genre_tensor *cnt, void *stream);
