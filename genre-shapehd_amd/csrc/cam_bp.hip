@@ -4,7 +4,11 @@
 // (kernels K1-K6, wrappers :629-963).  Not a translation: the reference's
 // pipeline per forward is  zero(cnt) + zero(tdf) + add 1/res (Python)  ->
 // zero(cnt) again  ->  K1 scatter  ->  K2 full-volume divide with 5 div/mod per
-// voxel and n-fastest (uncoalesced) indexing.  Here a forward is
+// voxel and n-fastest (uncoalesced) indexing.  Here the camera forward onto a dense
+// volume is ONE launch (cam_brick_kernel: a workgroup owns an 8x8x32 voxel brick,
+// screens the depth pixels under the brick's image footprint, accumulates the points
+// that land in it in an LDS tile and writes every voxel of the brick once; see there).
+// Other layouts, and the spherical forward, are
 //   (1) one float4 streaming fill of tdf and cnt (the only full-volume pass;
 //       16 B/lane stores, the algorithmic minimum of 2 x 4 B per voxel),
 //   (2) the scatter: a wave per 8x8 pixel tile, pixels of one voxel merged with
@@ -521,21 +525,24 @@ __global__ __launch_bounds__(kBlock) void cam_gather_kernel(Dims D, View4 depth,
     }
 }
 
-// ---- camera forward, single-launch BRICK formulation (small batches) ---------------------------------
-// At batch 1 the three launches above are bound by their boundaries, not by their 17 MB of traffic.  Here a
-// workgroup owns an 8x8x32 voxel brick (1024 workgroups per 128^3 image: four per CU, so the 16 MB of stores have
-// the memory parallelism the 256-workgroup gather kernel lacks) and does all three phases for it:
-//   (a) every thread fetches its share of the depth pixels under the brick's footprint (~23 x 71 px: 6 loads per
-//       thread, all in flight together) -- the wave/workgroup min/max of those depths rejects the ~90 % of bricks no
-//       point can reach, which then cost only their float4 stores;
-//   (b) live bricks: every footprint pixel is evaluated ONCE, by the thread that fetched it, with the reference's
-//       arithmetic (pixel_voxel); a point that lands inside the brick is added to the brick's LDS tile --
-//       ds_add_f64 for the distance (8.7 clk per wave-instruction on gfx950 against 193 for ds_add_f32,
-//       tools/bm_tile_bench.hip), ds_add_u32 for the count;
+// ---- camera forward, single-launch BRICK formulation (the default for dense volumes) ------------------
+// The three launches above are bound by their boundaries at batch 1 (17 MB of traffic, ~12 us) and by the float-atomic
+// rate at batch 32.  Here a workgroup owns an 8x8x32 voxel brick (1024 workgroups per 128^3 image: four per CU, so the
+// 16 MB of stores have the memory parallelism the 256-workgroup gather kernel lacks) and does all three phases for it:
+//   (a) every thread fetches its share of the depth pixels under the brick's footprint (~23 x 71 px: <= 8 loads per
+//       thread, all in flight together) -- the footprint's depth range (DPP wave reduction + one barrier) rejects the
+//       ~77 % of bricks no point can reach, which then cost only their float4 stores;
+//   (b) live bricks: every footprint pixel is evaluated ONCE, by the thread that fetched it -- a cheap plane-depth
+//       screen, then the reference's arithmetic (pixel_voxel); a point that lands inside the brick is added to the
+//       brick's LDS tile -- ds_add_f64 for the distance (8.7 clk per wave-instruction on gfx950 against 193 for
+//       ds_add_f32, tools/bm_tile_bench.hip), ds_add_u32 for the count;
 //   (c) the tile is normalised (K2, :291-305) and written with one float4 per thread and array.
 // A voxel hit by one point is bit-exact: its double sum IS that distance, and fl(fl(prefill + dist) - bias) is the
 // reference's sequence.  Voxels hit more than once add their (exact) distances in double instead of in the
-// reference's undefined fp32 atomic order: <= 1 ulp of 1/res from any of its orders, and deterministic.
+// reference's undefined fp32 atomic order and divide by rcp(cnt): <= 2 ulp of 1/res from any of its orders, and
+// deterministic.  tests/test_cam_brick_screens.py checks on the host that the three screens (footprint, depth range,
+// plane depth) never drop a pixel whose point the reference puts into the brick.  Measured variants: forward_impl.
+
 // wave-wide min / max / or with DPP (row shifts + row broadcasts, as wave_scan.hpp): the total lands in lane 63 and
 // is broadcast through a scalar register -- ~20 vector instructions instead of 18 dependent ds_bpermute round trips
 template <int CTRL, int ROW_MASK>
