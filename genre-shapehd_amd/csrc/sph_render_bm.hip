@@ -16,8 +16,13 @@
 //  * bm_sample_kernel: a workgroup stages its brick + the high halo (5 x 9 x 9 voxel lines of 32 images, 51 KB) in
 //    LDS; a WAVE marches one segment serially.  Lane = (image, z half): the two half-waves read the z0 / z0+1
 //    corner lines of the same sample -- adjacent in LDS, 256 contiguous bytes, conflict-free by construction -- and
-//    exchange their partial sums with one v_permlane32_swap.  Per sample: 2 broadcast reads of the 48-byte record,
+//    exchange their partial sums with one v_permlane32_swap.  Per sample: 2 reads of the 48-byte record,
 //    4 ds_read_b32, 4 multiply-adds, the clamp, 3 scan operations.
+//  * WAITS.  gfx950 counts vector loads AND stores in one in-order counter (vmcnt), and the compiler places the waits:
+//    to wait for an older load while younger operations stay in flight it must know their number at compile time, on
+//    every path.  Both kernels are written to that rule -- a fixed number of loads per prefetch, on every path (the
+//    tables are padded for what is read past a segment's own data), unconditional use of what was loaded, stores issued
+//    BEFORE the next prefetch and not after it -- or their software pipelines overlap nothing (see the kernels).
 //  * Backward: dL/dp_k = g T_k (w_k - R_{k+1}),  R_k = p_k w_k + (1 - p_k) R_{k+1},  R_end = 1 -- no division, no
 //    cancellation.  bm_combine_bwd_kernel leaves g*T at the start and R behind the end of every segment;
 //    bm_scatter_kernel: every brick PULLS the segments that touch one of its voxels, re-runs their (cheap) serial
@@ -43,6 +48,7 @@ constexpr int kImgs = 32;                                // images per group = l
 constexpr int kMaxSeg = 16;
 constexpr int kRec = 12;                                 // words per sample record
 constexpr int kThreads = 512;
+constexpr int kRecL = 16;                                // words per record slot in LDS (sampler and scatter kernel)
 
 struct BmDims {
     int N, X, Y, Z, R, pad;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
 {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     float *tile = lds_f;                                               // [kLinesF][32]
-    int *recs = reinterpret_cast<int *>(lds_f + kLinesF * kImgs);      // [(NT / 64)][kMaxSeg * kRec]
+    int *recs = reinterpret_cast<int *>(lds_f + kLinesF * kImgs);      // [(NT / 64)][64 lanes x 16 bytes]
     const int4 row = rows[blockIdx.x];
     if (row.w == 2) return;                                            // padding row of the XCD interleave
     const int g = blockIdx.y, n0 = g * kImgs;
@@ -150,60 +156,85 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int half = lane >> 5, l = lane & 31;
-    int *myrec = recs + wave * ((kMaxSeg + 1) * kRec);
+    // A wave's records in LDS: the 48-byte table records of the segment, as they come -- every lane parks its 16 bytes
+    // (1 KB per wave; the table is padded so that the lanes beyond the segment's L * 3 read real memory), sample i at
+    // myrec + 12 i words: header (tile byte offset, w_k) read by all lanes, corner weights per half-wave.  The march
+    // below is unrolled over the <= 16 samples of a segment, so all record offsets are compile-time constants.
+    int *myrec = recs + wave * (64 * 4);
+    const int *myw = myrec + 4 + half * 4;
     const char *tl = reinterpret_cast<const char *>(tile + half * kImgs + l);
     constexpr int kXS = kTY * kTZ * kImgs, kYS = kTZ * kImgs;          // floats between x / y neighbours
-    // Software pipeline over this wave's segments s, s + 8, ...: while segment s is marched, the records of the next
-    // one are in flight to registers and the header of the one after that is being fetched -- per segment the wave
-    // would otherwise sit through two dependent global round trips (header -> records) before its first sample.
-    const int4 none = make_int4(0, 0, 0, 0);
+    const unsigned lo_st = (unsigned)(half * kImgs + l);
+    // Software pipeline over this wave's segments s, s + NT/64, ...: while segment s is marched, the records of the next
+    // one are in flight to registers and the header of the one after that is being fetched.  Two rules keep the waits the
+    // compiler inserts from undoing it (gfx950 counts loads AND stores in one in-order counter, vmcnt):
+    //  * the record load and its use are UNCONDITIONAL (all 64 lanes, every segment; a wave's last segment loads its own
+    //    records again): a load behind an execution mask or a branch "may still be pending" on the other path, and the
+    //    next load into the same registers then waits for everything in flight;
+    //  * STORES ARE DELAYED BY ONE SEGMENT: the wait for the next segment's records would also wait for every store
+    //    issued after that load -- the saved samples of the segment just marched, a store round trip per segment and wave.
+    //    A segment's saved samples (and its (P, S) pair) stay in registers and leave at the top of the NEXT segment, after
+    //    the wait, so that at every wait the only operations outstanding were issued a whole march earlier.
+    const int NW = NT / 64;
     int s = row.y + wave;
-    int4 sg = none;
-    if (s < row.z) sg = segs[s];
-    int4 sg1 = none;
-    if (s + (NT / 64) < row.z) sg1 = segs[s + (NT / 64)];
-    int4 rq = none;                                                    // lane's 16 bytes of the segment's L*3 x 16
-    if (lane < sg.z * 3) rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)sg.w * kRec)[lane];
-    for (; s < row.z; s += (NT / 64)) {
+    if (s >= row.z) return;
+    const int s_last = s + ((row.z - 1 - s) / NW) * NW;                // this wave's last segment: indices are clamped to it
+    int4 sg = segs[s];
+    int4 sg1 = segs[min(s + NW, s_last)];
+    int4 rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)sg.w * kRec)[lane];     // lane's 16 bytes of the records
+    float sp[kMaxSeg / 2];                                             // this half-wave's saved sample of pair j
+    float ps_val = 0.f;
+    int Lprev = 0;
+    float *stp_prev = nullptr, *ps_prev = nullptr;
+    auto flush_prev = [&]() {                                          // the previous segment's stores
+        if (Lprev == 0) return;
+        if (SAVE) {
+#pragma unroll
+            for (int j = 0; j < kMaxSeg / 2; j++)      // samples 2j (lower half-wave) and 2j + 1 (upper): one 256-byte store
+                if (2 * j < Lprev && (2 * j + 1 < Lprev || half == 0)) (stp_prev + (2 * j) * kImgs)[lo_st] = sp[j];
+        }
+        ps_prev[lo_st] = ps_val;
+    };
+    for (; s < row.z; s += NW) {
         const int L = __builtin_amdgcn_readfirstlane(sg.z);
         const int64_t slot0 = __builtin_amdgcn_readfirstlane(sg.w);
-        if (lane < L * 3) reinterpret_cast<int4 *>(myrec)[lane] = rq;
+        reinterpret_cast<int4 *>(myrec)[lane] = rq;
         wave_lds_fence();
-        int4 sg2 = none;
-        if (s + 2 * (NT / 64) < row.z) sg2 = segs[s + 2 * (NT / 64)];
-        if (lane < sg1.z * 3) rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)sg1.w * kRec)[lane];
-        float T = 1.f, S = 0.f, sprev = 0.f;
-        float *st = SAVE ? stash + ((size_t)g * D.nslot + slot0) * kImgs + l : nullptr;
-        int2 hd = *reinterpret_cast<const int2 *>(myrec);                             // (tile byte offset, depth weight)
-        float4 w = *reinterpret_cast<const float4 *>(myrec + 4 + half * 4);
-        for (int i = 0; i < L; i++) {
-            const float *a = reinterpret_cast<const float *>(tl + hd.x);
-            const float a0 = a[0], a1 = a[kXS], a2 = a[kYS], a3 = a[kXS + kYS];
-            const float dwk = __int_as_float(hd.y);
-            const float4 wc = w;
-            // the next sample's record is requested before this one's taps are consumed (slot L is scratch)
-            const int *r = myrec + (i + 1) * kRec;
-            hd = *reinterpret_cast<const int2 *>(r);
-            w = *reinterpret_cast<const float4 *>(r + 4 + half * 4);
-            float v = a0 * wc.x;
-            v = __builtin_fmaf(a1, wc.y, v);
-            v = __builtin_fmaf(a2, wc.z, v);
-            v = __builtin_fmaf(a3, wc.w, v);
+        flush_prev();
+        const int4 sg2 = segs[min(s + 2 * NW, s_last)];
+        rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)__builtin_amdgcn_readfirstlane(sg1.w) * kRec)[lane];
+        float T = 1.f, S = 0.f;
+        auto one = [&](const int i) {                                  // sample i: returns the saved (sign-coded) value
+            const int2 h = *reinterpret_cast<const int2 *>(myrec + i * kRec);        // (tile byte offset, w_k)
+            const float4 w = *reinterpret_cast<const float4 *>(myw + i * kRec);
+            const float *a = reinterpret_cast<const float *>(tl + h.x);
+            float v = a[0] * w.x;
+            v = __builtin_fmaf(a[kXS], w.y, v);
+            v = __builtin_fmaf(a[kYS], w.z, v);
+            v = __builtin_fmaf(a[kXS + kYS], w.w, v);
             v = other_half_sum(v);
-            const float p = fminf(fmaxf(v, D.lo), D.hi);                              // spherical_proj.py:66
-            if (SAVE) {     // samples 2j (lower half-wave) and 2j+1 (upper) leave together: one 256-byte store per pair
-                const float sp = (v >= D.lo && v <= D.hi) ? p : -p;
-                if (i & 1) st[(size_t)(i - 1 + half) * kImgs] = half ? sp : sprev;
-                else if (i == L - 1 && half == 0) st[(size_t)i * kImgs] = sp;
-                sprev = sp;
-            }
-            S = __builtin_fmaf(T * p, dwk, S);                                        // + s_k w_k  (:68)
+            const float p = __builtin_amdgcn_fmed3f(v, D.lo, D.hi);                   // clamp (spherical_proj.py:66)
+            S = __builtin_fmaf(T * p, __int_as_float(h.y), S);                        // + s_k w_k  (:68)
             T *= 1.0f - p;
+            return (p == v) ? p : -p;                                  // negated where the clamp does not pass the gradient
+        };
+#pragma unroll
+        for (int j = 0; j < kMaxSeg / 2; j++) {
+            if (2 * j < L) {
+                const float spa = one(2 * j);
+                float spb = 0.f;
+                if (2 * j + 1 < L) spb = one(2 * j + 1);
+                sp[j] = half ? spb : spa;
+            }
         }
-        ps[((size_t)(g * D.nseg + s) * 2 + half) * kImgs + l] = half ? S : T;
+        ps_val = half ? S : T;
+        Lprev = L;
+        stp_prev = SAVE ? stash + ((size_t)g * D.nslot + slot0) * kImgs : nullptr;
+        ps_prev = ps + (size_t)(g * D.nseg + s) * 2 * kImgs;
         wave_lds_fence();                                                             // records are overwritten next
         sg = sg1; sg1 = sg2;
     }
+    flush_prev();
 }
 
 // sph_pad (spherical_proj.py:21-28) as a fan-out of map pixel (i, j): see sph_render.hip: pad_span
@@ -361,7 +392,6 @@ __device__ __forceinline__ void both_halves(float v, float &lower, float &upper)
 }
 
 constexpr int kHalfSeg = kMaxSeg / 2;
-constexpr int kRecL = 16;                                // words per record slot in the scatter kernel's LDS (see there)
 
 // A lane-uniform ownership bit pair (lower half-wave, upper half-wave) as an execution mask: two s_bfe_i32 and the
 // s_and_saveexec of the `if` -- no vector instruction and no branch, so the compiler counts the LDS operations in flight
@@ -421,8 +451,7 @@ __global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scat
     // entry = (segment, stash slot of its first sample, i0 | i1 << 6 | L << 12 | k0 << 18, rec_b slot of sample i0).
     // Software pipeline: while entry e is scattered, the saved samples, the two ray scalars, the depth weights and the
     // records of entry e + kWavesB are in flight to registers (two register sets, used alternately: no copies) and the
-    // header of e + 2 kWavesB is being fetched and decoded.  (Measured on MI355X, batch 32: a prefetch distance of two
-    // entries -- three register sets -- was 4 % SLOWER: the fetch phase runs at its throughput, not its latency.)
+    // header of e + 2 kWavesB is being fetched and decoded.
     // Global addresses = wave-uniform 64-bit base (scalar registers) + a 32-bit per-lane offset: three persistent
     // vector registers instead of three address pairs.
     const unsigned lo_st = (unsigned)(half * kImgs + l), lo_tr = (unsigned)l, lo_rq = (unsigned)lane * 4u;
@@ -439,26 +468,21 @@ __global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scat
         r.pk = h.z;
         return r;
     };
+    // EVERY fetch issues the same twelve vector loads, unconditionally: the compiler can then wait for "all but the
+    // twelve youngest" when the current entry's registers are first used -- with loads behind branches or execution masks
+    // it has to assume the fewest, waits for (almost) everything, and the prefetch it was meant to overlap is stalled on at
+    // once.  Samples and records read past the entry's own (the slot and record spaces are padded) are never used.
     auto fetch = [&](const Hdr h, BmEntryRegs &o) {
-        const int Lh = (h.pk >> 12) & 63;
-        // four samples at a time, decided on the scalar unit; the at most three slots read past the segment's end exist
-        // (the table builder pads the slot space) and are never used
 #pragma unroll
-        for (int jj = 0; jj < kHalfSeg / 2; jj++) {
-            if (4 * jj < Lh) {
-                o.p[2 * jj] = (h.st + (4 * jj) * kImgs)[lo_st];
-                o.p[2 * jj + 1] = (h.st + (4 * jj + 2) * kImgs)[lo_st];
-            }
-        }
+        for (int j = 0; j < kHalfSeg; j++) o.p[j] = (h.st + (2 * j) * kImgs)[lo_st];
         o.T = h.tp[lo_tr]; o.R = (h.tp + kImgs)[lo_tr];
-        const int cnt = (((h.pk >> 6) & 63) - (h.pk & 63)) * 3;
-        if (lane < cnt) o.rq = *reinterpret_cast<const int4 *>(h.rq + lo_rq);
-        if (lane < kMaxSeg) o.wk = dw[min(((h.pk >> 18) & 255) + lane, D.ZR - 1)];   // depth weight of sample `lane`
+        o.rq = *reinterpret_cast<const int4 *>(h.rq + lo_rq);
+        o.wk = dw[min(((h.pk >> 18) & 255) + (lane & (kMaxSeg - 1)), D.ZR - 1)];     // depth weight of sample `lane` (lanes 0-15)
     };
     // One entry.  `h2raw` is the raw header of the entry after next, requested by the caller just before: it is decoded
     // between the two scans, so that the scalar load is retired BEFORE the reverse loop -- a scalar load still in flight
     // would force every wait of that loop down to "everything", atomics included (scalar loads return out of order).
-    auto entry = [&](const int pk, const bool has_next, const Hdr h1, const bool has_next2, const int4 h2raw, Hdr &h2,
+    auto entry = [&](const int pk, const Hdr h1, const bool has_next2, const int4 h2raw, Hdr &h2,
                      BmEntryRegs &cur, BmEntryRegs &nxt) {
         const int i0 = pk & 63, i1 = (pk >> 6) & 63, L = (pk >> 12) & 63;
         if (lane < (i1 - i0) * 3) {
@@ -472,7 +496,7 @@ __global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scat
             myrec[lane * kRecL + 10] = __float_as_int(cur.wk);
         }
         wave_lds_fence();
-        if (has_next) fetch(h1, nxt);
+        fetch(h1, nxt);                                                 // (the last entry: itself again, see the caller)
         float Tg = cur.T, Rr = cur.R;
         float ce[kHalfSeg], co[kHalfSeg];                               // g T at samples 2j and 2j + 1
 #pragma unroll
@@ -531,6 +555,7 @@ __global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scat
         const Hdr h = decode(ents[e]);
         pk0 = h.pk;
         fetch(h, A);
+        h1 = h;                                                         // a wave's last entry prefetches a valid entry: itself
     }
     if (e + kWavesB < row.z) h1 = decode(ents[e + kWavesB]);
 #define GENRE_BM_STEP(CUR, NXT)                                                                                         \
@@ -538,8 +563,8 @@ __global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scat
         const bool n2_ = e + 2 * kWavesB < row.z;                                                                        \
         int4 raw_ = make_int4(0, 0, 0, 0);                                                                               \
         if (n2_) raw_ = ents[e + 2 * kWavesB];                                                                           \
-        entry(__builtin_amdgcn_readfirstlane(pk0), e + kWavesB < row.z, h1, n2_, raw_, h2, CUR, NXT);                    \
-        pk0 = h1.pk; h1 = h2;                                                                                            \
+        entry(__builtin_amdgcn_readfirstlane(pk0), h1, n2_, raw_, h2, CUR, NXT);                                         \
+        pk0 = h1.pk; if (n2_) h1 = h2;                                                                                   \
         e += kWavesB;                                                                                                   \
     }
     while (e < row.z) {
@@ -672,7 +697,7 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
     hipStream_t st = (hipStream_t)stream;
     // 1024 threads: 16 waves share one tile, two workgroups per CU = 8 waves per SIMD (measured 257 us against 318 with 512)
     constexpr int nt = 1024;
-    const size_t lds = (size_t)kLinesF * kImgs * 4 + (size_t)(nt / 64) * (kMaxSeg + 1) * kRec * 4;
+    const size_t lds = (size_t)kLinesF * kImgs * 4 + (size_t)(nt / 64) * 64 * 16;
     const dim3 grid((unsigned)fwd_rows->size[0], (unsigned)D.groups);
 #define GENRE_BM_SAMPLE_NT(PSV, SV, NTV)                                                                                  \
     do {                                                                                                                  \

@@ -19,8 +19,10 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
   segs      int32 [nseg,4]   (ray q, first sample k0, length L, slot of the first sample)   sorted by (brick, q, k0)
   rec_f     int32 [S,12]     per sample slot: (tile byte offset, depth_weight[k] bits, 0, 0,
                               w(x0y0z0), w(x1y0z0), w(x0y1z0), w(x1y1z0), w(x0y0z1), w(x1y0z1), w(x0y1z1), w(x1y1z1));
-                              S = samples + SLOT_PAD: the last SLOT_PAD slots belong to no sample (all zero) -- the backward
-                              fetches a segment's saved samples four at a time and may read up to three slots past its end
+                              S = samples + SLOT_PAD: the last SLOT_PAD slots belong to no sample (all zero) -- the kernels
+                              issue a FIXED number of loads per segment (every lane of a wave loads 16 bytes of records =
+                              21.3 records from the segment's first; all 16 sample slots of a segment are fetched) so
+                              that their waits on the in-order load counter can be exact; the excess is never used
   fwd_rows  int32 [rows,4]   (brick, seg begin, seg end, flag); flag 2 = padding row (skipped); order: see _xcd_order
   ray_ptr   int32 [RR+1], ray_seg int32 [nseg]   the segments of every ray in sample order
   ray_pre   float64 [RR,2]   (P0, S0) of the samples before the ray enters the volume (p = 1e-5 each)
@@ -28,7 +30,8 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
                               i0 | i1 << 6 | L << 12 | k0 << 18, rec_b slot of sample i0): samples i0..i1-1 of the
                               segment touch the brick of the row
   rec_b     int32 [SB,12]    (tile byte offset in the brick's own fp64 tile -- may point outside it for corners the
-                              brick does not own --, ownership bits (corner c, z half h) -> bit c + 4h, 0, 0, 8 weights)
+                              brick does not own --, ownership bits (corner c, z half h) -> bit c + 4h, 0, 0, 8 weights);
+                              SB = listed samples + REC_PAD zero records (same reason as SLOT_PAD)
   bwd_rows  int32 [rows,4]   (pull brick, ent begin, ent end, shared); shared = 1: the brick is split
                               over several rows, which add their tiles atomically onto pre-zeroed voxels.  The backward's
                               ("pull") bricks are PULL = 4x8x8 voxels like the forward's; 8x8x8 (a segment then touches fewer bricks,
@@ -39,7 +42,8 @@ import numpy as np
 BX, BY, BZ = 4, 8, 8            # must match csrc/sph_render_bm.hip
 TX, TY, TZ = BX + 1, BY + 1, BZ + 1
 MAXSEG = 16
-SLOT_PAD = 16                   # unused slots behind the last sample (see rec_f)
+SLOT_PAD = 24                   # unused slots behind the last sample (see rec_f): >= 22, every lane of a wave loads 16 bytes of rec_f
+REC_PAD = 22                    # unused records behind rec_b: every lane of a wave loads 16 bytes from an entry's first record
 LINE_F = 128                    # bytes of one voxel line in the forward tile (32 images x fp32)
 LINE_B = 256                    # ... in the backward tile (32 images x fp64)
 SPLIT_F = 4096                  # samples per forward row
@@ -192,8 +196,8 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     rel = []
     for ax in range(3):                                                     # base corner relative to the pulling brick
         rel.append(bxyz[ax][s_id] - (pb[ax][s_id] + ((dcode >> ax) & 1)) * pull[ax])
-    rec_b = np.zeros((nl, 12), np.int32)
-    rec_b[:, 0] = ((rel[0] * pull[1] + rel[1]) * pull[2] + rel[2]) * LINE_B
+    rec_b = np.zeros((nl + REC_PAD, 12), np.int32)
+    rec_b[:nl, 0] = ((rel[0] * pull[1] + rel[1]) * pull[2] + rel[2]) * LINE_B
     own = np.zeros(nl, np.int32)
     valid = [(np.ones(ns, bool), v1s[ax][qq, kk]) for ax in range(3)]
     for c in range(8):
@@ -204,8 +208,8 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
             okc &= (coord >= 0) & (coord < pull[ax]) & valid[ax][bit][s_id]
         h, cxy = c >> 2, c & 3
         own |= okc.astype(np.int32) << (cxy + 4 * h)
-    rec_b[:, 1] = own
-    rec_b[:, 4:12] = wts[s_id].view(np.int32)
+    rec_b[:nl, 1] = own
+    rec_b[:nl, 4:12] = wts[s_id].view(np.int32)
     assert (own != 0).all()
     eb = np.searchsorted(ent_brick, np.arange(pnb), side="left")
     ee = np.searchsorted(ent_brick, np.arange(pnb), side="right")

@@ -274,8 +274,10 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *                             sorted by (brick, ray, k0); slots number the in-volume samples in that order
  *   rec_f     int32 [S,12]    per slot: byte offset of the base voxel line in the brick's 5x9x9 x 32-image fp32 tile,
  *                             depth_weight[k] (fp32 bits), 0, 0, the 8 trilinear weights (x fastest, then y, then z);
- *                             S = in-volume samples + 16 unused trailing slots (the backward fetches saved samples four
- *                             at a time and may read up to three slots past a segment's end)
+ *                             S = in-volume samples + 24 unused trailing slots: the kernels issue a fixed number of loads
+ *                             per segment (all 64 lanes load 16 bytes of records, all 16 sample slots are fetched) so
+ *                             that the hardware's in-order load counter can be waited on exactly; what lies past a
+ *                             segment's own records / samples is read and never used
  *   fwd_rows  int32 [rows,4]  (brick, seg begin, seg end, 0): one workgroup each; every brick in >= 1 row
  *   ray_ptr   int32 [R*R+1], ray_seg int32 [nseg]: the segments of each ray in sample order
  *   ray_pre   float64 [R*R,2] viewed as fp32 [R*R,4]: (transmittance, partial sum) of the samples before the ray
@@ -284,7 +286,8 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *                             samples i0..i1-1 of the segment have a
  *                             corner inside the brick of the row that lists the entry
  *   rec_b     int32 [SB,12]   byte offset in the brick's own 4x8x8 x 32-image fp64 tile, ownership bits
- *                             (bit c + 4h: corner (x,y) = c of z half h belongs to this brick), 0, 0, 8 weights
+ *                             (bit c + 4h: corner (x,y) = c of z half h belongs to this brick), 0, 0, 8 weights;
+ *                             SB = listed samples + 22 unused trailing records (same reason)
  *   bwd_rows  int32 [rows,4]  (pull brick, ent begin, ent end, shared): shared = 1 rows add onto pre-zeroed voxels;
  *                             the backward's bricks are pull_brick = 488 (4x8x8 voxels) or 888 (8x8x8), as the tables were built
  * Scratch (caller-allocated, groups = ceil(N/32)):
