@@ -97,6 +97,8 @@ def parse():
                     help="memory order of the projected volume between cam_bp and the renderer: bm = image index fastest "
                          "(batch-minor tile renderer, batches >= 16), std = the reference's NCXYZ")
     ap.add_argument("--no-m1", action="store_true", help="skip the GenRe whole-model forward (M1)")
+    ap.add_argument("--no-train", action="store_true", help="skip the configs[3]/[4] train-step timings (`train`)")
+    ap.add_argument("--train-steps", type=int, default=8, help="timed optimizer steps per train config")
     ap.add_argument("--eager", action="store_true", help="time eager launches of the step instead of a HIP-graph replay")
     ap.add_argument("--stub", action="store_true", help="launcher self-test: a trivial CPU step over gloo, no GPU")
     return ap.parse_args()
@@ -442,6 +444,73 @@ def m1_genre_forward(G, dev):
     return res
 
 
+def train_bench(dev, dist, du, world, rank, steps):
+    """BASELINE.json configs[3] / configs[4] as per-rank shards of their 8-GPU batches: one optimizer step of
+      shapehd_b8      ShapeHD fine-tuning, batch 64 / 8 = 8 per rank (models/shapehd.py:82-118, marrnet2.py:46-54)
+      wgangp_b8       3-D WGAN-GP critic + generator step, batch 8 per rank (models/wgangp.py:77-164)
+      genre_joint_b4  GenRe joint fine-tuning through the projections + Chamfer, batch 32 / 8 = 4 per rank
+                      (depth_pred_with_sph_inpaint.py:114-118, genre_full_model.py:117-121)
+    at the reference's network widths, fp32, Adam, synthetic seeded batches resident on the device, every trainable
+    network under DistributedDataParallel when world > 1 (RCCL all-reduce overlapped with the backward).  Runs on EVERY
+    rank; timing = barrier + synchronize on both sides, max over ranks; samples/s = world * batch * steps / time."""
+    from genre_shapehd_amd import train as T
+    from genre_shapehd_amd.models import shapehd as MS
+    from genre_shapehd_amd.models.genre import GenReNet, GenReOptions
+    res = {"what": "one optimizer step per config at the per-rank shard of the 8-GPU batch, reference widths, fp32, "
+                   "DDP over %d rank(s)" % world, "steps": steps}
+
+    def fence():
+        du.fence(dist, torch.cuda.synchronize)
+
+    def timed(name, batch, fn, note):
+        try:
+            for _ in range(2):
+                fn()                                                    # MIOpen find, allocator, DDP bucket build
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            fence()
+            el = du.max_over_ranks(dist, time.perf_counter() - t0, dev)
+            res[name] = {"batch_per_gpu": batch, "ms_per_step": el * 1e3 / steps,
+                         "samples_per_s": world * batch * steps / el, "what": note}
+        except Exception as e:      # pragma: no cover -- never fatal for the bench line
+            res[name] = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
+
+    to = lambda ns: type(ns)(**{k: v.to(dev) for k, v in vars(ns).items()})       # noqa: E731
+    torch.manual_seed(1234)                                             # identical initial weights on every rank
+    # configs[3]
+    net = MS.ShapeHDNet().to(dev).train()
+    model = T.ddp(net, dev, dist)
+    optim = torch.optim.Adam(net.marrnet2.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    ins, vox = T.sketch_batch(8, "cpu", seed=500 + rank)
+    ins, vox = to(ins), vox.to(dev)
+    timed("shapehd_b8", 8, lambda: T.shapehd_train_step(model, optim, ins, vox, 1e-3),
+          "MarrNet-2 fine-tuned against the frozen 3-D critic: forward (incl. frozen copy + critic), backward, Adam")
+    del net, model, optim
+    gan = MS.WGANGP(lr=1e-4)
+    gan.net_g.to(dev), gan.net_d.to(dev)
+    gan.net_g, gan.net_d = T.ddp(gan.net_g, dev, dist), T.ddp(gan.net_d, dev, dist)
+    timed("wgangp_b8", 8, lambda: gan.train_on_batch(0, vox),
+          "critic step (real, fake, second-order gradient penalty) + generator step")
+    del gan, ins, vox
+    # configs[4]
+    gopt = GenReOptions(joint_train=True)
+    net = GenReNet(gopt).to(dev).train()
+    with torch.no_grad():                                               # a depth range that puts the surface in the cube
+        head = net.depth_and_inpaint.net1.decoder_minmax[9]
+        head.weight.zero_()
+        head.bias.copy_(torch.tensor([1.9, 2.4]))
+    model = T.ddp(net, dev, dist)
+    optim = torch.optim.Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.9))
+    gin, gt = T.genre_batch(4, "cpu", seed=600 + rank)
+    gin, gt = to(gin), to(gt)
+    timed("genre_joint_b4", 4, lambda: T.genre_train_step(model, optim, gin, gt, gopt, chamfer_weight=0.1),
+          "all three modules + cam_bp / render_spherical / spherical back-projection / Chamfer in the graph, Adam")
+    return res
+
+
 def cpu_baseline(budget_s):
     """the same step on the host cores: reference kernel bodies (oracle/_ref) if they travelled
     with the snapshot, else the C port; torch CPU ops (1 thread) for grid_sample/matmul."""
@@ -576,6 +645,10 @@ def main():
     elapsed = dist_utils.max_over_ranks(dist, elapsed, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
+    train = None
+    if not args.no_train:           # every rank takes part (DDP all-reduce); reported in the same JSON line
+        torch.cuda.empty_cache()
+        train = train_bench(dev, dist, dist_utils, world, rank, args.train_steps)
 
     if rank == 0:
         rows = kernel_table(G, dev, B)
@@ -638,6 +711,8 @@ def main():
                 out["m1"] = m1
             except Exception as e:          # pragma: no cover -- never fatal for the bench line
                 out["m1"] = {"error": str(e)[:300]}
+        if train is not None:
+            out["train"] = train
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -174,8 +174,13 @@ class GenReInference:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self.net(Inputs(s_rgb, s_sil))["pred_voxel"]
-            cap = self._captured[key] = (g, s_rgb, s_sil, out)
-        g, s_rgb, s_sil, out = cap
+            # the graph holds raw pointers of every tensor the forward read, among them the cached fl / cam_dist
+            # constants of the back-projection layers: pin them for the life of the graph
+            from ..toolbox import _fused_render
+            pinned = [t for m in self.net.modules() for t in getattr(m, "_consts", {}).values()]
+            pinned.append(list(_fused_render._TABLES.values()))          # the renderer's geometry tables likewise
+            cap = self._captured[key] = (g, s_rgb, s_sil, out, pinned)
+        g, s_rgb, s_sil, out = cap[:4]
         s_rgb.copy_(rgb)
         s_sil.copy_(silhou)
         g.replay()

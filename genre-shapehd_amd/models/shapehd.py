@@ -61,19 +61,29 @@ class WGANGP:
     penalty itself is differentiated) and, every gan_d_iter-th batch, one generator step.  `net_d` / `net_g` may be
     DistributedDataParallel wrappers: each loss.backward() then all-reduces that network's gradients over RCCL."""
 
-    def __init__(self, net_g=None, net_d=None, nz=200, lr=1e-4, betas=(0.5, 0.9), lam=10.0, norm=1.0, d_iter=1):
+    def __init__(self, net_g=None, net_d=None, nz=200, lr=1e-4, betas=(0.5, 0.9), lam=10.0, norm=1.0, d_iter=1,
+                 generator=None):
+        """generator: optional CPU torch.Generator -- latent codes and the interpolation weights of the penalty are then
+        drawn on the host from it and copied to the device (a run is reproducible across devices); default: drawn on
+        the device, as the reference does (wgangp.py:98,134)"""
         self.net_g = net_g if net_g is not None else VoxelGenerator(nz)
         self.net_d = net_d if net_d is not None else VoxelDiscriminator()
         self.nz, self.lam, self.norm, self.d_iter = nz, lam, norm, d_iter
         self.opt_g = torch.optim.Adam(self.net_g.parameters(), lr=lr, betas=betas)
         self.opt_d = torch.optim.Adam(self.net_d.parameters(), lr=lr, betas=betas)
         self._last_err_g = None
+        self.generator = generator
+
+    def _random(self, fn, shape, device):
+        if self.generator is None:
+            return fn(*shape, device=device)
+        return fn(*shape, generator=self.generator).to(device)
 
     def sample(self, n, device):
-        return self.net_g(torch.randn(n, self.nz, 1, 1, 1, device=device))
+        return self.net_g(self._random(torch.randn, (n, self.nz, 1, 1, 1), device))
 
     def grad_penalty(self, real, fake):
-        alpha = torch.rand(real.shape[0], *([1] * (real.dim() - 1)), device=real.device)
+        alpha = self._random(torch.rand, (real.shape[0],) + (1,) * (real.dim() - 1), real.device)
         inter = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
         score = self.net_d(inter)
         grads, = torch.autograd.grad(score, inter, torch.ones_like(score), create_graph=True, retain_graph=True)

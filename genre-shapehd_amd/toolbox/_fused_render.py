@@ -23,6 +23,32 @@ SPLIT_FWD = 16384       # forward rows may be split freely (every sample is writ
 SPLIT_FWD_SMALL = 4096  # ... more finely when fewer than SMALL_BATCH images have to fill 256 CUs
 SMALL_BATCH = 4
 _TABLES = {}
+_MAX_TABLES = 8          # device table sets kept per process (oldest evicted)
+_CONTENT = {}            # (data_ptr, _version, numel) of a buffer -> (sha1 of its contents, host copy)
+
+
+def _remember(key, t):
+    while len(_TABLES) >= _MAX_TABLES:
+        _TABLES.pop(next(iter(_TABLES)))
+    _TABLES[key] = t
+
+
+def _content_of(buf):
+    """(sha1, numpy copy) of a small device buffer, read back once per (address, version): a buffer that is rewritten
+    with the same values (DDP's buffer broadcast, load_state_dict) costs one device -> host copy per rewrite but maps to
+    the same table entry, and a different buffer at a recycled address cannot alias an old entry once its version or
+    contents differ."""
+    import hashlib
+    ident = (buf.data_ptr(), buf._version, buf.numel(), str(buf.device))
+    c = _CONTENT.get(ident)
+    if c is None:
+        host = buf.detach().cpu().numpy().copy()
+        c = (hashlib.sha1(host.tobytes()).hexdigest(), host)
+        if len(_CONTENT) >= 64:
+            _CONTENT.clear()
+        _CONTENT[ident] = c
+    return c
+
 
 
 def available():
@@ -149,7 +175,7 @@ def tables_for(vox_shape, device, dirs64, z_res):
         np_t = _disk_cached("brick", (tuple(vox_shape[2:]), z_res, sf, SPLIT_BWD, BRICK), [d64],
                             lambda: build_brick_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, z_res, split_fwd=sf))
         t = {k: torch.from_numpy(v).to(device) for k, v in np_t.items()}
-        _TABLES[key] = t
+        _remember(key, t)
     return t
 
 
@@ -164,13 +190,12 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
     import os
     from . import _bm_tables
     pull = {"488": (4, 8, 8), "888": (8, 8, 8)}[os.environ.get("GENRE_BM_PULL", "488")]      # backward brick (A/B switch)
-    # keyed on the identity + version of the depth_weight buffer, not on its contents: no device -> host copy (and no
-    # stream synchronisation, which HIP-graph capture forbids) on the hot path
-    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], depth_weight.data_ptr(),
-           depth_weight._version, str(device), pull)
+    # keyed on the CONTENTS of the depth_weight buffer (hashed once per address + version, _content_of): no device ->
+    # host copy -- and no stream synchronisation, which HIP-graph capture forbids -- while the buffer is untouched
+    dw_hash, dw = _content_of(depth_weight)
+    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], dw_hash, str(device), pull)
     t = _TABLES.get(key)
     if t is None:
-        dw = depth_weight.detach().cpu().numpy()
         d64 = dirs64.cpu().numpy()
 
         def build():
@@ -186,7 +211,7 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
             if k == "ray_pre":
                 tv = tv.view(torch.float32).reshape(-1, 4)
             t[k] = tv.to(device)
-        _TABLES[key] = t
+        _remember(key, t)
     return t
 
 

@@ -20,16 +20,22 @@ class Camera_back_projection_layer(nn.Module):
         self.batch_minor = batch_minor
         self._consts = {}
 
+    _MAX_CONSTS = 32
+
     def _const(self, value, n, device):
         # the reference allocates + fills a fresh [n,1] tensor every call (:16-21); cache it so the
-        # layer issues no extra kernels and can be captured in a HIP graph
-        # one entry per (constant, device): a new batch size replaces the old tensor, so the cache cannot grow with the
-        # batch sizes seen; the tensors are read-only inputs of the op (autograd saves them) -- do not modify them
-        key = (float(value), str(device))
-        t = self._consts.get(key)
-        if t is None or t.shape[0] != n:
+        # layer issues no extra kernels and can be captured in a HIP graph.
+        # One tensor per (constant, batch size, device), never replaced while it is in the cache: a captured HIP graph
+        # holds the raw pointer of the tensor that existed at capture, so a tensor handed out once must stay alive
+        # (GenReInference additionally pins the tensors its graphs saw).  The cache is a small LRU so that it cannot grow
+        # with the batch sizes seen; the tensors are read-only inputs of the op (autograd saves them) -- do not modify.
+        key = (float(value), int(n), str(device))
+        t = self._consts.pop(key, None)
+        if t is None:
             t = torch.full((n, 1), float(value), dtype=torch.float32, device=device)
-            self._consts[key] = t
+            while len(self._consts) >= self._MAX_CONSTS:
+                self._consts.pop(next(iter(self._consts)))
+        self._consts[key] = t                                            # most recently used last
         return t
 
     def forward(self, depth_t, fl=418.3, cam_dist=2.2, shift=True):

@@ -77,12 +77,14 @@ def shapehd_train_step(net, optimizer, inputs, gt_voxel, w_gan_loss=0.0):
     return loss.detach(), parts
 
 
-def depth_to_points(abs_depth, silhou_t, k=2048, fl=418.3, cam_dist=2.2, generator=None):
+def depth_to_points(abs_depth, silhou_t, k=2048, fl=418.3, cam_dist=2.2, generator=None, idx=None):
     """back-project k foreground pixels of a ray-depth map [n,1,H,W] (the layout get_abs_depth produces) to 3-D with
-    cam_bp's camera (back_projection_kernel.cu:231-242): differentiable w.r.t. the depth.  -> [n,k,3]"""
+    cam_bp's camera (back_projection_kernel.cu:231-242): differentiable w.r.t. the depth.  -> [n,k,3].  idx [n,k]
+    (int64 pixel indices) fixes the sample instead of drawing it (reproducible steps)."""
     n, _, H, W = abs_depth.shape
-    fg = (abs_depth.detach().flatten(1) > 0).float() + 1e-6
-    idx = torch.multinomial(fg, k, replacement=True, generator=generator)
+    if idx is None:
+        fg = (abs_depth.detach().flatten(1) > 0).float() + 1e-6
+        idx = torch.multinomial(fg, k, replacement=True, generator=generator)
     d = abs_depth.flatten(1).gather(1, idx)
     u = (idx // W).float() - (H - 1) / 2.0
     v = (idx % W).float() - (W - 1) / 2.0
@@ -90,7 +92,7 @@ def depth_to_points(abs_depth, silhou_t, k=2048, fl=418.3, cam_dist=2.2, generat
     return torch.stack((dz - cam_dist, -dz * v / fl, -dz * u / fl), -1)
 
 
-def genre_train_step(net, optimizer, inputs, gt, opt, chamfer_weight=0.0):
+def genre_train_step(net, optimizer, inputs, gt, opt, chamfer_weight=0.0, chamfer_idx=None):
     """joint fine-tuning of all three GenRe modules (--joint_train, depth_pred_with_sph_inpaint.py:114-118,
     genre_full_model.py:117-121): the gradient of the voxel / spherical losses flows back through the spherical
     back-projection, the inpainting net, render_spherical, cam_bp and get_abs_depth into MarrNet-1.  chamfer_weight > 0
@@ -104,7 +106,7 @@ def genre_train_step(net, optimizer, inputs, gt, opt, chamfer_weight=0.0):
     if chamfer_weight > 0:
         from genre_shapehd_amd.toolbox.nndistance.functions.nnd import nndistance
         depth = AbsDepth.apply(pred["depth"], pred["depth_minmax"], inputs.silhou, SCALE_25D)
-        pts = depth_to_points(depth, inputs.silhou).contiguous()
+        pts = depth_to_points(depth, inputs.silhou, idx=chamfer_idx).contiguous()
         d1, d2 = nndistance(pts, gt.cloud.contiguous())
         loss = loss + chamfer_weight * (d1.mean() + d2.mean())
     loss.backward()
@@ -116,9 +118,12 @@ def ddp(net, device, dist):
     if dist is None:
         return net
     from torch.nn.parallel import DistributedDataParallel as DDP
+    # broadcast_buffers=False: BatchNorm running statistics stay per rank (the reference has no SyncBN and no buffer
+    # broadcast); DDP's default would overwrite every rank's buffers with rank 0's on each forward
     if device.type == "cuda":
-        return DDP(net, device_ids=[device.index], bucket_cap_mb=64)     # ~2 buckets for Unet_3D's 214 MB of gradients
-    return DDP(net)
+        return DDP(net, device_ids=[device.index], bucket_cap_mb=64,     # ~4 buckets for Unet_3D's 214 MB of gradients
+                   broadcast_buffers=False)
+    return DDP(net, broadcast_buffers=False)
 
 
 def main(argv=None):

@@ -292,3 +292,50 @@ class GenReGlueCPU:
         proj_df = proj_df * mask
         pd = torch.clamp(proj_depth / 50, 1e-5, 1 - 1e-5)
         return torch.cat((proj_df, pd), dim=1), cnt
+
+
+def make_nnd(backend):
+    """toolbox/nndistance/functions/nnd.py:8-63 over the oracle's Chamfer (my_lib.c:30-118)"""
+
+    class NNDCPU(Function):
+        @staticmethod
+        def forward(ctx, xyz1, xyz2):
+            d1, d2, i1, i2 = backend.nnd_forward(_np(xyz1), _np(xyz2))
+            ctx.save_for_backward(xyz1, xyz2)
+            ctx.idx = (i1, i2)
+            return torch.from_numpy(d1), torch.from_numpy(d2)
+
+        @staticmethod
+        def backward(ctx, gd1, gd2):
+            xyz1, xyz2 = ctx.saved_tensors
+            g1, g2 = backend.nnd_backward(_np(xyz1), _np(xyz2), _np(gd1), _np(gd2), *ctx.idx)
+            return torch.from_numpy(g1), torch.from_numpy(g2)
+
+    return NNDCPU
+
+
+class GenReCPU:
+    """the forward of the reference's GenRe full model (genre_full_model.py:116-143 around
+    depth_pred_with_sph_inpaint.py:113-129) on CPU torch: the three networks are the ones handed in (CPU copies of the
+    model under test or the reference's own classes), every geometric op between them is the oracle's, wrapped in the
+    autograd Functions above so the chain is differentiable end to end.  Returns the reference's output dict."""
+
+    def __init__(self, backend, net1, net2, refine_net, margin=16):
+        self.glue = GenReGlueCPU(backend, margin)
+        self.net1, self.net2, self.refine_net = net1, net2, refine_net
+        self.nnd = make_nnd(backend).apply
+
+    def forward(self, input_struct, joint_train=True):
+        with torch.set_grad_enabled(joint_train and torch.is_grad_enabled()):
+            out = self.net1(input_struct)
+            depth = self.glue.get_abs_depth(out["depth"], out["depth_minmax"], input_struct.silhou)
+            proj50, sph_in = self.glue.depth_to_spherical(depth)
+            out["abs_depth"] = depth
+            out["proj_depth"] = proj50
+            out["pred_sph_partial"] = sph_in
+            out["pred_sph_full"] = self.net2(sph_in)["spherical"]
+        refine_input, _ = self.glue.refiner_input(out["pred_sph_full"], out["proj_depth"])
+        out["pred_proj_sph_full"] = refine_input[:, 0:1]
+        out["pred_proj_depth"] = refine_input[:, 1:2]
+        out["pred_voxel"] = self.refine_net(refine_input)
+        return out

@@ -19,6 +19,21 @@ rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_w" -o write -- python "$ROOT/profiles/pm
 F=$(ls "$OUT"/pmc_f/fetch_results.db "$OUT"/pmc_f/*/fetch_results.db 2>/dev/null | head -1)
 W=$(ls "$OUT"/pmc_w/write_results.db "$OUT"/pmc_w/*/write_results.db 2>/dev/null | head -1)
 python "$ROOT/profiles/pmc_traffic_table.py" "$F" "$W" "$OUT/pmc_hbm_traffic.json" "$B" > "$OUT/pmc_hbm_traffic.txt" 2>&1
+# SQ counters of the two batch-minor render kernels (8 SQ slots per pass on gfx950), no trace domains beside --pmc
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d "$OUT/pmc_s1" -o sq1 -- python "$ROOT/profiles/pmc_targets.py" "$B" > /dev/null 2> "$OUT/pmc_s1.err"
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU -d "$OUT/pmc_s2" -o sq2 -- python "$ROOT/profiles/pmc_targets.py" "$B" > /dev/null 2> "$OUT/pmc_s2.err"
+S1=$(ls "$OUT"/pmc_s1/sq1_results.db "$OUT"/pmc_s1/*/sq1_results.db 2>/dev/null | head -1)
+S2=$(ls "$OUT"/pmc_s2/sq2_results.db "$OUT"/pmc_s2/*/sq2_results.db 2>/dev/null | head -1)
+python "$ROOT/profiles/pmc_sq_table.py" $S1 $S2 -- bm_scatter_kernel bm_sample_kernel bm_combine cam_brick > "$OUT/sq_counters.txt" 2>&1
+# the bench line of the same build reads the table just measured (roofline.traffic must not be null in a committed line)
+cp "$OUT/pmc_hbm_traffic.json" "$ROOT/profiles/${TAG}_pmc_hbm_traffic.json"
 cd "$ROOT" && python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+if ! python - "$OUT/bench.json" <<'PY'
+import json, sys
+line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
+sys.exit(0 if json.loads(line)["roofline"]["traffic"] is not None else 1)
+PY
+then mv "$OUT/bench.json" "$OUT/bench_REJECTED_traffic_null.json"; echo "collect_pmc.sh: roofline.traffic is null -- bench line rejected" >&2; fi
 tail -c 600 "$OUT/bench.json"; echo; head -25 "$OUT/kernel_stats.txt"; cat "$OUT/pmc_hbm_traffic.txt"
-rm -rf "$OUT"/pmc_f "$OUT"/pmc_w "$OUT"/prof
+cat "$OUT/sq_counters.txt"
+rm -rf "$OUT"/pmc_f "$OUT"/pmc_w "$OUT"/pmc_s1 "$OUT"/pmc_s2 "$OUT"/prof

@@ -80,3 +80,27 @@ def test_tables_are_cached_on_disk(tmp_path, monkeypatch):
     assert not calls and set(a) == set(b)
     for k in a:
         assert a[k] == b[k] if isinstance(a[k], int) else torch.equal(a[k], b[k]), k
+
+
+def test_table_cache_is_keyed_on_the_contents_of_depth_weight(monkeypatch, tmp_path):
+    """a depth_weight buffer that is REWRITTEN with the same values (DDP's buffer broadcast, load_state_dict: its
+    _version moves) or re-allocated elsewhere maps to the same device tables -- no rebuild, no leak -- and different
+    values never alias an old entry; the cache is bounded (toolbox/_fused_render.py: bm_tables_for)"""
+    import genre_shapehd_amd  # noqa: F401
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    from oracle.torch_oracle import unit_dirs
+    monkeypatch.setenv("GENRE_TABLE_CACHE", str(tmp_path))
+    monkeypatch.setattr(F, "_TABLES", {})
+    monkeypatch.setattr(F, "_CONTENT", {})
+    dirs = torch.from_numpy(unit_dirs(6))
+    dw = torch.linspace(0, 1, 24)
+    shape = (32, 1, 13, 13, 13)
+    t1 = F.bm_tables_for(shape, "cpu", dirs, dw)
+    dw.copy_(torch.linspace(0, 1, 24))                                   # same values, new version
+    assert F.bm_tables_for(shape, "cpu", dirs, dw) is t1
+    assert F.bm_tables_for(shape, "cpu", dirs, dw.clone()) is t1         # same values, another address
+    t2 = F.bm_tables_for(shape, "cpu", dirs, dw * 0.5)
+    assert t2 is not t1 and len(F._TABLES) == 2
+    for k in range(3 * F._MAX_TABLES):
+        F.bm_tables_for(shape, "cpu", dirs, dw * (0.9 - 0.01 * k))
+    assert len(F._TABLES) <= F._MAX_TABLES

@@ -1,0 +1,165 @@
+"""SURVEY 8 f-3 on the GPU: the train steps of BASELINE.json configs[3] (ShapeHD fine-tuning, 3-D WGAN-GP) and
+configs[4] (GenRe joint fine-tuning through the differentiable projections + Chamfer) at the REFERENCE's network
+widths, each compared with the same step on CPU torch -- gradients of every trainable tensor, relative to that
+tensor's largest gradient.  The CPU side of the GenRe step is the chain of oracle/torch_oracle.py (GenReCPU: CPU
+copies of the three networks with the oracle's geometric ops between them).  Reference: models/shapehd.py:82-118,
+models/marrnet2.py:46-54, models/wgangp.py:77-164, models/depth_pred_with_sph_inpaint.py:113-129,
+models/genre_full_model.py:116-143."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 1e-4            # per tensor: max |g_gpu - g_cpu| <= GRAD_TOL * max |g_cpu|
+
+
+def grads(net):
+    return {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+
+def compare(got, want, tol, what):
+    """per tensor: max |got - want| <= tol * max(max |want|, 1e-6 * the largest gradient of the whole step) -- the floor
+    is for tensors whose gradient is analytically zero (a convolution bias in front of a BatchNorm) and hold rounding
+    noise on both sides"""
+    assert set(got) == set(want), (what, set(got) ^ set(want))
+    top = max(v.abs().max().item() for v in want.values())
+    assert top > 0, what
+    worst = (0.0, None)
+    for k in sorted(want):
+        scale = max(want[k].abs().max().item(), 1e-6 * top)
+        rel = (got[k] - want[k]).abs().max().item() / scale
+        if rel > worst[0]:
+            worst = (rel, k)
+    print("%s: %d tensors, worst relative gradient difference %.2e (%s)" % (what, len(want), worst[0], worst[1]))
+    assert worst[0] <= tol, (what,) + worst
+    return worst[0]
+
+
+def test_shapehd_train_step_gradients_match_the_cpu_step(genre, dev):
+    """configs[3]: MarrNet-2 (ResNet-18 encoder, 200-d code, nf=512 decoder to 128^3) fine-tuned against the frozen
+    3-D critic (nf=64), per-rank shard shape of batch 64 over 8 GPUs reduced to batch 2 for the CPU side"""
+    from genre_shapehd_amd import train as T
+    from genre_shapehd_amd.models.shapehd import ShapeHDNet
+    torch.manual_seed(3)
+    cpu = ShapeHDNet().train()
+    gpu = copy.deepcopy(cpu).to(dev)
+    inputs, voxel = T.sketch_batch(2, "cpu", seed=21)
+    res = {}
+    for name, net, d in (("cpu", cpu, "cpu"), ("gpu", gpu, dev)):
+        ins = type(inputs)(**{k: v.to(d) for k, v in vars(inputs).items()})
+        optim = torch.optim.SGD(net.marrnet2.parameters(), lr=0.0)         # lr 0: the step leaves the gradients in place
+        loss, parts = T.shapehd_train_step(net, optim, ins, voxel.to(d), w_gan_loss=0.5)
+        res[name] = (loss.item(), grads(net))
+    assert abs(res["gpu"][0] - res["cpu"][0]) <= 1e-4 * max(1.0, abs(res["cpu"][0]))
+    assert all(k.startswith("marrnet2.") for k in res["cpu"][1]) and len(res["cpu"][1]) > 50
+    compare(res["gpu"][1], res["cpu"][1], GRAD_TOL, "shapehd_train_step")
+
+
+def test_wgangp_train_on_batch_gradients_match_the_cpu_step(genre, dev):
+    """configs[3]'s critic: one WGAN-GP batch (critic step with the second-order gradient penalty, generator step) at
+    the reference's widths (nz=200, nf=64, 128^3), latent codes and interpolation weights drawn from one host generator
+    on both sides"""
+    from genre_shapehd_amd import train as T
+    from genre_shapehd_amd.models.shapehd import WGANGP
+    from genre_shapehd_amd.networks import VoxelGenerator, VoxelDiscriminator
+    torch.manual_seed(5)
+    g0, d0 = VoxelGenerator(), VoxelDiscriminator()
+    _, real = T.sketch_batch(2, "cpu", seed=22)
+    res = {}
+    for name, d in (("cpu", "cpu"), ("gpu", dev)):
+        gan = WGANGP(copy.deepcopy(g0).to(d), copy.deepcopy(d0).to(d), lr=1e-6,
+                     generator=torch.Generator().manual_seed(77))
+        log = gan.train_on_batch(0, real.to(d))
+        res[name] = ({k: float(v) for k, v in log.items()}, grads(gan.net_d), grads(gan.net_g))
+    for k, v in res["cpu"][0].items():
+        assert abs(res["gpu"][0][k] - v) <= 1e-4 * max(1.0, abs(v)), (k, res["gpu"][0][k], v)
+    compare(res["gpu"][1], res["cpu"][1], GRAD_TOL, "wgangp critic step (with gradient penalty)")
+    compare(res["gpu"][2], res["cpu"][2], GRAD_TOL, "wgangp generator step")
+
+
+def _plausible_geometry(net):
+    """default-initialised heads predict a garbage depth range; pin the range so that the predicted surface lies inside
+    the voxel cube (a checkpoint does the same) -- the depth itself stays the network's output"""
+    with torch.no_grad():
+        head = net.depth_and_inpaint.net1.decoder_minmax[9]
+        head.weight.zero_()
+        head.bias.copy_(torch.tensor([1.9, 2.4]))
+    return net
+
+
+def test_genre_joint_step_gradient_reaches_marrnet1_like_the_cpu_chain(genre, oracle, dev):
+    """configs[4]: the joint loss + Chamfer term.  CPU side: the same networks with the oracle's ops between them
+    (oracle/torch_oracle.py: GenReCPU).  Two comparisons:
+
+    (a) the gradient that reaches MarrNet-1's predicted depth map THROUGH THE PROJECTIONS only -- voxel + surface loss
+        (Unet_3D <- clamp(proj) <- cam_bp <- get_abs_depth; the branch through render_spherical carries an exactly zero
+        gradient on both sides because every occupied voxel saturates the x50 clamp, depth_pred_with_sph_inpaint.py:124)
+        plus the Chamfer term -- per pixel.  The geometric ops contain floor() decisions, so the two chains may put a
+        few points into neighbouring voxels: the fraction of pixels that differ is asserted, the rest must match;
+    (b) the product's train step (all loss terms) against the CPU chain, every trainable tensor of the three modules."""
+    import torch.nn.functional as F
+    from genre_shapehd_amd import train as T
+    from genre_shapehd_amd.callers import AbsDepth
+    from genre_shapehd_amd.models import GenReNet, GenReOptions, genre_loss
+    from genre_shapehd_amd.models.genre import SCALE_25D
+    from genre_shapehd_amd.toolbox.nndistance.functions.nnd import nndistance
+    from oracle.torch_oracle import GenReCPU
+    torch.manual_seed(7)
+    opt = GenReOptions(joint_train=True)
+    cpu = _plausible_geometry(GenReNet(opt)).train()
+    gpu = copy.deepcopy(cpu).to(dev)
+    inputs, gt = T.genre_batch(2, "cpu", seed=23)
+    idx = torch.randint(0, 256 * 256, (2, 2048), generator=torch.Generator().manual_seed(9))
+    w_ch = 0.1
+    to = lambda ns, d: type(ns)(**{k: v.to(d) for k, v in vars(ns).items()})        # noqa: E731
+    in_g, gt_g = to(inputs, dev), to(gt, dev)
+    chain = GenReCPU(oracle, cpu.depth_and_inpaint.net1, cpu.depth_and_inpaint.net2, cpu.refine_net)
+
+    # (a) projection path only: d(voxel + surface + Chamfer) / d(predicted depth map)
+    pred_c = chain.forward(inputs)
+    pts = T.depth_to_points(pred_c["abs_depth"], inputs.silhou, idx=idx).contiguous()
+    d1, d2 = chain.nnd(pts, gt.cloud.contiguous())
+    l_c = genre_loss(pred_c, gt, opt, joint=False) + w_ch * (d1.mean() + d2.mean())
+    gd_c, = torch.autograd.grad(l_c, pred_c["depth"], retain_graph=True)
+    pred_g = gpu(in_g)
+    depth = AbsDepth.apply(pred_g["depth"], pred_g["depth_minmax"], in_g.silhou, SCALE_25D)
+    e1, e2 = nndistance(T.depth_to_points(depth, in_g.silhou, idx=idx.to(dev)).contiguous(), gt_g.cloud.contiguous())
+    l_g = genre_loss(pred_g, gt_g, opt, joint=False) + w_ch * (e1.mean() + e2.mean())
+    gd_g, = torch.autograd.grad(l_g, pred_g["depth"], retain_graph=True)
+    assert abs(l_g.item() - l_c.item()) <= 1e-4 * max(1.0, abs(l_c.item())), (l_g.item(), l_c.item())
+    top = gd_c.abs().max().item()
+    live = (gd_c != 0).sum().item()
+    assert top > 0 and live > 10000, (top, live)                     # the gradient really arrives through cam_bp
+    diff = (gd_g.cpu() - gd_c).abs()
+    off = (diff > 1e-3 * top).sum().item()
+    rel_l2 = (diff.double().norm() / gd_c.double().norm()).item()
+    print("projection-path gradient at the depth map: max %.3e, %d live pixels, %d differ by > 1e-3 of max (%.3f %%), "
+          "relative L2 %.2e" % (top, live, off, 100.0 * off / live, rel_l2))
+    assert off <= 0.005 * live, (off, live)
+    assert rel_l2 <= 0.05, rel_l2
+    # render_spherical's branch: exactly zero on the CPU chain (saturated clamp), and on the GPU
+    gs_c, = torch.autograd.grad(F.mse_loss(pred_c["pred_sph_full"], gt.spherical_object), pred_c["depth"])
+    gs_g, = torch.autograd.grad(F.mse_loss(pred_g["pred_sph_full"], gt_g.spherical_object), pred_g["depth"])
+    assert gs_c.abs().max().item() == 0 and gs_g.abs().max().item() == 0
+    del pred_c, pred_g, l_c, l_g
+
+    # (b) the product's train step (lr 0 keeps the gradients in place) against the CPU chain with the same loss
+    optim = torch.optim.SGD(gpu.parameters(), lr=0.0)
+    loss_g = T.genre_train_step(gpu, optim, in_g, gt_g, opt, chamfer_weight=w_ch, chamfer_idx=idx.to(dev))
+    g_gpu = grads(gpu)
+    pred = chain.forward(inputs)
+    loss_c = genre_loss(pred, gt, opt, joint=True)
+    pts = T.depth_to_points(pred["abs_depth"], inputs.silhou, idx=idx).contiguous()
+    d1, d2 = chain.nnd(pts, gt.cloud.contiguous())
+    loss_c = loss_c + w_ch * (d1.mean() + d2.mean())
+    loss_c.backward()
+    g_cpu = grads(cpu)
+    assert abs(loss_g.item() - loss_c.item()) <= 1e-4 * max(1.0, abs(loss_c.item())), (loss_g.item(), loss_c.item())
+    key = "depth_and_inpaint.net1.decoder_depth.4.3.weight"
+    a, b = g_gpu[key].double(), g_cpu[key].double()
+    rel_l2 = ((a - b).norm() / b.norm()).item()
+    print("depth head gradient: |g| = %.3e, relative L2 difference %.2e" % (b.norm().item(), rel_l2))
+    assert b.abs().max().item() > 0 and rel_l2 <= 1e-3
+    compare(g_gpu, g_cpu, 1e-3, "genre joint step")

@@ -139,3 +139,61 @@ def test_genre_model_state_dict_has_the_reference_keys():
         want["depth_and_inpaint.net1.decoder_minmax.%s.num_batches_tracked" % i] = []
     got = {k: list(v.shape) for k, v in GenReNet().state_dict().items()}
     assert got == want
+
+
+def _gan_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import genre_shapehd_amd  # noqa: F401
+    from genre_shapehd_amd import train as T, dist_utils
+    from genre_shapehd_amd.models.shapehd import WGANGP
+    from genre_shapehd_amd.networks import VoxelGenerator, VoxelDiscriminator
+    dist = dist_utils.init_from_env("gloo")
+    torch.manual_seed(0)                                                # identical initial weights on every rank
+    raw_g, raw_d = VoxelGenerator(nz=8, nf=2, res=64), VoxelDiscriminator(nf=2, res=64)
+    gan = WGANGP(raw_g, raw_d, nz=8, lr=1e-3, generator=torch.Generator().manual_seed(100 + rank))
+    gan.net_g, gan.net_d = T.ddp(raw_g, torch.device("cpu"), dist), T.ddp(raw_d, torch.device("cpu"), dist)
+    rng = torch.Generator().manual_seed(200 + rank)                     # different data on every rank
+    for step in range(2):
+        real = (torch.rand(2, 1, 64, 64, 64, generator=rng) > 0.7).float()
+        gan.train_on_batch(step, real)
+    ret[rank] = {"g": [p.detach().numpy().copy() for p in raw_g.parameters()],
+                 "d": [p.detach().numpy().copy() for p in raw_d.parameters()],
+                 "bn": [b.detach().numpy().copy() for k, b in raw_g.named_buffers() if k.endswith("running_mean")]}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_wgangp_under_ddp_keeps_parameters_in_sync_and_batchnorm_statistics_per_rank():
+    """models/wgangp.py:77-164 under DDP: the critic is called three times (real, fake, interpolate) before its one
+    backward and its penalty is a second-order gradient; after two batches of different data per rank the parameters
+    of both networks are identical on the two ranks (all-reduced gradients), while the generator's BatchNorm running
+    statistics differ -- buffers are NOT broadcast (train.ddp: broadcast_buffers=False; the reference has no SyncBN)"""
+    import numpy as np
+    world, port = 2, 31600 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_gan_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    for net in ("g", "d"):
+        assert len(a[net]) == len(b[net]) > 0
+        for x, y in zip(a[net], b[net]):
+            assert np.array_equal(x, y), net
+    assert len(a["bn"]) > 0 and any(not np.array_equal(x, y) for x, y in zip(a["bn"], b["bn"]))
+
+
+def test_back_projection_layer_constants_survive_a_change_of_batch_size():
+    """a captured HIP graph holds the raw pointer of the layer's cached fl / cam_dist tensors: a tensor handed out for
+    one batch size must stay alive (and unchanged) when another batch size is seen"""
+    import genre_shapehd_amd  # noqa: F401
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp.modules.camera_backprojection_module import Camera_back_projection_layer
+    layer = Camera_back_projection_layer()
+    t1 = layer._const(418.3, 1, "cpu")
+    t8 = layer._const(418.3, 8, "cpu")
+    again = layer._const(418.3, 1, "cpu")
+    assert again is t1 and t8.shape == (8, 1) and t1.shape == (1, 1)
+    assert layer._const(2.2, 1, "cpu") is not t1
+    for n in range(2, 2 + 3 * layer._MAX_CONSTS):                       # bounded
+        layer._const(418.3, n, "cpu")
+    assert len(layer._consts) <= layer._MAX_CONSTS
