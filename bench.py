@@ -321,9 +321,15 @@ def batch1_graph(G, dev):
     s = torch.empty_like(p)
     reps = 20
 
-    def body():
+    # the camera as Camera_back_projection_layer passes it when called with Python floats (the reference's default call,
+    # camera_backprojection_module.py:12-21): by value (genre_back_projection_forward_const); `tensor_camera` below
+    # repeats the measurement with fl / cam_dist tensors (genre_back_projection_forward)
+    def cam_fwd():
+        cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, tdf, cnt)
+
+    def body(cam=cam_fwd):
         for _ in range(reps):
-            cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt)
+            cam()
             calc_prob_lib.calc_prob_forward(p, s)
 
     side = torch.cuda.Stream()
@@ -338,7 +344,17 @@ def batch1_graph(G, dev):
     us = event_time_us(graph.replay, 20, 3) / reps
     nbytes = BYTES_CAM_FWD + BYTES_CP_FWD
     res = dict(us_per_image=us, GBs=nbytes / us / 1e3, frac=nbytes / us / 1e3 / HBM_PEAK_GBS,
-               launches_per_image=2, note="HIP-graph replay of 20x(cam_bp fwd [cam_brick_kernel] + calc_prob fwd), batch 1")
+               launches_per_image=2, note="HIP-graph replay of 20x(cam_bp fwd [cam_brick_kernel, camera by value] + "
+                                          "calc_prob fwd), batch 1, one stream")
+    try:
+        gt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gt):
+            body(lambda: cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt))
+        ust = event_time_us(gt.replay, 20, 3) / reps
+        res["tensor_camera"] = dict(us_per_image=ust, frac=nbytes / ust / 1e3 / HBM_PEAK_GBS,
+                                    note="same, fl / cam_dist read from [1,1] tensors")
+    except Exception as e:      # pragma: no cover
+        res["tensor_camera"] = dict(error=str(e)[:200])
     try:
         # The same 20 + 20 calls as TWO request streams inside one graph: cam_bp's latency-bound kernel of image
         # i+1 run beside calc_prob's bandwidth-bound kernel of image i (a server pipelining consecutive batch-1
@@ -352,7 +368,7 @@ def batch1_graph(G, dev):
                 for _ in range(reps):
                     calc_prob_lib.calc_prob_forward(p, s)
             for _ in range(reps):
-                cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt)
+                cam_fwd()
             main.wait_stream(s2)
         us2 = event_time_us(g2.replay, 20, 3) / reps
         res["two_streams"] = dict(us_per_image=us2, GBs=nbytes / us2 / 1e3, frac=nbytes / us2 / 1e3 / HBM_PEAK_GBS,

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgenre_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 _MAX_DIMS = 5
 _F32, _I32 = 0, 1
 
@@ -40,10 +40,12 @@ def _load():
     T, V = C.POINTER(GenreTensor), C.c_void_p
     scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float],
                "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float, C.c_int],
-               "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float]}
+               "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float],
+               "genre_back_projection_forward_const": [C.c_float, C.c_float, C.c_int]}
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
                         ("genre_get_surface_mask", 5), ("genre_back_projection_forward_shifted", 5),
-                        ("genre_back_projection_backward_shifted", 8), ("genre_spherical_back_proj_forward", 4),
+                        ("genre_back_projection_backward_shifted", 8), ("genre_back_projection_forward_const", 3),
+                        ("genre_spherical_back_proj_forward", 4),
                         ("genre_spherical_back_proj_backward", 5), ("genre_spherical_back_proj_forward_shifted", 4),
                         ("genre_spherical_back_proj_backward_shifted", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
@@ -127,6 +129,12 @@ class _CamBpLib:
     @staticmethod
     def back_projection_forward(depth, camdist, fl, voxel, cnt):
         return _call("genre_back_projection_forward", depth, camdist, fl, voxel, cnt)
+
+    @staticmethod
+    def back_projection_forward_const(depth, camdist, fl, voxel, cnt, shifted=False):
+        """extension: camdist / fl are Python floats (one camera for every image), passed by value"""
+        return _call("genre_back_projection_forward_const", depth, voxel, cnt,
+                     scalars=(C.c_float(camdist), C.c_float(fl), C.c_int(1 if shifted else 0)))
 
     @staticmethod
     def back_projection_backward(depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl):

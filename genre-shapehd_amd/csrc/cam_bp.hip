@@ -577,9 +577,14 @@ __device__ __forceinline__ void divmod_px(int t, int d, float inv_d, int &r, int
     else if (q >= d) { r++; q -= d; }
 }
 
+// BYVAL: focal length and camera distance are kernel arguments (one value for every image -- what
+// Camera_back_projection_layer fills its [N,1] tensors with, camera_backprojection_module.py:16-21) instead of two loads
+// in front of the footprint: one dependent memory round trip less before a workgroup knows its pixels.
+template <bool BYVAL>
 __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, View2 camdist, View2 fl, View5 vox,
                                                             View5 cnt, float prefill, float bias, float post_scale,
-                                                            float post_bias, float fill_val, int vec_ok)
+                                                            float post_bias, float fill_val, int vec_ok, float fl_val,
+                                                            float cd_val)
 {
     __shared__ double s_sum[kQVox];
     __shared__ unsigned s_cnt[kQVox];
@@ -588,8 +593,8 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
     const int nbz = (D.Z + kQZ - 1) / kQZ, nby = (D.Y + kQY - 1) / kQY;
     const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
     const int img = blockIdx.y, n = img / D.NC, c = img % D.NC;
-    const float f = fl.p[n * fl.s0 + c * fl.s1];
-    const float cam_dist = camdist.p[n * camdist.s0 + c * camdist.s1];
+    const float f = BYVAL ? fl_val : fl.p[n * fl.s0 + c * fl.s1];
+    const float cam_dist = BYVAL ? cd_val : camdist.p[n * camdist.s0 + c * camdist.s1];
     const float *dimg = depth.p + n * depth.s0 + c * depth.s1;
     float *vimg = vox.p + n * vox.s0 + c * vox.s1, *cimg = cnt.p + n * cnt.s0 + c * cnt.s1;
     const int x0 = bx * kQX, y0 = by * kQY, z0 = bz * kQZ;
@@ -668,9 +673,8 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
     // ---- (c) normalise (:291-305) and write the brick; a dead brick streams the fill values ---------------------
     auto value = [&](int l, float &k) {
         k = (float)s_cnt[l];
-        // (sum - bias) / k  (:304) as a multiplication by 1/k: exact for the voxels hit once (and 2, 4, ... times), within an
-        // ulp of the division otherwise -- the summation order of such voxels is already free
-        return k > 0.0f ? post_bias + post_scale * (((prefill + (float)s_sum[l]) - bias) * __frcp_rn(k)) : fill_val;
+        // (sum - bias) / k  (:304): a correctly rounded division, as the reference's -- once per voxel, not on the hot path
+        return k > 0.0f ? post_bias + post_scale * (((prefill + (float)s_sum[l]) - bias) / k) : fill_val;
     };
     if (vec_ok && z1 - z0 == kQZ) {
         const int z4 = (threadIdx.x & (kQZ / 4 - 1)) * 4;
@@ -985,7 +989,7 @@ inline CamMode cam_mode()
 template <bool SPH>
 int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *camdist, const genre_tensor *fl,
                  const genre_tensor *grid, const genre_tensor *voxel, const genre_tensor *cnt, void *stream,
-                 bool shifted = false)
+                 bool shifted = false, const float *byval = nullptr)
 {
     Dims D{};
     if (!check_image(op, depth, D)) return 0;
@@ -996,7 +1000,7 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
                           grid->size[2] == D.H && grid->size[3] == D.W && grid->size[4] == 3,
                       "%s: grid must be a 5-D fp32 tensor [%d,%d,%d,%d,3]", op, D.N, D.NC, D.H, D.W);
         vgrid = view5(grid);
-    } else {
+    } else if (!byval) {
         if (!check_scalar(op, "camdist", camdist, D) || !check_scalar(op, "fl", fl, D)) return 0;
         vcd = view2(camdist); vfl = view2(fl);
     }
@@ -1031,6 +1035,12 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
     const int vec_ok = rows_aligned(voxel) && rows_aligned(cnt);
     CamMode mode = SPH ? kScatter : cam_mode();
     if (mode == kAuto) mode = (vec_ok && D.N * D.NC <= 65535) ? kBrick : kScatter;
+    if (byval) {
+        GENRE_REQUIRE(!SPH && vec_ok && D.N * D.NC <= 65535 && (mode == kBrick || cam_mode() == kAuto),
+                      "%s: the by-value entry runs the single-launch brick kernel only (dense NCXYZ outputs with unit "
+                      "z stride, 16-byte aligned rows, Z %% 4 == 0); pass fl / camdist tensors otherwise", op);
+        mode = kBrick;
+    }
     if (mode != kScatter) {
         const int64_t nvox = (int64_t)D.X * D.Y * D.Z;
         if (nvox == 0 || D.N * D.NC == 0) return 1;
@@ -1040,9 +1050,13 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         if (mode == kBrick) {
             const int64_t bricks = (int64_t)((D.X + kQX - 1) / kQX) * ((D.Y + kQY - 1) / kQY) * ((D.Z + kQZ - 1) / kQZ);
             GENRE_REQUIRE(bricks < ((int64_t)1 << 31), "%s: volume too large", op);
-            cam_brick_kernel<<<dim3((unsigned)bricks, D.N * D.NC), kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel),
-                                                                                   view5(cnt), prefill, bias, post_scale,
-                                                                                   post_bias, fill_val, vec_ok);
+            const dim3 bgrid((unsigned)bricks, D.N * D.NC);
+            if (byval)
+                cam_brick_kernel<true><<<bgrid, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias,
+                                                                 post_scale, post_bias, fill_val, vec_ok, byval[0], byval[1]);
+            else
+                cam_brick_kernel<false><<<bgrid, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias,
+                                                                  post_scale, post_bias, fill_val, vec_ok, 0.0f, 0.0f);
             GENRE_LAUNCH_CHECK("projection forward (bricks)");
             return 1;
         }
@@ -1143,6 +1157,15 @@ extern "C" int genre_back_projection_forward_shifted(const genre_tensor *depth, 
                                                      const genre_tensor *cnt, void *stream)
 {
     return forward_impl<false>("back_projection_forward_shifted", depth, camdist, fl, nullptr, voxel, cnt, stream, true);
+}
+
+extern "C" int genre_back_projection_forward_const(const genre_tensor *depth, const genre_tensor *voxel,
+                                                   const genre_tensor *cnt, float camdist, float fl, int shifted,
+                                                   void *stream)
+{
+    const float byval[2] = {fl, camdist};
+    return forward_impl<false>("back_projection_forward_const", depth, nullptr, nullptr, nullptr, voxel, cnt, stream,
+                               shifted != 0, byval);
 }
 
 extern "C" int genre_back_projection_backward_shifted(const genre_tensor *depth, const genre_tensor *fl,

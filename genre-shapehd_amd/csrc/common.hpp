@@ -1,6 +1,7 @@
 // common.hpp -- shared host/device helpers for libgenre_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -97,5 +98,21 @@ constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kCUs = 256;          // MI355X
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Kernels that take more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which is a
+// property of the kernel ON ONE DEVICE.  `done` (one static per kernel instantiation, at the launch site) remembers
+// the devices that have it, one bit each; devices >= 64 and failures are never cached (the call is cheap and a failure
+// may be transient), so a second GPU in the same process gets its own attribute and a first failure is not permanent.
+inline int reserve_lds(const char *op, const void *kernel, size_t bytes, std::atomic<uint64_t> &done)
+{
+    int dev = 0;
+    GENRE_REQUIRE(hipGetDevice(&dev) == hipSuccess, "%s: hipGetDevice failed", op);
+    const uint64_t bit = (dev >= 0 && dev < 64) ? (uint64_t)1 << dev : 0;
+    if (bit && (done.load(std::memory_order_relaxed) & bit)) return 1;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    GENRE_REQUIRE(e == hipSuccess, "%s: cannot reserve %zu bytes of LDS on device %d (%s)", op, bytes, dev, hipGetErrorString(e));
+    if (bit) done.fetch_or(bit, std::memory_order_relaxed);
+    return 1;
+}
 
 }  // namespace genre

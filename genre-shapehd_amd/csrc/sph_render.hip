@@ -528,10 +528,8 @@ int launch_sample_group(const char *op, const RenderDims &D, const genre_tensor 
                         int rows, int imgs, hipStream_t st)
 {
     constexpr size_t lds = (size_t)G * kTile3 * sizeof(float);
-    static const hipError_t attr =
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&render_sample_brick_group_kernel<G, NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    GENRE_REQUIRE(attr == hipSuccess, "%s: cannot reserve %zu bytes of LDS", op, lds);
+    static std::atomic<uint64_t> done{0};
+    if (!reserve_lds(op, reinterpret_cast<const void *>(&render_sample_brick_group_kernel<G, NT>), lds, done)) return 0;
     render_sample_brick_group_kernel<G, NT><<<dim3(rows, (imgs + G - 1) / G), NT, lds, st>>>(
         D, view5(vox), (const double *)dirs->data, (const int *)fwd_table->data, (const int *)fwd_chunks->data,
         (float *)v_scratch->data, imgs);

@@ -49,6 +49,7 @@ constexpr int kMaxSeg = 16;
 constexpr int kRec = 12;                                 // words per sample record
 constexpr int kThreads = 512;
 constexpr int kRecL = 16;                                // words per record slot in LDS (sampler and scatter kernel)
+constexpr int kRayRegs = 31;                             // segments of a ray the per-ray backward pass keeps in registers
 
 struct BmDims {
     int N, X, Y, Z, R, pad;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void bm_combine_fwd_kernel(BmDims D, const flo
 
 // ---- backward: per-ray pass ------------------------------------------------------------------------------
 // tr [group][segment][2][32] <- (g * T at the segment's start, R behind its end)
-__global__ __launch_bounds__(256) void bm_combine_bwd_kernel(BmDims D, const float *__restrict__ ps,
+__global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const float *__restrict__ ps,
                                                              const int *__restrict__ ray_ptr,
                                                              const int *__restrict__ ray_seg,
                                                              const double2 *__restrict__ ray_pre, View4 gout,
@@ -321,6 +322,43 @@ __global__ __launch_bounds__(256) void bm_combine_bwd_kernel(BmDims D, const flo
     }
     const int j0 = ray_ptr[q], j1 = ray_ptr[q + 1];
     const size_t gb = (size_t)g * D.nseg * 2 * kImgs + l;
+    if (j1 - j0 <= kRayRegs && (int64_t)D.nseg * (2 * kImgs * 4) < ((int64_t)1 << 31)) {
+        // The usual case (<= 32 segments per ray; 19 on average at 128^3): ALL of the ray's (P, S) lines are requested at
+        // once -- the kernel is three dependent round trips (ray_ptr -> segment ids -> lines) instead of ten -- and both
+        // chains run from registers: g T at every segment's start (prefix products), R behind its end (suffix recursion).
+        // Buffer addressing (wave-uniform descriptor of this group's slice + a 32-bit byte offset per line): one
+        // register per line address instead of two.
+        const int cnt = j1 - j0;
+        const int myid = l < cnt ? ray_seg[j0 + l] : 0;
+        const unsigned bytes = (unsigned)D.nseg * (2 * kImgs * 4);
+        const auto r_ps = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ps) + (size_t)g * D.nseg * 2 * kImgs, 0, bytes, 0x00020000);
+        const auto r_tr = __builtin_amdgcn_make_buffer_rsrc(tr + (size_t)g * D.nseg * 2 * kImgs, 0, bytes, 0x00020000);
+        int o[kRayRegs];
+        float P[kRayRegs], Sg[kRayRegs];
+#pragma unroll
+        for (int u = 0; u < kRayRegs; u++) {
+            o[u] = (__shfl(myid, u < cnt ? u : 0, 32) * (2 * kImgs) + l) * 4;   // (an index beyond the ray re-reads its first line)
+            P[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_ps, o[u], 0, 0));
+            Sg[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_ps, o[u] + kImgs * 4, 0, 0));
+        }
+        double T = ray_pre[q].x;
+#pragma unroll
+        for (int u = 0; u < kRayRegs; u++) {
+            if (u < cnt) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)((double)gv * T)), r_tr, o[u], 0, 0);
+                T *= (double)P[u];
+            }
+        }
+        double Rr = 1.0;                                                  // behind the last sample: prod(1-p) * 1
+#pragma unroll
+        for (int u = kRayRegs - 1; u >= 0; u--) {
+            if (u < cnt) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)Rr), r_tr, o[u] + kImgs * 4, 0, 0);
+                Rr = (double)Sg[u] + (double)P[u] * Rr;
+            }
+        }
+        return;
+    }
     double T = ray_pre[q].x;
     for (int jb = j0; jb < j1; jb += 32) {                               // forward: g T at every segment's start
         const int cnt = (j1 - jb < 32) ? j1 - jb : 32;
@@ -655,14 +693,6 @@ int check_rows(const char *op, const BmDims &D, const genre_tensor *rows, int bx
     return 1;
 }
 
-template <typename K>
-int reserve_lds(const char *op, K kernel, size_t bytes)
-{
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    GENRE_REQUIRE(e == hipSuccess, "%s: cannot reserve %zu bytes of LDS", op, bytes);
-    return 1;
-}
-
 }  // namespace
 }  // namespace genre
 
@@ -701,8 +731,8 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
     const dim3 grid((unsigned)fwd_rows->size[0], (unsigned)D.groups);
 #define GENRE_BM_SAMPLE_NT(PSV, SV, NTV)                                                                                  \
     do {                                                                                                                  \
-        static const int ok_ = reserve_lds(op, &bm_sample_kernel<PSV, SV, NTV>, lds);                                     \
-        if (!ok_) return 0;                                                                                               \
+        static std::atomic<uint64_t> done_{0};                                                                            \
+        if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_sample_kernel<PSV, SV, NTV>), lds, done_)) return 0;      \
         bm_sample_kernel<PSV, SV, NTV><<<grid, NTV, lds, st>>>(                                                           \
             D, (const float *)vox->data, (const int4 *)segs->data, (const int *)rec_f->data, (const int4 *)fwd_rows->data, \
             (float *)ps_scratch->data, save ? (float *)p_stash->data : nullptr,                                           \
@@ -771,8 +801,8 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
             GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");                                                \
         }                                                                                                                 \
         constexpr size_t lds = (size_t)PXV * 64 * kImgs * 8 + (size_t)(NTV / 64) * kMaxSeg * kRecL * 4 + (size_t)PXV * 64 * 4; \
-        static const int ok_ = reserve_lds(op, &bm_scatter_kernel<PSV, PXV, 8, 8, NTV>, lds);                             \
-        if (!ok_) return 0;                                                                                               \
+        static std::atomic<uint64_t> done_{0};                                                                            \
+        if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_scatter_kernel<PSV, PXV, 8, 8, NTV>), lds, done_)) return 0; \
         bm_scatter_kernel<PSV, PXV, 8, 8, NTV><<<grid, NTV, lds, st>>>(                                                   \
             D, (const int4 *)ent->data, (const int *)rec_b->data, (const int4 *)bwd_rows->data,                           \
             (const float *)depth_weight->data, (const float *)tr_scratch->data, (const float *)p_stash->data,             \

@@ -7,6 +7,8 @@ op writes every element, so the reference's two ``zero_()`` passes and the
 ``+ 1/res`` pass, :22-24, disappear), and ``cnt`` is kept both on ``ctx`` (as the
 reference does, :28) and in ``saved_tensors``.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -52,7 +54,10 @@ class ShiftedCameraBackProjection(Function):
     values, one full-volume elementwise pass less in each direction.  Used by the layer."""
 
     @staticmethod
-    def forward(ctx, depth_t, fl, cam_dist, res=128, batch_minor=False):
+    def forward(ctx, depth_t, fl, cam_dist, res=128, batch_minor=False, const=None):
+        """const = (fl, cam_dist) as Python floats when the two tensors are filled with those constants (the layer's
+        default call, camera_backprojection_module.py:16-21): the forward then takes the by-value entry point (no
+        loads of the camera in front of the brick screen); the tensors are still what the backward reads"""
         assert depth_t.dim() == 4
         n, nc = depth_t.shape[0], depth_t.shape[1]
         assert fl.dim() == 2 and tuple(fl.shape) == (n, nc)
@@ -67,7 +72,11 @@ class ShiftedCameraBackProjection(Function):
         else:
             out = torch.empty((n, nc, res, res, res), dtype=depth_t.dtype, device=depth_t.device)
             cnt = torch.empty_like(out)
-        cam_bp_lib.back_projection_forward_shifted(depth_t, cam_dist, fl, out, cnt)
+        if (const is not None and not (batch_minor and nc == 1) and n * nc <= 65535
+                and os.environ.get("GENRE_CAMBP_MODE", "") in ("", "auto", "brick")):
+            cam_bp_lib.back_projection_forward_const(depth_t, const[1], const[0], out, cnt, shifted=True)
+        else:
+            cam_bp_lib.back_projection_forward_shifted(depth_t, cam_dist, fl, out, cnt)
         ctx.save_for_backward(depth_t, fl, cam_dist, cnt)
         ctx.depth_shape = depth_t.shape
         return out
@@ -82,4 +91,4 @@ class ShiftedCameraBackProjection(Function):
         grad_camdist = torch.empty_like(grad_fl)
         cam_bp_lib.back_projection_backward_shifted(depth_t, fl, cam_dist, cnt, grad_output,
                                                     grad_depth, grad_camdist, grad_fl)
-        return grad_depth, grad_fl, grad_camdist, None, None
+        return grad_depth, grad_fl, grad_camdist, None, None, None

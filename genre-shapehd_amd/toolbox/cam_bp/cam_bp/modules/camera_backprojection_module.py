@@ -40,13 +40,14 @@ class Camera_back_projection_layer(nn.Module):
 
     def forward(self, depth_t, fl=418.3, cam_dist=2.2, shift=True):
         n = depth_t.size(0)
+        const = (fl, cam_dist) if type(fl) == float and type(cam_dist) == float and depth_t.size(1) == 1 else None
         if type(fl) == float:
             fl = self._const(fl, n, depth_t.device)
         if type(cam_dist) == float:
             cam_dist = self._const(cam_dist, n, depth_t.device)
         if shift:       # 1 - res*tdf evaluated inside the native op (same values as shift_tdf(df))
             bm = self.batch_minor and n >= 16 and depth_t.size(1) == 1
-            return ShiftedCameraBackProjection.apply(depth_t, fl, cam_dist, self.res, bm)
+            return ShiftedCameraBackProjection.apply(depth_t, fl, cam_dist, self.res, bm, const)
         return CameraBackProjection.apply(depth_t, fl, cam_dist, self.res)
 
     @staticmethod

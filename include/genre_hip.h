@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GENRE_ABI_VERSION 1
+#define GENRE_ABI_VERSION 2
 #define GENRE_MAX_DIMS 5
 
 enum { GENRE_F32 = 0, GENRE_I32 = 1 };
@@ -98,6 +98,17 @@ int genre_back_projection_backward_shifted(const genre_tensor *depth, const genr
                                            const genre_tensor *grad_in, const genre_tensor *grad_depth,
                                            const genre_tensor *grad_camdist, const genre_tensor *grad_fl,
                                            void *stream);
+
+/* Extension: the camera forward with ONE focal length and ONE camera distance for every image, passed by value --
+ * exactly what Camera_back_projection_layer fills its [N,NC] tensors with when it is called with Python floats
+ * (camera_backprojection_module.py:16-21).  The kernel then has the camera in its arguments instead of behind two
+ * loads (one dependent memory round trip less in front of the brick screen; batch-1 latency).  shifted != 0: output
+ * as genre_back_projection_forward_shifted.  Single-launch brick kernel only: dense NCXYZ outputs (unit z stride,
+ * 16-byte aligned rows, Z % 4 == 0); other layouts return 0 -- pass tensors there.  Results are identical to the
+ * tensor entry points called with constant-filled tensors. */
+int genre_back_projection_forward_const(const genre_tensor *depth, const genre_tensor *voxel,
+                                        const genre_tensor *cnt, float camdist, float fl, int shifted,
+                                        void *stream);
 
 /* Replaces get_surface_mask (back_projection.c:30-38 -> :840-891, kernel
  * :310-358).  mask [N,NC,X,Y,Z] := 1, except 0 for empty voxels (cnt <= 1e-5)

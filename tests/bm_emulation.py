@@ -130,3 +130,78 @@ def _flush(grad, written, tile, brick, dims, nby, nbz, mask, pre_scale):
         val = np.where(mask[ox:ox + BX, oy:oy + BY, oz:oz + BZ], val * pre_scale, 0.0)
     view[...] = val
     written[ox:ox + BX, oy:oy + BY, oz:oz + BZ] += 1
+
+
+def backward_gather(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
+    """the gather form of the backward (bm_gather_kernel): per chunk the listed samples' dL/dp are parked in a sample
+    buffer, then every voxel of the brick sums its list of (sample line, weight) contributions.  g [RR] -> grad_vox"""
+    X, Y, Z = shape
+    BX, BY, BZ = mod.GATHER_BRICK
+    nby, nbz = -(-Y // BY), -(-Z // BZ)
+    segs = t["segs"]
+    TR = np.zeros((segs.shape[0], 2))
+    rr = t["ray_ptr"].shape[0] - 1
+    for q in range(rr):
+        ids = t["ray_seg"][t["ray_ptr"][q]:t["ray_ptr"][q + 1]]
+        T = t["ray_pre"][q][0]
+        for s in ids:
+            TR[s, 0] = g[q] * T
+            T *= PS[s, 0]
+        Rr = 1.0
+        for s in ids[::-1]:
+            TR[s, 1] = Rr
+            Rr = PS[s, 1] + PS[s, 0] * Rr
+    grad = np.full(shape, np.nan)
+    written = np.zeros(shape, np.int32)
+    blob = t["g_blob"]
+    vi = np.arange(BX * BY * BZ)
+    lx, ly, lz = vi // (BY * BZ), (vi // BZ) % BY, vi % BZ
+    hidx = ((lx * 2 + (ly >> 2)) * 2 + (lz & 1)) * 16 + (ly & 3) * 4 + (lz >> 1)      # header slot of voxel vi
+    acc_shared = {}
+    for brick, c0, c1, shared in t["g_rows"]:
+        if shared == mod.SKIP:
+            continue
+        tile = np.zeros(BX * BY * BZ)
+        for c in range(c0, c1):
+            e0, e1, b0, nw = t["g_chunks"][c]
+            sbuf = np.full(mod.GATHER_CH, np.nan)                       # a line that no entry fills must never be read
+            Ls = [(t["g_ent"][e][2] >> 12) & 63 for e in range(e0, e1)]
+            assert Ls == sorted(Ls, reverse=True), "entries of a chunk: longest first"
+            for e in range(e0, e1):
+                s, slot0, pk, ls0 = t["g_ent"][e]
+                i0, i1, L, k0 = pk & 63, (pk >> 6) & 63, (pk >> 12) & 63, (pk >> 18) & 255
+                assert (segs[s][1], segs[s][2], segs[s][3]) == (k0, L, slot0)
+                p = stash[slot0:slot0 + L]
+                Tg, Rr = TR[s]
+                cT = np.zeros(L)
+                for i in range(L):
+                    cT[i] = Tg
+                    Tg *= 1.0 - abs(p[i])
+                for i in range(L - 1, -1, -1):
+                    d = float(dw[k0 + i]) - Rr
+                    Rr = Rr + abs(p[i]) * d
+                    if i0 <= i < i1:
+                        assert np.isnan(sbuf[ls0 + i - i0]), "two samples share a line of the sample buffer"
+                        sbuf[ls0 + i - i0] = cT[i] * d if p[i] > 0 else 0.0
+            hdr = blob[b0:b0 + 256]
+            lists = blob[b0 + 256:b0 + nw].reshape(-1, 2)
+            assert nw == 256 + 2 * int((hdr >> 16).sum()) and (hdr >> 16).sum() <= mod.GATHER_LCAP
+            for v in range(BX * BY * BZ):
+                h, hp = hdr[hidx[v]], hdr[hidx[v ^ 1]]
+                st, n = h & 0xFFFF, h >> 16
+                assert n == hp >> 16 and n % 2 == 0 and st % 2 == 0       # the wave's two lists: one even length
+                sub = lists[st:st + n]
+                off, w = sub[:, 0], sub[:, 1].view(np.float32).astype(np.float64)
+                assert (off % 128 == 0).all()
+                vals = sbuf[off // 128]
+                vals = np.where(w == 0.0, 0.0, vals)                    # padding reads line 0, weight 0
+                assert not np.isnan(vals).any()
+                tile[v] += (w * vals).sum()
+        if shared:
+            acc_shared[brick] = acc_shared.get(brick, 0) + tile
+            continue
+        _flush(grad, written, tile, brick, (BX, BY, BZ), nby, nbz, mask, pre_scale)
+    for brick, tile in acc_shared.items():
+        _flush(grad, written, tile, brick, (BX, BY, BZ), nby, nbz, mask, pre_scale)
+    assert (written == 1).all(), "every voxel must be written exactly once"
+    return grad

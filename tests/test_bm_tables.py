@@ -29,11 +29,16 @@ def _field(res, seed):
 
 
 @pytest.mark.parametrize("res,sph,zr,pre_scale,split,pull", [(16, 8, 32, 0.0, None, (8, 8, 8)), (20, 10, 48, 0.0, 64, (4, 8, 8)),
-                                                              (13, 6, 24, 3.0, 40, (8, 8, 8))])
+                                                              (13, 6, 24, 3.0, 40, (8, 8, 8)), (16, 8, 32, 2.5, None, (4, 8, 8)),
+                                                              (21, 12, 40, 0.0, 150, (4, 8, 8))])
 def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, pull, oracle, monkeypatch):
     from oracle.torch_oracle import RenderSphericalCPU, unit_dirs
     m = _mod()
     monkeypatch.setattr(m, "ROW_ORDER", "xcd" if res == 20 else "heaviest")      # both row orders are exercised
+    if res == 21:           # small buffers: several chunks per row, chunks halved because of their lists
+        monkeypatch.setattr(m, "GATHER_CH", 40)
+        monkeypatch.setattr(m, "GATHER_RAW", 200)
+        monkeypatch.setattr(m, "GATHER_LCAP", 260)
     dw = np.linspace(0, 1, zr).astype(np.float32)
     dw = torch.linspace(0, 1, zr).numpy()
     kw = dict(pull=pull) if split is None else dict(split_f=split, split_b=split, pull=pull)
@@ -51,6 +56,9 @@ def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, pu
     grad = E.backward(m, t, vox.shape, PS, stash, mask, g, dw, pre_scale)
     gr = vt.grad[0, 0].numpy()
     assert (np.abs(grad - gr) / np.maximum(1, np.abs(gr))).max() <= 2e-5
+    if tuple(pull) == m.GATHER_BRICK:                                       # the gather form of the backward: same sums
+        grad_g = E.backward_gather(m, t, vox.shape, PS, stash, mask, g, dw, pre_scale)
+        assert (np.abs(grad_g - grad) / np.maximum(1, np.abs(grad))).max() <= 1e-12
     # structure: segments partition the in-volume samples, rows cover all bricks
     assert t["segs"][:, 2].sum() + m.SLOT_PAD == t["rec_f"].shape[0] and t["segs"][:, 2].max() <= m.MAXSEG
     assert not t["rec_f"][-m.SLOT_PAD:].any()

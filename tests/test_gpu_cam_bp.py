@@ -306,3 +306,43 @@ def test_point_exactly_on_a_voxel_centre(genre, oracle, dev):
         want = ((-tdf_o + 1.0 / res) * res * np.clip(cnt_o, 0, 1)) if shifted else tdf_o
         assert np.array_equal(out.cpu().numpy(), want.astype(np.float32))
         assert out[0, 0, 64, 64, 64].item() == (1.0 if shifted else 0.0)
+
+
+def test_by_value_camera_entry_equals_the_tensor_entry(genre, oracle, dev):
+    """genre_back_projection_forward_const (one focal length / camera distance for every image, passed by value -- what
+    Camera_back_projection_layer fills its tensors with, camera_backprojection_module.py:16-21): bit-for-bit the
+    tensor entry's output (plain and shifted), parity with the oracle, and the layer takes it when called with floats"""
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    fl1, cd1 = inputs.cam_params(1)
+    cases = [(d, fl1, cd1, 128) for d in depth_cases().values()] + _odd_cases() + [(inputs.batch_depth(5), None, None, 128)]
+    for d, fl, cd, res in cases:
+        n = d.shape[0]
+        flv, cdv = (418.3, 2.2) if fl is None else (float(fl[0, 0]), float(cd[0, 0]))
+        flt = torch.full((n, 1), flv, device=dev)
+        cdt = torch.full((n, 1), cdv, device=dev)
+        for shifted in (False, True):
+            a, ca = torch.empty((n, 1, res, res, res), device=dev), torch.empty((n, 1, res, res, res), device=dev)
+            b, cb = torch.empty_like(a), torch.empty_like(a)
+            (cam_bp_lib.back_projection_forward_shifted if shifted else cam_bp_lib.back_projection_forward)(t(d, dev), cdt, flt, a, ca)
+            cam_bp_lib.back_projection_forward_const(t(d, dev), cdv, flv, b, cb, shifted=shifted)
+            assert torch.equal(a, b) and torch.equal(ca, cb), (d.shape, res, shifted)
+        tdf_o, cnt_o = oracle.back_projection_forward(d, np.full((n, 1), cdv, np.float32), np.full((n, 1), flv, np.float32), res)
+        assert np.array_equal(cb.cpu().numpy(), cnt_o)
+        assert np.abs(b.cpu().numpy() - (1 - res * tdf_o)).max() <= res * TOL
+    # layouts the brick kernel cannot take are refused, not silently mishandled
+    d = t(inputs.batch_depth(16), dev)
+    from genre_shapehd_amd.toolbox import _fused_render
+    bm = _fused_render.empty_batch_minor((16, 1, 128, 128, 128), torch.float32, dev)
+    with pytest.raises(RuntimeError, match="by-value"):
+        cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, bm, torch.empty_like(bm))
+    # the layer: floats -> by-value entry, same values and gradients as with tensors
+    layer = genre.Camera_back_projection_layer().to(dev)
+    d1 = t(inputs.sphere_depth(noise_seed=2), dev)
+    x1, x2 = d1.clone().requires_grad_(True), d1.clone().requires_grad_(True)
+    y1 = layer(x1)
+    y2 = layer(x2, torch.full((1, 1), 418.3, device=dev), torch.full((1, 1), 2.2, device=dev))
+    assert torch.equal(y1, y2)
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g)
+    assert torch.equal(x1.grad, x2.grad)
