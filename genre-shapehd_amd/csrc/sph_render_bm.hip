@@ -650,6 +650,168 @@ __global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scat
     }
 }
 
+// ---- backward, gather form -----------------------------------------------------------------------------------------
+// The adjoint of the trilinear interpolation is a sparse matrix product  grad_vox[v, :] = sum_s W[v, s] dLdp[s, :]  whose
+// dense dimension is the image index = the 32 lanes of a half-wave.  bm_scatter_kernel keeps dLdp in a register and the
+// voxel sums in LDS: one ds_add_f64 (8.7 LDS cycles per wave instruction on gfx950) per corner line plus the scalar-unit
+// ownership masks.  Here the voxel sums live in REGISTERS -- a half-wave owns 16 voxels of its 4 x 8 x 8 brick for the whole
+// row -- the dL/dp of the samples that touch the brick are parked in an LDS sample buffer (one plain ds_write per sample),
+// and every contribution costs one ds_read_b32 (2 LDS cycles) and one fused multiply-add; which sample adds to which voxel
+// with which weight is a LIST built on the host (toolbox/_bm_tables.py: _gather_tables), read with one 16-byte LDS read per
+// two contributions.  No atomics, no ownership logic, no tile to clear or flush.
+//   row    = a pull brick's chunks (or a share of them: such rows add onto pre-zeroed voxels)
+//   chunk  = <= kGCH listed samples (whole entries) + the voxel lists over them ("blob"), staged in LDS
+//   phase A  a HALF-wave per entry (32 lanes = images): the segment's saved samples p and its (g T, R) are loaded -- the
+//            next round's loads are in flight during this round's scans --, forward scan g T_k, reverse scan R_k,
+//            dL/dp_k = g T_k (w_k - R_{k+1}) of the listed samples written to their lines of the sample buffer.  The two
+//            entries of a wave are neighbours in a longest-first order, so the scans run to the longer one's length.
+//   phase B  half-wave hw, voxel v: the list (start, n) from the blob's header; both half-waves of a wave hold z-neighbours,
+//            whose lists are padded to one even length -- the loop count is wave-uniform.
+constexpr int kGThreads = 512, kGHW = kGThreads / 32, kGVox = 16;
+constexpr int kGCH = 384, kGLCAP = 2816;                   // toolbox/_bm_tables.py: GATHER_CH, GATHER_LCAP
+constexpr int kGBlobWords = 256 + 2 * kGLCAP, kGDwWords = 256 + kMaxSeg;
+constexpr size_t kGLds = (size_t)(kGBlobWords + kGDwWords) * 4 + (size_t)kGCH * kImgs * 4;
+
+struct GEntry { float p[kMaxSeg]; float T, R; };
+
+template <bool PS>
+__global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const int4 *__restrict__ ents, const int4 *__restrict__ chunks,
+                                                                 const int *__restrict__ blob, const int4 *__restrict__ rows,
+                                                                 const float *__restrict__ dw, const float *__restrict__ tr,
+                                                                 const float *__restrict__ stash, const unsigned *__restrict__ mask,
+                                                                 float *__restrict__ gvox)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds_g[];
+    int *bl = lds_g;                                                    // [256 headers][2 * kGLCAP]
+    float *dwl = reinterpret_cast<float *>(lds_g + kGBlobWords);       // depth weights (+ kMaxSeg: read past a short segment)
+    float *sbuf = dwl + kGDwWords;                                      // [kGCH][32]  (behind >= 16 lines of other data: the
+                                                                        //  per-entry base below, (ls0 - i0) lines, is never negative)
+    const int4 row = rows[blockIdx.x];
+    if (row.w == 2) return;
+    const int g = blockIdx.y, n0 = g * kImgs;
+    int ox, oy, oz;
+    brick_origin<4, 8, 8>(D, row.x, ox, oy, oz);
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), hw = wave * 2 + half;
+    for (int i = tid; i < kGDwWords; i += kGThreads) dwl[i] = dw[min(i, D.ZR - 1)];
+    const float *stash_g = stash + (size_t)g * D.nslot * kImgs + l;
+    const float *tr_g = tr + (size_t)g * D.nseg * 2 * kImgs + l;
+    float acc[kGVox];
+#pragma unroll
+    for (int v = 0; v < kGVox; v++) acc[v] = 0.f;
+    for (int c = row.y; c < row.z; c++) {
+        const int4 ck = chunks[c];                                     // (entry begin, entry end, blob begin, blob words)
+        if (c > row.y) __syncthreads();                                // the previous chunk's lists and samples are done with
+        for (int i = tid * 4; i < ck.w; i += kGThreads * 4)
+            *reinterpret_cast<int4 *>(bl + i) = *reinterpret_cast<const int4 *>(blob + (size_t)ck.z + i);
+        // ---- phase A ----
+        const int rounds = (ck.y - ck.x + kGHW - 1) / kGHW;
+        auto header = [&](int r) {                                     // the entry of this half-wave in round r (pk = 0: none)
+            const int e = ck.x + r * kGHW + hw;
+            int4 h = ents[min(e, ck.y - 1)];
+            if (e >= ck.y) h.z = 0;
+            return h;
+        };
+        auto fetch = [&](const int4 h, GEntry &o) {                    // 18 loads, unconditionally (exact waits)
+            const float *st = stash_g + (size_t)h.y * kImgs;
+#pragma unroll
+            for (int j = 0; j < kMaxSeg; j++) o.p[j] = st[j * kImgs];
+            const float *tp = tr_g + (size_t)h.x * 2 * kImgs;
+            o.T = tp[0]; o.R = tp[kImgs];
+        };
+        auto process = [&](const int4 h, GEntry &e) {
+            const int pk = h.z;
+            const int i0 = pk & 63, n_l = ((pk >> 6) & 63) - i0, L = (pk >> 12) & 63, k0 = (pk >> 18) & 255;
+            const int Lmax = __builtin_amdgcn_readfirstlane(L);        // the wave's lower entry is the longer one
+            float ce[kMaxSeg];
+            float Tg = e.T, Rr = e.R;
+#pragma unroll
+            for (int j = 0; j < kMaxSeg; j++) {                         // forward: g T_k
+                if (j < Lmax) {
+                    e.p[j] = j < L ? e.p[j] : 0.f;                      // (the shorter entry of the wave: no-ops beyond its end)
+                    ce[j] = Tg;
+                    Tg = __builtin_fmaf(-fabsf(e.p[j]), Tg, Tg);
+                }
+            }
+            float *sb = sbuf + (h.w - i0) * kImgs + l;
+            const float *wl = dwl + k0;
+#pragma unroll
+            for (int j = kMaxSeg - 1; j >= 0; j--) {                    // reverse: R_k; dL/dp_k of the listed samples
+                if (j < Lmax) {
+                    const float d = wl[j] - Rr;
+                    Rr = __builtin_fmaf(fabsf(e.p[j]), d, Rr);
+                    const float dp = e.p[j] > 0.f ? ce[j] * d : 0.f;    // the clamp passes the gradient where the saved sample is > 0
+                    if ((unsigned)(j - i0) < (unsigned)n_l) sb[j * kImgs] = dp;
+                }
+            }
+        };
+        {
+            GEntry A, B;
+            int4 hA = header(0), hB = header(1);
+            fetch(hA, A);
+            for (int r = 0; r < rounds; r += 2) {
+                const int4 hC = header(r + 2);
+                fetch(hB, B);
+                process(hA, A);
+                if (r + 1 >= rounds) break;
+                const int4 hD = header(r + 3);
+                fetch(hC, A);
+                process(hB, B);
+                hA = hC; hB = hD;
+            }
+        }
+        __syncthreads();
+        // ---- phase B ----
+        int hd[kGVox];
+#pragma unroll
+        for (int v4 = 0; v4 < kGVox / 4; v4++) {
+            const int4 t4 = reinterpret_cast<const int4 *>(bl + hw * kGVox)[v4];
+            hd[4 * v4] = t4.x; hd[4 * v4 + 1] = t4.y; hd[4 * v4 + 2] = t4.z; hd[4 * v4 + 3] = t4.w;
+        }
+        const char *lists = reinterpret_cast<const char *>(bl + 256);
+        const char *sl = reinterpret_cast<const char *>(sbuf + l);
+#pragma unroll
+        for (int v = 0; v < kGVox; v++) {
+            const int n = __builtin_amdgcn_readfirstlane(hd[v] >> 16);  // one (even) length for the wave's two lists
+            if (n == 0) continue;
+            const char *q = lists + (hd[v] & 0xFFFF) * 8;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int i = 0;
+            for (; i + 4 <= n; i += 4) {
+                const int4 c01 = *reinterpret_cast<const int4 *>(q + i * 8);           // (offset, weight) x 2
+                const int4 c23 = *reinterpret_cast<const int4 *>(q + i * 8 + 16);
+                a0 = __builtin_fmaf(__int_as_float(c01.y), *reinterpret_cast<const float *>(sl + c01.x), a0);
+                a1 = __builtin_fmaf(__int_as_float(c01.w), *reinterpret_cast<const float *>(sl + c01.z), a1);
+                a2 = __builtin_fmaf(__int_as_float(c23.y), *reinterpret_cast<const float *>(sl + c23.x), a2);
+                a3 = __builtin_fmaf(__int_as_float(c23.w), *reinterpret_cast<const float *>(sl + c23.z), a3);
+            }
+            if (i < n) {
+                const int4 c01 = *reinterpret_cast<const int4 *>(q + i * 8);
+                a0 = __builtin_fmaf(__int_as_float(c01.y), *reinterpret_cast<const float *>(sl + c01.x), a0);
+                a1 = __builtin_fmaf(__int_as_float(c01.w), *reinterpret_cast<const float *>(sl + c01.z), a1);
+            }
+            acc[v] += (a0 + a1) + (a2 + a3);
+        }
+    }
+    // ---- every voxel of the brick once: a 128-byte line per half-wave and voxel ----
+    const int lx = wave >> 1;
+#pragma unroll
+    for (int v = 0; v < kGVox; v++) {
+        const int ly = (wave & 1) * 4 + (v >> 2), lz = 2 * (v & 3) + half;
+        const int x = ox + lx, y = oy + ly, z = oz + lz, n = n0 + l;
+        if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
+            float val = acc[v];
+            if (PS) {                                                   // adjoint of clamp(x * pre_scale, lo, hi)
+                const unsigned m = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
+                val = ((m >> l) & 1u) ? val * D.pre_scale : 0.f;
+            }
+            float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
+            if (row.w == 0) *dst = val;
+            else if (val != 0.f) unsafeAtomicAdd(dst, val);
+        }
+    }
+}
+
 int check_bm(const char *op, const genre_tensor *vox, const genre_tensor *map, const genre_tensor *segs,
              const genre_tensor *ray_ptr, const genre_tensor *ray_seg, const genre_tensor *ray_pre, BmDims &D, bool grad)
 {
@@ -812,5 +974,65 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
     else { if (pre_scale != 0.0f) GENRE_BM_SCATTER(true, 8, 1024); else GENRE_BM_SCATTER(false, 8, 1024); }
 #undef GENRE_BM_SCATTER
     GENRE_LAUNCH_CHECK("render_bm backward (bricks)");
+    return 1;
+}
+
+extern "C" int genre_render_bm_backward_gather(const genre_tensor *grad_out, const genre_tensor *grad_vox,
+                                               const genre_tensor *segs, const genre_tensor *ray_ptr,
+                                               const genre_tensor *ray_seg, const genre_tensor *ray_pre,
+                                               const genre_tensor *g_ent, const genre_tensor *g_chunks,
+                                               const genre_tensor *g_blob, const genre_tensor *g_rows,
+                                               const genre_tensor *depth_weight, const genre_tensor *ps_scratch,
+                                               const genre_tensor *tr_scratch, const genre_tensor *p_stash,
+                                               const genre_tensor *mask, float pre_scale, void *stream)
+{
+    const char *op = "render_bm_backward_gather";
+    BmDims D{};
+    if (!check_bm(op, grad_vox, grad_out, segs, ray_ptr, ray_seg, ray_pre, D, true)) return 0;
+    if (!check_rows(op, D, g_rows, 4, 8, 8)) return 0;
+    D.gx = grad_vox->stride[2]; D.gy = grad_vox->stride[3]; D.gz = grad_vox->stride[4];
+    D.pre_scale = pre_scale;
+    GENRE_REQUIRE(is_i32(g_ent, 2) && g_ent->size[1] == 4 && is_contiguous(g_ent) && aligned16(g_ent->data) && g_ent->size[0] >= 1,
+                  "%s: g_ent must be int32 [E,4]", op);
+    GENRE_REQUIRE(is_i32(g_chunks, 2) && g_chunks->size[1] == 4 && is_contiguous(g_chunks) && aligned16(g_chunks->data),
+                  "%s: g_chunks must be int32 [C,4]", op);
+    GENRE_REQUIRE(is_i32(g_blob, 1) && is_contiguous(g_blob) && aligned16(g_blob->data) && g_blob->size[0] < ((int64_t)1 << 31),
+                  "%s: g_blob must be a contiguous int32 tensor", op);
+    GENRE_REQUIRE(is_f32(depth_weight, 1) && is_contiguous(depth_weight) && depth_weight->size[0] >= 1 &&
+                      depth_weight->size[0] <= 256, "%s: depth_weight must be fp32 [ZR], 1 <= ZR <= 256", op);
+    D.ZR = (int)depth_weight->size[0];
+    const int64_t per = (int64_t)D.groups * D.nseg * 2 * kImgs;
+    GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ps_scratch->size[0] >= per &&
+                      is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && tr_scratch->size[0] >= per,
+                  "%s: ps_scratch / tr_scratch must hold groups*nseg*64 floats", op);
+    GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] % kImgs == 0 && D.groups > 0 &&
+                      p_stash->size[0] / kImgs % D.groups == 0, "%s: p_stash must be the forward's [groups*S*32] buffer", op);
+    D.nslot = p_stash->size[0] / kImgs / D.groups;
+    GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) && mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z),
+                  "%s: pre_scale needs the forward's mask int32 [groups*X*Y*Z]", op);
+    hipStream_t st = (hipStream_t)stream;
+    bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
+        D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
+        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data);
+    GENRE_LAUNCH_CHECK("render_bm backward (rays)");
+    const int nb = ((D.X + 3) / 4) * ((D.Y + 7) / 8) * ((D.Z + 7) / 8);
+    const dim3 grid((unsigned)g_rows->size[0], (unsigned)D.groups);
+    if (g_rows->size[0] > nb) {                   // some bricks are split over several rows: those add atomically
+        bm_zero_shared_kernel<4, 8, 8><<<grid, kThreads, 0, st>>>(D, (const int4 *)g_rows->data, (float *)grad_vox->data);
+        GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");
+    }
+#define GENRE_BM_GATHER(PSV)                                                                                              \
+    do {                                                                                                                  \
+        static std::atomic<uint64_t> done_{0};                                                                            \
+        if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_gather_kernel<PSV>), kGLds, done_)) return 0;             \
+        bm_gather_kernel<PSV><<<grid, kGThreads, kGLds, st>>>(                                                            \
+            D, (const int4 *)g_ent->data, (const int4 *)g_chunks->data, (const int *)g_blob->data,                        \
+            (const int4 *)g_rows->data, (const float *)depth_weight->data, (const float *)tr_scratch->data,               \
+            (const float *)p_stash->data, pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr,                     \
+            (float *)grad_vox->data);                                                                                     \
+    } while (0)
+    if (pre_scale != 0.0f) GENRE_BM_GATHER(true); else GENRE_BM_GATHER(false);
+#undef GENRE_BM_GATHER
+    GENRE_LAUNCH_CHECK("render_bm backward (gather)");
     return 1;
 }
