@@ -259,14 +259,27 @@ def kernel_table(G, dev, B):
                                          src=("common.hpp", "sph_render_bm.hip"))
             rows["render_fwd_bm_nosave"] = dict(us=event_time_us(lambda: bm_fwd(False), iters, 5),
                                                 bytes=B * BYTES_RENDER_FUSED, kernels="bm_sample_kernel (no saved state)")
+            def bm_bwd_scatter():
+                render_lib.render_bm_backward(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"],
+                                              TB["ent"], TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, tr, stash,
+                                              mask, 50.0, TB["pull_code"])
+
+            def bm_bwd_gather():
+                render_lib.render_bm_backward_gather(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"],
+                                                     TB["ray_pre"], TB["g_ent"], TB["g_chunks"], TB["g_blob"],
+                                                     TB["g_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0)
+            gather = "g_ent" in TB and _fused_render.bm_backward_mode() == "gather"     # what the step's autograd runs
             rows["render_bwd_bm"] = dict(
-                us=event_time_us(lambda: render_lib.render_bm_backward(
-                    gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"], TB["rec_b"],
-                    TB["bwd_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0, TB["pull_code"]), iters, 5),
+                us=event_time_us(bm_bwd_gather if gather else bm_bwd_scatter, iters, 5),
                 bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+bm_scatter_kernel",
-                pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel<4, 8, 8>", "bm_scatter_kernel<true, 4, 8, 8, 768>"],
+                kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+" + ("bm_gather_kernel" if gather else "bm_scatter_kernel"),
+                pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel<4, 8, 8>",
+                     "bm_gather_kernel<true>" if gather else "bm_scatter_kernel<true, 4, 8, 8, 768>"],
                 src=("common.hpp", "sph_render_bm.hip"))
+            if gather:      # the scatter form (LDS atomics), for comparison
+                rows["render_bwd_bm_scatter"] = dict(us=event_time_us(bm_bwd_scatter, iters, 5),
+                                                     bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
+                                                     kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+bm_scatter_kernel")
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3
     # forward-only chain (inference) at this batch size, standard layout and batch-minor layout

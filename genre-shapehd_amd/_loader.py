@@ -40,6 +40,7 @@ def _load():
     T, V = C.POINTER(GenreTensor), C.c_void_p
     scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float],
                "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float, C.c_int],
+               "genre_render_bm_backward_gather": [C.c_float],
                "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float],
                "genre_back_projection_forward_const": [C.c_float, C.c_float, C.c_int]}
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
@@ -52,6 +53,7 @@ def _load():
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
                         ("genre_render_spherical_forward", 8), ("genre_render_spherical_backward", 10),
                         ("genre_render_bm_forward", 11), ("genre_render_bm_backward", 14),
+                        ("genre_render_bm_backward_gather", 15),
                         ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4),
                         ("genre_nnd_forward_host", 6), ("genre_nnd_backward_host", 8)):
         fn = getattr(lib, name, None)
@@ -226,6 +228,15 @@ class _RenderLib:
         return _call("genre_render_bm_backward", grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, ent,
                      rec_b, bwd_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask,
                      scalars=(C.c_float(pre_scale), C.c_int(pull_brick)))
+
+
+    @staticmethod
+    def render_bm_backward_gather(grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, g_ent, g_chunks, g_blob,
+                                  g_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask=None, pre_scale=0.0):
+        """the backward in gather form (voxel sums in registers, per-voxel contribution lists; no LDS atomics)"""
+        return _call("genre_render_bm_backward_gather", grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32,
+                     g_ent, g_chunks, g_blob, g_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask,
+                     scalars=(C.c_float(pre_scale),))
 
 
 class _GlueLib:

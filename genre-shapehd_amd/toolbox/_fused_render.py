@@ -215,6 +215,15 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
     return t
 
 
+def bm_backward_mode():
+    """which backward the batch-minor renderer runs: "gather" (default; bm_gather_kernel) or "scatter"
+    (bm_scatter_kernel, LDS atomics) -- the A/B switch GENRE_BM_BWD, read at every call"""
+    import os
+    mode = os.environ.get("GENRE_BM_BWD", "gather")
+    assert mode in ("gather", "scatter"), "GENRE_BM_BWD must be gather or scatter"
+    return mode
+
+
 def is_batch_minor(vox):
     """image index fastest in memory (the layout the batch-minor kernels of csrc/sph_render.hip want)"""
     return vox.dim() == 5 and vox.shape[1] == 1 and vox.shape[0] >= 16 and vox.stride(0) == 1
@@ -277,9 +286,14 @@ class RenderSphericalFused(Function):
             dirs64, depth_weight, ps, stash = ctx.saved_tensors
             t = bm_tables_for(ctx.vox_shape, grad_out.device, dirs64, depth_weight)
             grad_vox = empty_batch_minor(ctx.vox_shape, grad_out.dtype, grad_out.device)
-            lib.render_bm_backward(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], t["ent"],
-                                   t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,
-                                   ctx.pre_scale, t["pull_code"])
+            if "g_ent" in t and bm_backward_mode() == "gather":
+                lib.render_bm_backward_gather(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"],
+                                              t["g_ent"], t["g_chunks"], t["g_blob"], t["g_rows"], depth_weight, ps,
+                                              torch.empty_like(ps), stash, ctx.mask, ctx.pre_scale)
+            else:
+                lib.render_bm_backward(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], t["ent"],
+                                       t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,
+                                       ctx.pre_scale, t["pull_code"])
             return grad_vox, None, None, None, None
         vox, dirs64, depth_weight, v = ctx.saved_tensors
         z_res = depth_weight.shape[0]

@@ -322,6 +322,20 @@ int genre_render_bm_backward(const genre_tensor *grad_out, const genre_tensor *g
                              const genre_tensor *tr_scratch, const genre_tensor *p_stash, const genre_tensor *mask,
                              float pre_scale, int pull_brick, void *stream);
 
+/* The same backward in GATHER form (csrc/sph_render_bm.hip: bm_gather_kernel): the voxel sums of a 4x8x8 brick live in
+ * registers, the dL/dp of the samples that touch it are parked in LDS, and the adjoint of the trilinear interpolation is
+ * a list per voxel of (sample line, weight) contributions -- tables g_ent int32 [E,4], g_chunks int32 [C,4], g_blob int32
+ * [..], g_rows int32 [rows,4] of toolbox/_bm_tables.py (_gather_tables).  No LDS atomics.  Same inputs, outputs and
+ * scratch buffers as genre_render_bm_backward; gradients equal to fp32 summation order. */
+int genre_render_bm_backward_gather(const genre_tensor *grad_out, const genre_tensor *grad_vox,
+                                    const genre_tensor *segs, const genre_tensor *ray_ptr,
+                                    const genre_tensor *ray_seg, const genre_tensor *ray_pre,
+                                    const genre_tensor *g_ent, const genre_tensor *g_chunks,
+                                    const genre_tensor *g_blob, const genre_tensor *g_rows,
+                                    const genre_tensor *depth_weight, const genre_tensor *ps_scratch,
+                                    const genre_tensor *tr_scratch, const genre_tensor *p_stash,
+                                    const genre_tensor *mask, float pre_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,10 @@ for _ in range(3):
                               TB["ray_pre"], ps, stash, mask, 50.0)
         lib.render_bm_backward(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"],
                                TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, trs, stash, mask, 50.0, TB["pull_code"])
+        if "g_ent" in TB:
+            lib.render_bm_backward_gather(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"],
+                                          TB["g_ent"], TB["g_chunks"], TB["g_blob"], TB["g_rows"], mod.depth_weight, ps,
+                                          trs, stash, mask, 50.0)
 # Chamfer forward (VALU-bound: used with --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ...)
 from genre_shapehd_amd.toolbox.nndistance._ext import my_lib  # noqa: E402
 xa = torch.rand((B, 2048, 3), device=dev)
