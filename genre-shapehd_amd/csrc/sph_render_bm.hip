@@ -667,6 +667,9 @@ __global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scat
 //            entries of a wave are neighbours in a longest-first order, so the scans run to the longer one's length.
 //   phase B  half-wave hw, voxel v: the list (start, n) from the blob's header; both half-waves of a wave hold z-neighbours,
 //            whose lists are padded to one even length -- the loop count is wave-uniform.
+#ifndef GENRE_G_ABL
+#define GENRE_G_ABL 0          // tools/ab_gather.py: 1 no phase B, 2 no scans, 4 no entry loads, 8 no list staging, 16 no flush mask
+#endif
 constexpr int kGThreads = 512, kGHW = kGThreads / 32, kGVox = 16;
 constexpr int kGCH = 384, kGLCAP = 2816;                   // toolbox/_bm_tables.py: GATHER_CH, GATHER_LCAP
 constexpr int kGBlobWords = 256 + 2 * kGLCAP, kGDwWords = 256 + kMaxSeg;
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
     for (int c = row.y; c < row.z; c++) {
         const int4 ck = chunks[c];                                     // (entry begin, entry end, blob begin, blob words)
         if (c > row.y) __syncthreads();                                // the previous chunk's lists and samples are done with
-        for (int i = tid * 4; i < ck.w; i += kGThreads * 4)
+        for (int i = tid * 4; i < ((GENRE_G_ABL & 8) ? 256 : ck.w); i += kGThreads * 4)
             *reinterpret_cast<int4 *>(bl + i) = *reinterpret_cast<const int4 *>(blob + (size_t)ck.z + i);
         // ---- phase A ----
         const int rounds = (ck.y - ck.x + kGHW - 1) / kGHW;
@@ -713,6 +716,12 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
             return h;
         };
         auto fetch = [&](const int4 h, GEntry &o) {                    // 18 loads, unconditionally (exact waits)
+            if (GENRE_G_ABL & 4) {
+#pragma unroll
+                for (int j = 0; j < kMaxSeg; j++) o.p[j] = __int_as_float(h.x + j);
+                o.T = 1.f; o.R = 0.5f;
+                return;
+            }
             const float *st = stash_g + (size_t)h.y * kImgs;
 #pragma unroll
             for (int j = 0; j < kMaxSeg; j++) o.p[j] = st[j * kImgs];
@@ -720,6 +729,7 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
             o.T = tp[0]; o.R = tp[kImgs];
         };
         auto process = [&](const int4 h, GEntry &e) {
+            if (GENRE_G_ABL & 2) { if (e.p[3] == 12345.f && e.T == e.R) sbuf[l] = e.p[5]; return; }
             const int pk = h.z;
             const int i0 = pk & 63, n_l = ((pk >> 6) & 63) - i0, L = (pk >> 12) & 63, k0 = (pk >> 18) & 255;
             const int Lmax = __builtin_amdgcn_readfirstlane(L);        // the wave's lower entry is the longer one
@@ -772,7 +782,7 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
         const char *sl = reinterpret_cast<const char *>(sbuf + l);
 #pragma unroll
         for (int v = 0; v < kGVox; v++) {
-            const int n = __builtin_amdgcn_readfirstlane(hd[v] >> 16);  // one (even) length for the wave's two lists
+            const int n = (GENRE_G_ABL & 1) ? 0 : __builtin_amdgcn_readfirstlane(hd[v] >> 16);  // one (even) length for the wave's two lists
             if (n == 0) continue;
             const char *q = lists + (hd[v] & 0xFFFF) * 8;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -801,7 +811,7 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
         const int x = ox + lx, y = oy + ly, z = oz + lz, n = n0 + l;
         if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
             float val = acc[v];
-            if (PS) {                                                   // adjoint of clamp(x * pre_scale, lo, hi)
+            if (PS && !(GENRE_G_ABL & 16)) {                            // adjoint of clamp(x * pre_scale, lo, hi)
                 const unsigned m = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
                 val = ((m >> l) & 1u) ? val * D.pre_scale : 0.f;
             }

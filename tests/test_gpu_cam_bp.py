@@ -320,6 +320,11 @@ def test_by_value_camera_entry_equals_the_tensor_entry(genre, oracle, dev):
         flv, cdv = (418.3, 2.2) if fl is None else (float(fl[0, 0]), float(cd[0, 0]))
         flt = torch.full((n, 1), flv, device=dev)
         cdt = torch.full((n, 1), cdv, device=dev)
+        if res % 4:                      # rows that are not float4-aligned: the brick kernel cannot take them
+            e = torch.empty((n, 1, res, res, res), device=dev)
+            with pytest.raises(RuntimeError, match="by-value"):
+                cam_bp_lib.back_projection_forward_const(t(d, dev), cdv, flv, e, torch.empty_like(e))
+            continue
         for shifted in (False, True):
             a, ca = torch.empty((n, 1, res, res, res), device=dev), torch.empty((n, 1, res, res, res), device=dev)
             b, cb = torch.empty_like(a), torch.empty_like(a)
