@@ -696,82 +696,114 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
     brick_origin<4, 8, 8>(D, row.x, ox, oy, oz);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), hw = wave * 2 + half;
+    const int lx = wave >> 1;
+    // voxel v of this half-wave: (lx, ly, lz) = (wave >> 1, (wave & 1) * 4 + (v >> 2), 2 * (v & 3) + half)
+    unsigned mword = 0u;                                                // clamp mask of voxel (l & 15), for the flush
+    if (PS && !(GENRE_G_ABL & 16)) {
+        const int v = l & 15;
+        const int x = ox + lx, y = oy + (wave & 1) * 4 + (v >> 2), z = oz + 2 * (v & 3) + half;
+        if (x < D.X && y < D.Y && z < D.Z) mword = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
+    }
     for (int i = tid; i < kGDwWords; i += kGThreads) dwl[i] = dw[min(i, D.ZR - 1)];
     const float *stash_g = stash + (size_t)g * D.nslot * kImgs + l;
     const float *tr_g = tr + (size_t)g * D.nseg * 2 * kImgs + l;
     float acc[kGVox];
 #pragma unroll
     for (int v = 0; v < kGVox; v++) acc[v] = 0.f;
-    for (int c = row.y; c < row.z; c++) {
-        const int4 ck = chunks[c];                                     // (entry begin, entry end, blob begin, blob words)
-        if (c > row.y) __syncthreads();                                // the previous chunk's lists and samples are done with
-        for (int i = tid * 4; i < ((GENRE_G_ABL & 8) ? 256 : ck.w); i += kGThreads * 4)
-            *reinterpret_cast<int4 *>(bl + i) = *reinterpret_cast<const int4 *>(blob + (size_t)ck.z + i);
-        // ---- phase A ----
-        const int rounds = (ck.y - ck.x + kGHW - 1) / kGHW;
-        auto header = [&](int r) {                                     // the entry of this half-wave in round r (pk = 0: none)
-            const int e = ck.x + r * kGHW + hw;
-            int4 h = ents[min(e, ck.y - 1)];
-            if (e >= ck.y) h.z = 0;
-            return h;
-        };
-        auto fetch = [&](const int4 h, GEntry &o) {                    // 18 loads, unconditionally (exact waits)
-            if (GENRE_G_ABL & 4) {
+
+    auto header = [&](const int4 ck, int r) {                          // the entry of this half-wave in round r (pk = 0: none)
+        const int e = ck.x + r * kGHW + hw;
+        int4 h = ents[min(e, ck.y - 1)];
+        if (e >= ck.y) h.z = 0;
+        return h;
+    };
+    auto fetch = [&](const int4 h, GEntry &o) {                        // 18 loads, unconditionally (exact waits)
+        if (GENRE_G_ABL & 4) {
 #pragma unroll
-                for (int j = 0; j < kMaxSeg; j++) o.p[j] = __int_as_float(h.x + j);
-                o.T = 1.f; o.R = 0.5f;
-                return;
-            }
-            const float *st = stash_g + (size_t)h.y * kImgs;
+            for (int j = 0; j < kMaxSeg; j++) o.p[j] = __int_as_float(h.x + j);
+            o.T = 1.f; o.R = 0.5f;
+            return;
+        }
+        const float *st = stash_g + (size_t)h.y * kImgs;
 #pragma unroll
-            for (int j = 0; j < kMaxSeg; j++) o.p[j] = st[j * kImgs];
-            const float *tp = tr_g + (size_t)h.x * 2 * kImgs;
-            o.T = tp[0]; o.R = tp[kImgs];
-        };
-        auto process = [&](const int4 h, GEntry &e) {
-            if (GENRE_G_ABL & 2) { if (e.p[3] == 12345.f && e.T == e.R) sbuf[l] = e.p[5]; return; }
-            const int pk = h.z;
-            const int i0 = pk & 63, n_l = ((pk >> 6) & 63) - i0, L = (pk >> 12) & 63, k0 = (pk >> 18) & 255;
-            const int Lmax = __builtin_amdgcn_readfirstlane(L);        // the wave's lower entry is the longer one
-            float ce[kMaxSeg];
-            float Tg = e.T, Rr = e.R;
+        for (int j = 0; j < kMaxSeg; j++) o.p[j] = st[j * kImgs];
+        const float *tp = tr_g + (size_t)h.x * 2 * kImgs;
+        o.T = tp[0]; o.R = tp[kImgs];
+    };
+    auto process = [&](const int4 h, GEntry &e) {
+        if (GENRE_G_ABL & 2) { if (e.p[3] == 12345.f && e.T == e.R) sbuf[l] = e.p[5]; return; }
+        const int pk = h.z;
+        const int i0 = pk & 63, n_l = ((pk >> 6) & 63) - i0, L = (pk >> 12) & 63, k0 = (pk >> 18) & 255;
+        const int Lmax = __builtin_amdgcn_readfirstlane(L);            // the wave's lower entry is the longer one
+        float ce[kMaxSeg];
+        float Tg = e.T, Rr = e.R;
 #pragma unroll
-            for (int j = 0; j < kMaxSeg; j++) {                         // forward: g T_k
-                if (j < Lmax) {
-                    e.p[j] = j < L ? e.p[j] : 0.f;                      // (the shorter entry of the wave: no-ops beyond its end)
-                    ce[j] = Tg;
-                    Tg = __builtin_fmaf(-fabsf(e.p[j]), Tg, Tg);
-                }
-            }
-            float *sb = sbuf + (h.w - i0) * kImgs + l;
-            const float *wl = dwl + k0;
-#pragma unroll
-            for (int j = kMaxSeg - 1; j >= 0; j--) {                    // reverse: R_k; dL/dp_k of the listed samples
-                if (j < Lmax) {
-                    const float d = wl[j] - Rr;
-                    Rr = __builtin_fmaf(fabsf(e.p[j]), d, Rr);
-                    const float dp = e.p[j] > 0.f ? ce[j] * d : 0.f;    // the clamp passes the gradient where the saved sample is > 0
-                    if ((unsigned)(j - i0) < (unsigned)n_l) sb[j * kImgs] = dp;
-                }
-            }
-        };
-        {
-            GEntry A, B;
-            int4 hA = header(0), hB = header(1);
-            fetch(hA, A);
-            for (int r = 0; r < rounds; r += 2) {
-                const int4 hC = header(r + 2);
-                fetch(hB, B);
-                process(hA, A);
-                if (r + 1 >= rounds) break;
-                const int4 hD = header(r + 3);
-                fetch(hC, A);
-                process(hB, B);
-                hA = hC; hB = hD;
+        for (int j = 0; j < kMaxSeg; j++) {                             // forward: g T_k
+            if (j < Lmax) {
+                e.p[j] = j < L ? e.p[j] : 0.f;                          // (the shorter entry of the wave: no-ops beyond its end)
+                ce[j] = Tg;
+                Tg = __builtin_fmaf(-fabsf(e.p[j]), Tg, Tg);
             }
         }
+        float *sb = sbuf + (h.w - i0) * kImgs + l;
+        const float *wl = dwl + k0;
+#pragma unroll
+        for (int j = kMaxSeg - 1; j >= 0; j--) {                        // reverse: R_k; dL/dp_k of the listed samples
+            if (j < Lmax) {
+                const float d = wl[j] - Rr;
+                Rr = __builtin_fmaf(fabsf(e.p[j]), d, Rr);
+                const float dp = e.p[j] > 0.f ? ce[j] * d : 0.f;        // the clamp passes the gradient where the saved sample is > 0
+                if ((unsigned)(j - i0) < (unsigned)n_l) sb[j * kImgs] = dp;
+            }
+        }
+    };
+    // a chunk's blob travels global -> registers -> LDS: three 16-byte pieces per thread (kGBlobWords <= 3 * 4 * kGThreads)
+    static_assert(kGBlobWords <= 3 * 4 * kGThreads, "blob staging: three sweeps");
+    int4 bq[3];
+    auto blob_load = [&](const int4 ck) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int i = (tid + u * kGThreads) * 4;
+            bq[u] = make_int4(0, 0, 0, 0);
+            if (i < ((GENRE_G_ABL & 8) ? 256 : ck.w)) bq[u] = *reinterpret_cast<const int4 *>(blob + (size_t)ck.z + i);
+        }
+    };
+    auto blob_store = [&](const int4 ck) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int i = (tid + u * kGThreads) * 4;
+            if (i < ck.w) *reinterpret_cast<int4 *>(bl + i) = bq[u];
+        }
+    };
+
+    int4 ck = chunks[row.y];                                           // (entry begin, entry end, blob begin, blob words)
+    GEntry A, B;
+    int4 hA = header(ck, 0), hB = header(ck, 1);
+    blob_load(ck);
+    fetch(hA, A);
+    for (int c = row.y; c < row.z; c++) {
+        // here: the blob of chunk c is in bq (requested a phase ago), round 0 of its entries in hA / hB / A, LDS is free
+        blob_store(ck);
+        const int rounds = (ck.y - ck.x + kGHW - 1) / kGHW;
+        for (int r = 0; r < rounds; r += 2) {                          // phase A: the next round's loads fly during this round's scans
+            const int4 hC = header(ck, r + 2);
+            fetch(hB, B);
+            process(hA, A);
+            if (r + 1 >= rounds) break;
+            const int4 hD = header(ck, r + 3);
+            fetch(hC, A);
+            process(hB, B);
+            hA = hC; hB = hD;
+        }
         __syncthreads();
-        // ---- phase B ----
+        // phase B; the next chunk of the row is requested meanwhile: its headers and blob now, its first entries half way
+        const bool more = c + 1 < row.z;
+        int4 ckn = ck;
+        if (more) {
+            ckn = chunks[c + 1];
+            hA = header(ckn, 0); hB = header(ckn, 1);
+            blob_load(ckn);
+        }
         int hd[kGVox];
 #pragma unroll
         for (int v4 = 0; v4 < kGVox / 4; v4++) {
@@ -782,39 +814,36 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
         const char *sl = reinterpret_cast<const char *>(sbuf + l);
 #pragma unroll
         for (int v = 0; v < kGVox; v++) {
-            const int n = (GENRE_G_ABL & 1) ? 0 : __builtin_amdgcn_readfirstlane(hd[v] >> 16);  // one (even) length for the wave's two lists
+            if (v == kGVox / 2 && more) fetch(hA, A);
+            const int n = (GENRE_G_ABL & 1) ? 0 : __builtin_amdgcn_readfirstlane(hd[v] >> 16);  // one length (a multiple of 4) for the wave's two lists
             if (n == 0) continue;
             const char *q = lists + (hd[v] & 0xFFFF) * 8;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int i = 0;
-            for (; i + 4 <= n; i += 4) {
-                const int4 c01 = *reinterpret_cast<const int4 *>(q + i * 8);           // (offset, weight) x 2
-                const int4 c23 = *reinterpret_cast<const int4 *>(q + i * 8 + 16);
-                a0 = __builtin_fmaf(__int_as_float(c01.y), *reinterpret_cast<const float *>(sl + c01.x), a0);
-                a1 = __builtin_fmaf(__int_as_float(c01.w), *reinterpret_cast<const float *>(sl + c01.z), a1);
-                a2 = __builtin_fmaf(__int_as_float(c23.y), *reinterpret_cast<const float *>(sl + c23.x), a2);
-                a3 = __builtin_fmaf(__int_as_float(c23.w), *reinterpret_cast<const float *>(sl + c23.z), a3);
-            }
-            if (i < n) {
-                const int4 c01 = *reinterpret_cast<const int4 *>(q + i * 8);
-                a0 = __builtin_fmaf(__int_as_float(c01.y), *reinterpret_cast<const float *>(sl + c01.x), a0);
-                a1 = __builtin_fmaf(__int_as_float(c01.w), *reinterpret_cast<const float *>(sl + c01.z), a1);
+            int4 c01 = *reinterpret_cast<const int4 *>(q), c23 = *reinterpret_cast<const int4 *>(q + 16);   // (offset, weight) x 2, twice
+            for (int i = 0; i < n; i += 4) {
+                const float x0 = *reinterpret_cast<const float *>(sl + c01.x), x1 = *reinterpret_cast<const float *>(sl + c01.z);
+                const float x2 = *reinterpret_cast<const float *>(sl + c23.x), x3 = *reinterpret_cast<const float *>(sl + c23.z);
+                const float w0 = __int_as_float(c01.y), w1 = __int_as_float(c01.w), w2 = __int_as_float(c23.y), w3 = __int_as_float(c23.w);
+                q += 32;                                               // the next four are requested before these are used
+                c01 = *reinterpret_cast<const int4 *>(q);              // (behind the list: the next list / the buffer's tail, unused)
+                c23 = *reinterpret_cast<const int4 *>(q + 16);
+                a0 = __builtin_fmaf(w0, x0, a0); a1 = __builtin_fmaf(w1, x1, a1);
+                a2 = __builtin_fmaf(w2, x2, a2); a3 = __builtin_fmaf(w3, x3, a3);
             }
             acc[v] += (a0 + a1) + (a2 + a3);
         }
+        if (more) __syncthreads();                                     // this chunk's lists and samples are done with
+        ck = ckn;
     }
     // ---- every voxel of the brick once: a 128-byte line per half-wave and voxel ----
-    const int lx = wave >> 1;
 #pragma unroll
     for (int v = 0; v < kGVox; v++) {
         const int ly = (wave & 1) * 4 + (v >> 2), lz = 2 * (v & 3) + half;
         const int x = ox + lx, y = oy + ly, z = oz + lz, n = n0 + l;
+        const unsigned m = PS ? (unsigned)__shfl((int)mword, (lane & 32) | v) : 0u;
         if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
             float val = acc[v];
-            if (PS && !(GENRE_G_ABL & 16)) {                            // adjoint of clamp(x * pre_scale, lo, hi)
-                const unsigned m = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
-                val = ((m >> l) & 1u) ? val * D.pre_scale : 0.f;
-            }
+            if (PS && !(GENRE_G_ABL & 16)) val = ((m >> l) & 1u) ? val * D.pre_scale : 0.f;   // adjoint of clamp(x * pre_scale, lo, hi)
             float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
             if (row.w == 0) *dst = val;
             else if (val != 0.f) unsafeAtomicAdd(dst, val);

@@ -238,8 +238,8 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
 #                                           half_wave * 16 + v (see hidx below): list start | list length << 16, in
 #                                           contributions -- then the lists, 8 bytes per contribution: (byte offset of the
 #                                           sample's line in the sample buffer, weight).  The lists of z-neighbours (the two
-#                                           half-waves of a wave) are padded with zero-weight contributions to the same,
-#                                           even, length.
+#                                           half-waves of a wave) are padded with zero-weight contributions to the same
+#                                           length, a multiple of four.
 #   g_rows    int32 [rows, 4]             (pull brick, chunk begin, chunk end, shared)
 GATHER_BRICK = (4, 8, 8)
 GATHER_CH = 384                 # listed samples per chunk: 48 KB of LDS (32 images x fp32 per sample)
@@ -292,7 +292,7 @@ def _gather_tables(pnb, ent, ent_brick, gstart, gcount, i_first, rel, own, wl, e
         keys = chunk_of[c_e] * 256 + c_vi
         counts = np.bincount(keys, minlength=nC * 256).reshape(nC, 256)
         padded = np.maximum(counts, counts[:, vi_all ^ 1])
-        padded += padded & 1
+        padded = (padded + 3) & ~3                                         # the kernel takes four contributions per step
         tot = padded.sum(1)
         big = np.nonzero(tot > GATHER_LCAP)[0]
         if big.size == 0:

@@ -189,7 +189,7 @@ def backward_gather(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
             for v in range(BX * BY * BZ):
                 h, hp = hdr[hidx[v]], hdr[hidx[v ^ 1]]
                 st, n = h & 0xFFFF, h >> 16
-                assert n == hp >> 16 and n % 2 == 0 and st % 2 == 0       # the wave's two lists: one even length
+                assert n == hp >> 16 and n % 4 == 0 and st % 4 == 0       # the wave's two lists: one length, a multiple of 4
                 sub = lists[st:st + n]
                 off, w = sub[:, 0], sub[:, 1].view(np.float32).astype(np.float64)
                 assert (off % 128 == 0).all()

@@ -38,7 +38,7 @@ def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, pu
     if res == 21:           # small buffers: several chunks per row, chunks halved because of their lists
         monkeypatch.setattr(m, "GATHER_CH", 40)
         monkeypatch.setattr(m, "GATHER_RAW", 200)
-        monkeypatch.setattr(m, "GATHER_LCAP", 260)
+        monkeypatch.setattr(m, "GATHER_LCAP", 420)
     dw = np.linspace(0, 1, zr).astype(np.float32)
     dw = torch.linspace(0, 1, zr).numpy()
     kw = dict(pull=pull) if split is None else dict(split_f=split, split_b=split, pull=pull)
