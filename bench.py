@@ -242,7 +242,7 @@ def kernel_table(G, dev, B):
             TB = _fused_render.bm_tables_for(proj_bm.shape, dev, mod._dirs64, mod.depth_weight)
             groups = -(-B // 32)
             ps = torch.empty((groups * TB["segs"].shape[0] * 64,), device=dev)
-            tr = torch.empty_like(ps)
+            tr = torch.empty((ps.numel() + 64,), device=dev)          # + the gather kernel's row counters (one per group)
             stash = torch.empty((groups * TB["rec_f"].shape[0] * 32,), device=dev)
             mask = torch.empty((groups * 128 ** 3,), dtype=torch.int32, device=dev)
             out_p = torch.empty((B, 1, 160, 160), device=dev)

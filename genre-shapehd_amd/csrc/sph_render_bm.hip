@@ -301,8 +301,9 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
                                                              const int *__restrict__ ray_ptr,
                                                              const int *__restrict__ ray_seg,
                                                              const double2 *__restrict__ ray_pre, View4 gout,
-                                                             float *__restrict__ tr)
+                                                             float *__restrict__ tr, int *__restrict__ row_counter)
 {
+    if (row_counter && blockIdx.x == 0 && threadIdx.x == 0) row_counter[blockIdx.y] = 0;   // for the gather kernel behind this one
     const int q = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     if (q >= D.R * D.R) return;
     const int g = blockIdx.y, n = g * kImgs + l;
@@ -679,31 +680,27 @@ struct GEntry { float p[kMaxSeg]; float T, R; };
 
 template <bool PS>
 __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const int4 *__restrict__ ents, const int4 *__restrict__ chunks,
-                                                                 const int *__restrict__ blob, const int4 *__restrict__ rows,
+                                                                 const int *__restrict__ blob, const int4 *__restrict__ rows, int nrows,
                                                                  const float *__restrict__ dw, const float *__restrict__ tr,
                                                                  const float *__restrict__ stash, const unsigned *__restrict__ mask,
-                                                                 float *__restrict__ gvox)
+                                                                 float *__restrict__ gvox, int *__restrict__ row_counter)
 {
+    // PERSISTENT workgroups: the launch has two per CU; each takes rows from a counter (the table is sorted heaviest first)
+    // and walks the chunks of its rows as ONE stream -- while chunk i is gathered, the headers, the blob and the first
+    // entries of chunk i + 1 are in flight, whether it belongs to the same row or to the next one.  (A workgroup per row
+    // spends three dependent memory round trips -- row, chunk, entry headers -- before its first useful instruction:
+    // 110 us of the first version's 550.)
     extern __shared__ __attribute__((aligned(16))) int lds_g[];
+    __shared__ int s_next;
     int *bl = lds_g;                                                    // [256 headers][2 * kGLCAP]
     float *dwl = reinterpret_cast<float *>(lds_g + kGBlobWords);       // depth weights (+ kMaxSeg: read past a short segment)
     float *sbuf = dwl + kGDwWords;                                      // [kGCH][32]  (behind >= 16 lines of other data: the
                                                                         //  per-entry base below, (ls0 - i0) lines, is never negative)
-    const int4 row = rows[blockIdx.x];
-    if (row.w == 2) return;
     const int g = blockIdx.y, n0 = g * kImgs;
-    int ox, oy, oz;
-    brick_origin<4, 8, 8>(D, row.x, ox, oy, oz);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), hw = wave * 2 + half;
     const int lx = wave >> 1;
     // voxel v of this half-wave: (lx, ly, lz) = (wave >> 1, (wave & 1) * 4 + (v >> 2), 2 * (v & 3) + half)
-    unsigned mword = 0u;                                                // clamp mask of voxel (l & 15), for the flush
-    if (PS && !(GENRE_G_ABL & 16)) {
-        const int v = l & 15;
-        const int x = ox + lx, y = oy + (wave & 1) * 4 + (v >> 2), z = oz + 2 * (v & 3) + half;
-        if (x < D.X && y < D.Y && z < D.Z) mword = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
-    }
     for (int i = tid; i < kGDwWords; i += kGThreads) dwl[i] = dw[min(i, D.ZR - 1)];
     const float *stash_g = stash + (size_t)g * D.nslot * kImgs + l;
     const float *tr_g = tr + (size_t)g * D.nseg * 2 * kImgs + l;
@@ -735,12 +732,13 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
         const int pk = h.z;
         const int i0 = pk & 63, n_l = ((pk >> 6) & 63) - i0, L = (pk >> 12) & 63, k0 = (pk >> 18) & 255;
         const int Lmax = __builtin_amdgcn_readfirstlane(L);            // the wave's lower entry is the longer one
+        const bool uneven = __builtin_amdgcn_readlane(L, 32) != Lmax;  // ... and usually they are equally long
         float ce[kMaxSeg];
         float Tg = e.T, Rr = e.R;
 #pragma unroll
         for (int j = 0; j < kMaxSeg; j++) {                             // forward: g T_k
             if (j < Lmax) {
-                e.p[j] = j < L ? e.p[j] : 0.f;                          // (the shorter entry of the wave: no-ops beyond its end)
+                if (uneven) e.p[j] = j < L ? e.p[j] : 0.f;              // (the shorter entry of the wave: no-ops beyond its end)
                 ce[j] = Tg;
                 Tg = __builtin_fmaf(-fabsf(e.p[j]), Tg, Tg);
             }
@@ -775,14 +773,20 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
             if (i < ck.w) *reinterpret_cast<int4 *>(bl + i) = bq[u];
         }
     };
-
-    int4 ck = chunks[row.y];                                           // (entry begin, entry end, blob begin, blob words)
+    int row_i = blockIdx.x;
+    if (row_i >= nrows) return;
+    int4 row = rows[row_i];
+    int c = row.y;
+    int4 ck = chunks[c];                                               // (entry begin, entry end, blob begin, blob words)
     GEntry A, B;
     int4 hA = header(ck, 0), hB = header(ck, 1);
     blob_load(ck);
     fetch(hA, A);
-    for (int c = row.y; c < row.z; c++) {
+    bool row_start = true;
+    int next_row = nrows;
+    for (;;) {
         // here: the blob of chunk c is in bq (requested a phase ago), round 0 of its entries in hA / hB / A, LDS is free
+        if (row_start && tid == 0) s_next = (int)gridDim.x + atomicAdd(row_counter + g, 1);    // the row after this one
         blob_store(ck);
         const int rounds = (ck.y - ck.x + kGHW - 1) / kGHW;
         for (int r = 0; r < rounds; r += 2) {                          // phase A: the next round's loads fly during this round's scans
@@ -796,58 +800,83 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
             hA = hC; hB = hD;
         }
         __syncthreads();
-        // phase B; the next chunk of the row is requested meanwhile: its headers and blob now, its first entries half way
-        const bool more = c + 1 < row.z;
+        if (row_start) next_row = s_next;
+        // the next chunk of the stream: of this row, else the first of the next row
+        const bool row_ends = c + 1 >= row.z;
+        int4 rown = row;
+        int cn = c + 1;
+        bool more = true;
+        if (row_ends) {
+            more = next_row < nrows;
+            if (more) { rown = rows[next_row]; cn = rown.y; }
+        }
         int4 ckn = ck;
         if (more) {
-            ckn = chunks[c + 1];
+            ckn = chunks[cn];
             hA = header(ckn, 0); hB = header(ckn, 1);
             blob_load(ckn);
         }
-        int hd[kGVox];
+        // ---- phase B: this half-wave's sixteen lists are one contiguous stream in the blob (so are its partner's, of the
+        // same lengths): four contributions per step, the list words requested two steps ahead ACROSS the voxel boundaries
+        {
+            int hd[kGVox];
 #pragma unroll
-        for (int v4 = 0; v4 < kGVox / 4; v4++) {
-            const int4 t4 = reinterpret_cast<const int4 *>(bl + hw * kGVox)[v4];
-            hd[4 * v4] = t4.x; hd[4 * v4 + 1] = t4.y; hd[4 * v4 + 2] = t4.z; hd[4 * v4 + 3] = t4.w;
-        }
-        const char *lists = reinterpret_cast<const char *>(bl + 256);
-        const char *sl = reinterpret_cast<const char *>(sbuf + l);
-#pragma unroll
-        for (int v = 0; v < kGVox; v++) {
-            if (v == kGVox / 2 && more) fetch(hA, A);
-            const int n = (GENRE_G_ABL & 1) ? 0 : __builtin_amdgcn_readfirstlane(hd[v] >> 16);  // one length (a multiple of 4) for the wave's two lists
-            if (n == 0) continue;
-            const char *q = lists + (hd[v] & 0xFFFF) * 8;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int4 c01 = *reinterpret_cast<const int4 *>(q), c23 = *reinterpret_cast<const int4 *>(q + 16);   // (offset, weight) x 2, twice
-            for (int i = 0; i < n; i += 4) {
-                const float x0 = *reinterpret_cast<const float *>(sl + c01.x), x1 = *reinterpret_cast<const float *>(sl + c01.z);
-                const float x2 = *reinterpret_cast<const float *>(sl + c23.x), x3 = *reinterpret_cast<const float *>(sl + c23.z);
-                const float w0 = __int_as_float(c01.y), w1 = __int_as_float(c01.w), w2 = __int_as_float(c23.y), w3 = __int_as_float(c23.w);
-                q += 32;                                               // the next four are requested before these are used
-                c01 = *reinterpret_cast<const int4 *>(q);              // (behind the list: the next list / the buffer's tail, unused)
-                c23 = *reinterpret_cast<const int4 *>(q + 16);
-                a0 = __builtin_fmaf(w0, x0, a0); a1 = __builtin_fmaf(w1, x1, a1);
-                a2 = __builtin_fmaf(w2, x2, a2); a3 = __builtin_fmaf(w3, x3, a3);
+            for (int v4 = 0; v4 < kGVox / 4; v4++) {
+                const int4 t4 = reinterpret_cast<const int4 *>(bl + hw * kGVox)[v4];
+                hd[4 * v4] = t4.x; hd[4 * v4 + 1] = t4.y; hd[4 * v4 + 2] = t4.z; hd[4 * v4 + 3] = t4.w;
             }
-            acc[v] += (a0 + a1) + (a2 + a3);
-        }
-        if (more) __syncthreads();                                     // this chunk's lists and samples are done with
-        ck = ckn;
-    }
-    // ---- every voxel of the brick once: a 128-byte line per half-wave and voxel ----
+            const char *q = reinterpret_cast<const char *>(bl + 256) + (hd[0] & 0xFFFF) * 8;
+            const char *sl = reinterpret_cast<const char *>(sbuf + l);
+            int4 c01 = *reinterpret_cast<const int4 *>(q), c23 = *reinterpret_cast<const int4 *>(q + 16);
+            int4 d01 = *reinterpret_cast<const int4 *>(q + 32), d23 = *reinterpret_cast<const int4 *>(q + 48);
 #pragma unroll
-    for (int v = 0; v < kGVox; v++) {
-        const int ly = (wave & 1) * 4 + (v >> 2), lz = 2 * (v & 3) + half;
-        const int x = ox + lx, y = oy + ly, z = oz + lz, n = n0 + l;
-        const unsigned m = PS ? (unsigned)__shfl((int)mword, (lane & 32) | v) : 0u;
-        if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
-            float val = acc[v];
-            if (PS && !(GENRE_G_ABL & 16)) val = ((m >> l) & 1u) ? val * D.pre_scale : 0.f;   // adjoint of clamp(x * pre_scale, lo, hi)
-            float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
-            if (row.w == 0) *dst = val;
-            else if (val != 0.f) unsafeAtomicAdd(dst, val);
+            for (int v = 0; v < kGVox; v++) {
+                if (v == kGVox / 2 && more) fetch(hA, A);               // the next chunk's first entries (headers requested above)
+                const int n = (GENRE_G_ABL & 1) ? 0 : __builtin_amdgcn_readfirstlane(hd[v] >> 16);   // a multiple of 4, wave-uniform
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int i = 0; i < n; i += 4) {
+                    const float x0 = *reinterpret_cast<const float *>(sl + c01.x), x1 = *reinterpret_cast<const float *>(sl + c01.z);
+                    const float x2 = *reinterpret_cast<const float *>(sl + c23.x), x3 = *reinterpret_cast<const float *>(sl + c23.z);
+                    const float w0 = __int_as_float(c01.y), w1 = __int_as_float(c01.w), w2 = __int_as_float(c23.y), w3 = __int_as_float(c23.w);
+                    c01 = d01; c23 = d23;
+                    q += 32;
+                    d01 = *reinterpret_cast<const int4 *>(q + 32);     // (behind the stream: other lists / the buffer's tail, unused)
+                    d23 = *reinterpret_cast<const int4 *>(q + 48);
+                    a0 = __builtin_fmaf(w0, x0, a0); a1 = __builtin_fmaf(w1, x1, a1);
+                    a2 = __builtin_fmaf(w2, x2, a2); a3 = __builtin_fmaf(w3, x3, a3);
+                }
+                acc[v] += (a0 + a1) + (a2 + a3);
+            }
         }
+        if (row_ends) {
+            // ---- every voxel of the brick once: a 128-byte line per half-wave and voxel ----
+            int ox, oy, oz;
+            brick_origin<4, 8, 8>(D, row.x, ox, oy, oz);
+            unsigned mword = 0u;                                        // clamp mask of voxel (l & 15)
+            if (PS && !(GENRE_G_ABL & 16)) {
+                const int v = l & 15;
+                const int x = ox + lx, y = oy + (wave & 1) * 4 + (v >> 2), z = oz + 2 * (v & 3) + half;
+                if (x < D.X && y < D.Y && z < D.Z) mword = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
+            }
+#pragma unroll
+            for (int v = 0; v < kGVox; v++) {
+                const int ly = (wave & 1) * 4 + (v >> 2), lz = 2 * (v & 3) + half;
+                const int x = ox + lx, y = oy + ly, z = oz + lz, n = n0 + l;
+                const unsigned m = PS ? (unsigned)__shfl((int)mword, (lane & 32) | v) : 0u;
+                if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
+                    float val = acc[v];
+                    if (PS && !(GENRE_G_ABL & 16)) val = ((m >> l) & 1u) ? val * D.pre_scale : 0.f;   // adjoint of clamp(x * pre_scale, lo, hi)
+                    float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
+                    if (row.w == 0) *dst = val;
+                    else if (val != 0.f) unsafeAtomicAdd(dst, val);
+                }
+                acc[v] = 0.f;
+            }
+        }
+        if (!more) break;
+        __syncthreads();                                               // this chunk's lists and samples are done with
+        row_start = row_ends;
+        row = rown; c = cn; ck = ckn;
     }
 }
 
@@ -987,7 +1016,7 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
     hipStream_t st = (hipStream_t)stream;
     bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
         D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
-        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data);
+        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data, nullptr);
     GENRE_LAUNCH_CHECK("render_bm backward (rays)");
     const int nb = ((D.X + px - 1) / px) * ((D.Y + 7) / 8) * ((D.Z + 7) / 8);
     const dim3 grid((unsigned)bwd_rows->size[0], (unsigned)D.groups);
@@ -1042,8 +1071,8 @@ extern "C" int genre_render_bm_backward_gather(const genre_tensor *grad_out, con
     D.ZR = (int)depth_weight->size[0];
     const int64_t per = (int64_t)D.groups * D.nseg * 2 * kImgs;
     GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ps_scratch->size[0] >= per &&
-                      is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && tr_scratch->size[0] >= per,
-                  "%s: ps_scratch / tr_scratch must hold groups*nseg*64 floats", op);
+                      is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && tr_scratch->size[0] >= per + D.groups,
+                  "%s: ps_scratch must hold groups*nseg*64 floats, tr_scratch groups*nseg*64 + groups", op);
     GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] % kImgs == 0 && D.groups > 0 &&
                       p_stash->size[0] / kImgs % D.groups == 0, "%s: p_stash must be the forward's [groups*S*32] buffer", op);
     D.nslot = p_stash->size[0] / kImgs / D.groups;
@@ -1052,10 +1081,16 @@ extern "C" int genre_render_bm_backward_gather(const genre_tensor *grad_out, con
     hipStream_t st = (hipStream_t)stream;
     bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
         D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
-        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data);
+        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data,
+        reinterpret_cast<int *>((float *)tr_scratch->data + per));
     GENRE_LAUNCH_CHECK("render_bm backward (rays)");
     const int nb = ((D.X + 3) / 4) * ((D.Y + 7) / 8) * ((D.Z + 7) / 8);
     const dim3 grid((unsigned)g_rows->size[0], (unsigned)D.groups);
+    const int nrows = (int)g_rows->size[0];
+    // persistent workgroups: two per CU (LDS), fewer when there are fewer rows; they take rows from a counter per group
+    // that lives behind tr_scratch's payload and is reset by the per-ray kernel in front of this one
+    const dim3 pgrid((unsigned)(nrows < 2 * kCUs ? nrows : 2 * kCUs), (unsigned)D.groups);
+    int *counter = reinterpret_cast<int *>((float *)tr_scratch->data + per);
     if (g_rows->size[0] > nb) {                   // some bricks are split over several rows: those add atomically
         bm_zero_shared_kernel<4, 8, 8><<<grid, kThreads, 0, st>>>(D, (const int4 *)g_rows->data, (float *)grad_vox->data);
         GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");
@@ -1064,11 +1099,11 @@ extern "C" int genre_render_bm_backward_gather(const genre_tensor *grad_out, con
     do {                                                                                                                  \
         static std::atomic<uint64_t> done_{0};                                                                            \
         if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_gather_kernel<PSV>), kGLds, done_)) return 0;             \
-        bm_gather_kernel<PSV><<<grid, kGThreads, kGLds, st>>>(                                                            \
+        bm_gather_kernel<PSV><<<pgrid, kGThreads, kGLds, st>>>(                                                           \
             D, (const int4 *)g_ent->data, (const int4 *)g_chunks->data, (const int *)g_blob->data,                        \
-            (const int4 *)g_rows->data, (const float *)depth_weight->data, (const float *)tr_scratch->data,               \
+            (const int4 *)g_rows->data, nrows, (const float *)depth_weight->data, (const float *)tr_scratch->data,        \
             (const float *)p_stash->data, pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr,                     \
-            (float *)grad_vox->data);                                                                                     \
+            (float *)grad_vox->data, counter);                                                                            \
     } while (0)
     if (pre_scale != 0.0f) GENRE_BM_GATHER(true); else GENRE_BM_GATHER(false);
 #undef GENRE_BM_GATHER

@@ -286,10 +286,12 @@ class RenderSphericalFused(Function):
             dirs64, depth_weight, ps, stash = ctx.saved_tensors
             t = bm_tables_for(ctx.vox_shape, grad_out.device, dirs64, depth_weight)
             grad_vox = empty_batch_minor(ctx.vox_shape, grad_out.dtype, grad_out.device)
+            groups = -(-ctx.vox_shape[0] // 32)
             if "g_ent" in t and bm_backward_mode() == "gather":
                 lib.render_bm_backward_gather(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"],
                                               t["g_ent"], t["g_chunks"], t["g_blob"], t["g_rows"], depth_weight, ps,
-                                              torch.empty_like(ps), stash, ctx.mask, ctx.pre_scale)
+                                              torch.empty((ps.numel() + groups,), dtype=ps.dtype, device=ps.device),
+                                              stash, ctx.mask, ctx.pre_scale)      # (+ one row counter per image group)
             else:
                 lib.render_bm_backward(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], t["ent"],
                                        t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,

@@ -44,7 +44,7 @@ TB = _fused_render.bm_tables_for(proj_bm.shape, dev, mod._dirs64, mod.depth_weig
 if TB is not None:
     groups = -(-B // 32)
     ps = torch.empty((groups * TB["segs"].shape[0] * 64,), device=dev)
-    trs = torch.empty_like(ps)
+    trs = torch.empty((ps.numel() + 64,), device=dev)      # + the gather kernel's row counters
     stash = torch.empty((groups * TB["rec_f"].shape[0] * 32,), device=dev)
     mask = torch.empty((groups * 128 ** 3,), dtype=torch.int32, device=dev)
     out_p = torch.empty((B, 1, 160, 160), device=dev)

@@ -30,7 +30,7 @@ def worker(tag):
     lib = _fused_render._loader().render_lib
     f32 = dict(dtype=torch.float32, device=dev)
     ps = torch.empty((T["segs"].shape[0] * 64,), **f32)
-    tr = torch.empty_like(ps)
+    tr = torch.empty((ps.numel() + 64,), **f32)
     stash = torch.empty((T["rec_f"].shape[0] * 32,), **f32)
     mask = torch.empty((128 ** 3,), dtype=torch.int32, device=dev)
     out = torch.empty((B, 1, 160, 160), **f32)

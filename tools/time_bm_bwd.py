@@ -24,7 +24,7 @@ lib = _fused_render._loader().render_lib
 groups = -(-B // 32)
 f32 = dict(dtype=torch.float32, device=dev)
 ps = torch.empty((groups * T["segs"].shape[0] * 64,), **f32)
-tr = torch.empty_like(ps)
+tr = torch.empty((ps.numel() + 64,), **f32)
 stash = torch.empty((groups * T["rec_f"].shape[0] * 32,), **f32)
 mask = torch.empty((groups * 128 ** 3,), dtype=torch.int32, device=dev)
 out = torch.empty((B, 1, 160, 160), **f32)
