@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
         ps_val = half ? S : T;
         Lprev = L;
         stp_prev = SAVE ? stash + ((size_t)g * D.nslot + slot0) * kImgs : nullptr;
-        ps_prev = ps + (size_t)(g * D.nseg + s) * 2 * kImgs;
+        ps_prev = ps + (size_t)(g * D.nseg + __builtin_amdgcn_readfirstlane(sg.x)) * 2 * kImgs;   // its line: ray order
         wave_lds_fence();                                                             // records are overwritten next
         sg = sg1; sg1 = sg2;
     }
@@ -261,22 +261,19 @@ __global__ __launch_bounds__(256) void bm_combine_fwd_kernel(BmDims D, const flo
     const double2 pre = ray_pre[q];
     double T = pre.x, S = pre.y;
     const float *base = ps + (size_t)g * D.nseg * 2 * kImgs + l;
-    // the ray's segment ids are fetched 32 at a time (one per lane of the half-wave) and handed round with shuffles;
-    // the (P, S) lines of four segments are in flight together
-    for (int jb = j0; jb < j1; jb += 32) {
-        const int cnt = (j1 - jb < 32) ? j1 - jb : 32;
-        const int myid = l < cnt ? ray_seg[jb + l] : 0;
-        for (int t = 0; t < cnt; t += 4) {
-            float P[4], Sg[4];
+    // the ray's segments are neighbours in the scratch buffer (line = ray-order position): contiguous 256-byte records,
+    // eight in flight together
+    for (int jb = j0; jb < j1; jb += 8) {
+        float P[8], Sg[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int s = __shfl(myid, t + u, 32);
-                const bool on = t + u < cnt;
-                P[u] = on ? base[(size_t)s * 2 * kImgs] : 1.f;
-                Sg[u] = on ? base[(size_t)s * 2 * kImgs + kImgs] : 0.f;
-            }
+        for (int u = 0; u < 8; u++) {
+            const int j = min(jb + u, j1 - 1);
+            P[u] = base[(size_t)j * 2 * kImgs];
+            Sg[u] = base[(size_t)j * 2 * kImgs + kImgs];
+        }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 8; u++) {
+            if (jb + u < j1) {
                 S += T * (double)Sg[u];
                 T *= (double)P[u];
             }
@@ -330,7 +327,6 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
         // Buffer addressing (wave-uniform descriptor of this group's slice + a 32-bit byte offset per line): one
         // register per line address instead of two.
         const int cnt = j1 - j0;
-        const int myid = l < cnt ? ray_seg[j0 + l] : 0;
         const unsigned bytes = (unsigned)D.nseg * (2 * kImgs * 4);
         const auto r_ps = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ps) + (size_t)g * D.nseg * 2 * kImgs, 0, bytes, 0x00020000);
         const auto r_tr = __builtin_amdgcn_make_buffer_rsrc(tr + (size_t)g * D.nseg * 2 * kImgs, 0, bytes, 0x00020000);
@@ -338,7 +334,7 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
         float P[kRayRegs], Sg[kRayRegs];
 #pragma unroll
         for (int u = 0; u < kRayRegs; u++) {
-            o[u] = (__shfl(myid, u < cnt ? u : 0, 32) * (2 * kImgs) + l) * 4;   // (an index beyond the ray re-reads its first line)
+            o[u] = ((j0 + (u < cnt ? u : 0)) * (2 * kImgs) + l) * 4;      // (an index beyond the ray re-reads its first line)
             P[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_ps, o[u], 0, 0));
             Sg[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_ps, o[u] + kImgs * 4, 0, 0));
         }
@@ -363,13 +359,12 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
     double T = ray_pre[q].x;
     for (int jb = j0; jb < j1; jb += 32) {                               // forward: g T at every segment's start
         const int cnt = (j1 - jb < 32) ? j1 - jb : 32;
-        const int myid = l < cnt ? ray_seg[jb + l] : 0;
         for (int t = 0; t < cnt; t += 4) {
             float P[4];
             size_t o[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                o[u] = gb + (size_t)__shfl(myid, t + u, 32) * 2 * kImgs;
+                o[u] = gb + (size_t)(jb + min(t + u, cnt - 1)) * 2 * kImgs;
                 P[u] = t + u < cnt ? ps[o[u]] : 1.f;
             }
 #pragma unroll
@@ -382,13 +377,12 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
     double Rr = 1.0;                                                      // behind the last sample: prod(1-p) * 1
     for (int je = j1; je > j0; je -= 32) {                                // reverse: R behind every segment's end
         const int cnt = (je - j0 < 32) ? je - j0 : 32;
-        const int myid = l < cnt ? ray_seg[je - 1 - l] : 0;              // lane t holds segment je - 1 - t
         for (int t = 0; t < cnt; t += 4) {
             float P[4], Sg[4];
             size_t o[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                o[u] = gb + (size_t)__shfl(myid, t + u, 32) * 2 * kImgs;
+                o[u] = gb + (size_t)(je - 1 - min(t + u, cnt - 1)) * 2 * kImgs;
                 const bool on = t + u < cnt;
                 P[u] = on ? ps[o[u]] : 0.f;
                 Sg[u] = on ? ps[o[u] + kImgs] : 0.f;

@@ -16,7 +16,8 @@ every brick PULLS the samples that touch one of its voxels and accumulates them 
 (plain stores, every voxel of grad_vox written exactly once).
 
 Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h, "batch-minor tile renderer":
-  segs      int32 [nseg,4]   (ray q, first sample k0, length L, slot of the first sample)   sorted by (brick, q, k0)
+  segs      int32 [nseg,4]   (line of the segment in the per-segment scratch buffers = its position in RAY order, first
+                              sample k0, length L, slot of the first sample)   sorted by (brick, ray, k0)
   rec_f     int32 [S,12]     per sample slot: (tile byte offset, depth_weight[k] bits, 0, 0,
                               w(x0y0z0), w(x1y0z0), w(x0y1z0), w(x1y1z0), w(x0y0z1), w(x1y0z1), w(x0y1z1), w(x1y1z1));
                               S = samples + SLOT_PAD: the last SLOT_PAD slots belong to no sample (all zero) -- the kernels
@@ -26,7 +27,7 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
   fwd_rows  int32 [rows,4]   (brick, seg begin, seg end, flag); flag 2 = padding row (skipped); order: see _xcd_order
   ray_ptr   int32 [RR+1], ray_seg int32 [nseg]   the segments of every ray in sample order
   ray_pre   float64 [RR,2]   (P0, S0) of the samples before the ray enters the volume (p = 1e-5 each)
-  ent       int32 [E,4]      backward listing: (segment, slot of the segment's first sample,
+  ent       int32 [E,4]      backward listing: (the segment's scratch line = ray-order position, slot of its first sample,
                               i0 | i1 << 6 | L << 12 | k0 << 18, rec_b slot of sample i0): samples i0..i1-1 of the
                               segment touch the brick of the row
   rec_b     int32 [SB,12]    (tile byte offset in the brick's own fp64 tile -- may point outside it for corners the
@@ -123,7 +124,10 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     rank = np.empty(nseg, np.int64)
     rank[order] = np.arange(nseg)
     slot0 = np.concatenate(([0], np.cumsum(seg_len[order])))[:-1]           # by forward position
-    segs = np.stack([seg_q[order], seg_k0[order], seg_len[order], slot0.astype(np.int32)], 1).astype(np.int32)
+    # column 0: the segment's position in RAY order (rank[.] inverted) = its line in the per-segment scratch buffers
+    # (P, S) / (g T, R): a ray's segments are neighbours there, so the per-ray passes stream contiguous memory
+    rpos = order.astype(np.int32)                                            # forward position -> ray-order position
+    segs = np.stack([rpos, seg_k0[order], seg_len[order], slot0.astype(np.int32)], 1).astype(np.int32)
     # per-ray segment lists, in sample order (ray-order segments are already sorted by (q, k0))
     ray_seg = rank.astype(np.int32)
     ray_ptr = np.searchsorted(seg_q, np.arange(RR + 1), side="left").astype(np.int32)
@@ -189,7 +193,7 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     assert ((i_last - i_first + 1) == gcount).all(), "a brick's share of a segment is not contiguous"
     ent_seg = ((keys[gstart] >> 8) & 0xFFFFFFFF).astype(np.int64)
     pack = i_first | ((i_last + 1) << 6) | (segs[ent_seg, 2] << 12) | (segs[ent_seg, 1] << 18)
-    ent = np.stack([ent_seg.astype(np.int32), segs[ent_seg, 3], pack.astype(np.int32), gstart.astype(np.int32)], 1).astype(np.int32)
+    ent = np.stack([segs[ent_seg, 0], segs[ent_seg, 3], pack.astype(np.int32), gstart.astype(np.int32)], 1).astype(np.int32)
     ent_brick = (keys[gstart] >> 40).astype(np.int64)
     # rec_b of every listed sample, relative to the pulling brick
     s_id, dcode = whos[:, 0], whos[:, 1]

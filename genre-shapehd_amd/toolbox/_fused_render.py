@@ -193,16 +193,18 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
     # keyed on the CONTENTS of the depth_weight buffer (hashed once per address + version, _content_of): no device ->
     # host copy -- and no stream synchronisation, which HIP-graph capture forbids -- while the buffer is untouched
     dw_hash, dw = _content_of(depth_weight)
-    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], dw_hash, str(device), pull)
+    gather = bm_backward_mode() == "gather"
+    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], dw_hash, str(device), pull, gather)
     t = _TABLES.get(key)
     if t is None:
         d64 = dirs64.cpu().numpy()
 
         def build():
-            return _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, pull=pull)
+            return _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, pull=pull,
+                                              gather=gather)
         build.__module__ = _bm_tables.__name__
         np_t = _disk_cached("bm", (tuple(vox_shape[2:]), pull, _bm_tables.ROW_ORDER, _bm_tables.SPLIT_F,
-                                   _bm_tables.SPLIT_B, _bm_tables.MAXSEG), [d64, dw], build)
+                                   _bm_tables.SPLIT_B, _bm_tables.MAXSEG, gather), [d64, dw], build)
         t = {"pull_code": int(np_t["pull"][0]) * 100 + int(np_t["pull"][1]) * 10 + int(np_t["pull"][2])}
         for k, v in np_t.items():
             if k == "pull":
@@ -216,10 +218,12 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
 
 
 def bm_backward_mode():
-    """which backward the batch-minor renderer runs: "gather" (default; bm_gather_kernel) or "scatter"
-    (bm_scatter_kernel, LDS atomics) -- the A/B switch GENRE_BM_BWD, read at every call"""
+    """which backward the batch-minor renderer runs: "scatter" (default; bm_scatter_kernel, LDS fp64 atomics) or
+    "gather" (bm_gather_kernel: voxel sums in registers over per-voxel contribution lists -- measured on MI355X at batch
+    32: no faster; its tables are only built when it is selected) -- the switch GENRE_BM_BWD, read
+    at every call"""
     import os
-    mode = os.environ.get("GENRE_BM_BWD", "gather")
+    mode = os.environ.get("GENRE_BM_BWD", "scatter")
     assert mode in ("gather", "scatter"), "GENRE_BM_BWD must be gather or scatter"
     return mode
 

@@ -280,7 +280,8 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  * vox [N,1,X,Y,Z] with stride[0] == 1 (element (n,x,y,z) at x*sx + y*sy + z*sz + n; e.g. memory order
  * (X,Y,Z,N)).  32 lanes = 32 images of one sample; all geometry comes from tables built once per geometry
  * (genre-shapehd_amd/toolbox/_bm_tables.py: build_bm_tables -- formats are documented there and repeated here):
- *   segs      int32 [nseg,4]  (ray, first sample k0, length L, slot of the first sample); a segment = a run of
+ *   segs      int32 [nseg,4]  (the segment's line in ps_scratch / tr_scratch = its position in RAY order, first sample k0,
+ *                             length L, slot of the first sample); a segment = a run of
  *                             consecutive samples of one ray whose base voxel lies in one 4x8x8-voxel brick (L <= 16);
  *                             sorted by (brick, ray, k0); slots number the in-volume samples in that order
  *   rec_f     int32 [S,12]    per slot: byte offset of the base voxel line in the brick's 5x9x9 x 32-image fp32 tile,
@@ -290,10 +291,12 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *                             that the hardware's in-order load counter can be waited on exactly; what lies past a
  *                             segment's own records / samples is read and never used
  *   fwd_rows  int32 [rows,4]  (brick, seg begin, seg end, 0): one workgroup each; every brick in >= 1 row
- *   ray_ptr   int32 [R*R+1], ray_seg int32 [nseg]: the segments of each ray in sample order
+ *   ray_ptr   int32 [R*R+1], ray_seg int32 [nseg]: the segments of each ray in sample order (ray q owns the scratch
+ *                             lines ray_ptr[q] .. ray_ptr[q+1]-1: the per-ray passes stream contiguous memory; ray_seg -- the
+ *                             segs row of each line -- is part of the table contract, the kernels do not read it)
  *   ray_pre   float64 [R*R,2] viewed as fp32 [R*R,4]: (transmittance, partial sum) of the samples before the ray
  *                             enters the volume (p = 1e-5 each)
- *   ent       int32 [E,4]     (segment, slot of its first sample, i0 | i1<<6 | L<<12 | k0<<18, rec_b slot of sample i0):
+ *   ent       int32 [E,4]     (the segment's scratch line, slot of its first sample, i0 | i1<<6 | L<<12 | k0<<18, rec_b slot of sample i0):
  *                             samples i0..i1-1 of the segment have a
  *                             corner inside the brick of the row that lists the entry
  *   rec_b     int32 [SB,12]   byte offset in the brick's own 4x8x8 x 32-image fp64 tile, ownership bits
@@ -302,7 +305,8 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *   bwd_rows  int32 [rows,4]  (pull brick, ent begin, ent end, shared): shared = 1 rows add onto pre-zeroed voxels;
  *                             the backward's bricks are pull_brick = 488 (4x8x8 voxels) or 888 (8x8x8), as the tables were built
  * Scratch (caller-allocated, groups = ceil(N/32)):
- *   ps_scratch fp32 [groups*nseg*64]: per segment and image (prod(1-p), sum T p w) -- forward output, backward input
+ *   ps_scratch fp32 [groups*nseg*64]: per segment (in ray order) and image (prod(1-p), sum T p w) -- forward output,
+ *                             backward input
  *   p_stash    fp32 [groups*S*32] or NULL: clamped sample values (negated where the clamp blocks the gradient);
  *              pass it when a backward will follow;  mask int32 [groups*X*Y*Z] (with p_stash and pre_scale != 0):
  *              bit i = image i passes clamp(vox*pre_scale)

@@ -46,14 +46,15 @@ def forward(mod, t, vox, pre_scale=0.0, lo=np.float32(1e-5), hi=np.float32(1 - 1
                 stash[r] = p if (v >= lo and v <= hi) else -p
                 S += T * p * dwk[r]
                 T *= 1.0 - p
-            PS[s] = (T, S)
+            assert t["ray_seg"][q] == s                                 # q = the segment's line = its position in ray order
+            PS[q] = (T, S)
     rr = t["ray_ptr"].shape[0] - 1
     out = np.zeros(rr)
     for q in range(rr):
         T, S = t["ray_pre"][q]
-        for s in t["ray_seg"][t["ray_ptr"][q]:t["ray_ptr"][q + 1]]:
-            S += T * PS[s, 1]
-            T *= PS[s, 0]
+        for j in range(t["ray_ptr"][q], t["ray_ptr"][q + 1]):           # a ray's segments are neighbours in the scratch buffer
+            S += T * PS[j, 1]
+            T *= PS[j, 0]
         out[q] = S + T
     return out, PS, stash, mask
 
@@ -67,7 +68,7 @@ def backward(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
     TR = np.zeros((segs.shape[0], 2))
     rr = t["ray_ptr"].shape[0] - 1
     for q in range(rr):
-        ids = t["ray_seg"][t["ray_ptr"][q]:t["ray_ptr"][q + 1]]
+        ids = range(t["ray_ptr"][q], t["ray_ptr"][q + 1])
         T = t["ray_pre"][q][0]
         for s in ids:
             TR[s, 0] = g[q] * T
@@ -87,9 +88,10 @@ def backward(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
             continue
         tile = np.zeros(BX * BY * BZ)
         for e in range(e0, e1):
-            s, slot0, pk, rs = t["ent"][e]
+            s, slot0, pk, rs = t["ent"][e]                               # s: the segment's scratch line (ray order)
             i0, i1, L, k0 = pk & 63, (pk >> 6) & 63, (pk >> 12) & 63, (pk >> 18) & 255
-            assert (segs[s][1], segs[s][2], segs[s][3]) == (k0, L, slot0)
+            sf = t["ray_seg"][s]
+            assert (segs[sf][0], segs[sf][1], segs[sf][2], segs[sf][3]) == (s, k0, L, slot0)
             p = stash[slot0:slot0 + L]
             Tg, Rr = TR[s]
             c = np.zeros(L)
@@ -142,7 +144,7 @@ def backward_gather(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
     TR = np.zeros((segs.shape[0], 2))
     rr = t["ray_ptr"].shape[0] - 1
     for q in range(rr):
-        ids = t["ray_seg"][t["ray_ptr"][q]:t["ray_ptr"][q + 1]]
+        ids = range(t["ray_ptr"][q], t["ray_ptr"][q + 1])
         T = t["ray_pre"][q][0]
         for s in ids:
             TR[s, 0] = g[q] * T
@@ -170,7 +172,8 @@ def backward_gather(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
             for e in range(e0, e1):
                 s, slot0, pk, ls0 = t["g_ent"][e]
                 i0, i1, L, k0 = pk & 63, (pk >> 6) & 63, (pk >> 12) & 63, (pk >> 18) & 255
-                assert (segs[s][1], segs[s][2], segs[s][3]) == (k0, L, slot0)
+                sf = t["ray_seg"][s]
+                assert (segs[sf][0], segs[sf][1], segs[sf][2], segs[sf][3]) == (s, k0, L, slot0)
                 p = stash[slot0:slot0 + L]
                 Tg, Rr = TR[s]
                 cT = np.zeros(L)

@@ -78,13 +78,16 @@ def test_bm_listing_names_every_touching_sample_once_per_brick(res, sph, zr, pul
     bs = pull
     segs = t["segs"]
     # segments: consecutive samples of one ray, every in-volume sample in exactly one, per ray in order
+    # column 0 of a segment = its line in the per-segment scratch buffers = its position in RAY order
+    ray_of = np.searchsorted(t["ray_ptr"], segs[:, 0], side="right") - 1
     seen = np.zeros(inside.shape, int)
-    for q, k0, L, slot0 in segs:
+    for q, (_, k0, L, slot0) in zip(ray_of, segs):
         seen[q, k0:k0 + L] += 1
     assert np.array_equal(seen, inside.astype(int))
+    assert sorted(segs[:, 0].tolist()) == list(range(segs.shape[0]))
     for q in range(sph * sph):
         ids = t["ray_seg"][t["ray_ptr"][q]:t["ray_ptr"][q + 1]]
-        assert (segs[ids, 0] == q).all() and (np.diff(segs[ids, 1]) > 0).all()
+        assert (segs[ids, 0] == np.arange(t["ray_ptr"][q], t["ray_ptr"][q + 1])).all() and (np.diff(segs[ids, 1]) > 0).all()
         assert segs[ids, 2].sum() == inside[q].sum()
     # expected (brick, sample, corner) triples: corners inside the volume; the -1 corner of a low-side sample is padding
     expect = {}
@@ -103,7 +106,8 @@ def test_bm_listing_names_every_touching_sample_once_per_brick(res, sph, zr, pul
         if shared == B.SKIP:
             continue
         for s_, slot0_, pk, rs in t["ent"][e0:e1]:
-            q, k0, L, slot0 = segs[s_]
+            _, k0, L, slot0 = segs[t["ray_seg"][s_]]                     # s_: the segment's scratch line (ray order)
+            q = ray_of[t["ray_seg"][s_]]
             i0, i1 = pk & 63, (pk >> 6) & 63
             assert ((pk >> 12) & 63, (pk >> 18) & 255, slot0_) == (L, k0, slot0)
             assert 0 <= i0 < i1 <= L

@@ -9,6 +9,7 @@ import shutil
 import subprocess
 import sys
 
+os.environ.setdefault("GENRE_BM_BWD", "gather")          # the gather tables are only built when it is selected
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "genre-shapehd_amd", "csrc", "libgenre_hip.so")
 

@@ -4,6 +4,8 @@ usage: python tools/time_bm_bwd.py [B]"""
 import os
 import sys
 
+os.environ.setdefault("GENRE_BM_BWD", "gather")          # the gather tables are only built when it is selected
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
