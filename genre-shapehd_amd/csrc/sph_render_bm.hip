@@ -704,7 +704,7 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
 
     auto header = [&](const int4 ck, int r) {                          // the entry of this half-wave in round r (pk = 0: none)
         const int e = ck.x + r * kGHW + hw;
-        int4 h = ents[min(e, ck.y - 1)];
+        int4 h = ents[max(min(e, ck.y - 1), 0)];                        // (a chunk without entries: the table's first row, unused)
         if (e >= ck.y) h.z = 0;
         return h;
     };
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
     };
     int row_i = blockIdx.x;
     if (row_i >= nrows) return;
-    int4 row = rows[row_i];
+    int4 row = rows[row_i];                                            // (every row has at least one chunk: _gather_tables)
     int c = row.y;
     int4 ck = chunks[c];                                               // (entry begin, entry end, blob begin, blob words)
     GEntry A, B;

@@ -332,7 +332,7 @@ def _gather_tables(pnb, ent, ent_brick, gstart, gcount, i_first, rel, own, wl, e
     words = 256 + 2 * tot
     base = np.concatenate(([0], np.cumsum(words)))
     assert base[-1] < (1 << 31)
-    g_blob = np.zeros(int(base[-1]) + 4, np.int32)
+    g_blob = np.zeros(int(base[-1]) + 256 + 4, np.int32)                  # + one all-empty blob (below)
     hdr_pos = (base[:-1, None] + np.arange(256)[None, :]).reshape(-1)
     g_blob[hdr_pos] = (starts_h | (padded_h << 16)).reshape(-1).astype(np.int32)
     o = np.argsort(keys, kind="stable")
@@ -348,6 +348,12 @@ def _gather_tables(pnb, ent, ent_brick, gstart, gcount, i_first, rel, own, wl, e
     rb = np.searchsorted(chunk_brick, np.arange(pnb), side="left")
     re_ = np.searchsorted(chunk_brick, np.arange(pnb), side="right")
     g_rows = _split_rows(rb, re_, np.concatenate(([0], np.cumsum(lis_c))), split_b, 1)
+    # a brick that no sample touches still has to be written (zeros): its row gets one chunk without entries, whose blob
+    # is 256 empty lists -- the kernel walks the chunks of its rows as one stream and never meets a row without one
+    g_chunks = np.concatenate((g_chunks, np.asarray([[0, 0, int(base[-1]), 256]], np.int32)))
+    empty = (g_rows[:, 1] == g_rows[:, 2]) & (g_rows[:, 3] != SKIP)
+    g_rows[empty, 1] = nC
+    g_rows[empty, 2] = nC + 1
     return dict(g_ent=g_ent, g_chunks=g_chunks, g_blob=g_blob, g_rows=g_rows)
 
 

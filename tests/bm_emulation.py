@@ -164,6 +164,7 @@ def backward_gather(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
         if shared == mod.SKIP:
             continue
         tile = np.zeros(BX * BY * BZ)
+        assert c1 > c0, "every row has at least one chunk (a brick that nothing touches: one without entries)"
         for c in range(c0, c1):
             e0, e1, b0, nw = t["g_chunks"][c]
             sbuf = np.full(mod.GATHER_CH, np.nan)                       # a line that no entry fills must never be read
