@@ -124,7 +124,13 @@ def test_genre_joint_step_gradient_reaches_marrnet1_like_the_cpu_chain(genre, or
         gradient on both sides because every occupied voxel saturates the x50 clamp, depth_pred_with_sph_inpaint.py:124)
         plus the Chamfer term -- per pixel.  The geometric ops contain floor() decisions, so the two chains may put a
         few points into neighbouring voxels: the fraction of pixels that differ is asserted, the rest must match;
-    (b) the product's train step (all loss terms) against the CPU chain, every trainable tensor of the three modules."""
+    (b) the product's train step (all loss terms) against the CPU chain, every trainable tensor of the three modules.
+
+    BatchNorm runs on its running statistics here (eval mode; the gradients still reach every weight).  With batch
+    statistics over TWO samples the refiner's bottleneck layers (1^3 ... 4^3 voxels) normalise two numbers to +-1: the
+    handful of voxels that the two chains' floor() decisions put elsewhere then changes the refiner's output by 5 % and
+    its input gradient by 100 % (measured, first version of this test) -- chaos of the test configuration, not of the
+    ops; the train-mode BatchNorm path itself is covered by the ShapeHD and WGAN-GP steps above."""
     import torch.nn.functional as F
     from genre_shapehd_amd import train as T
     from genre_shapehd_amd.callers import AbsDepth
@@ -134,7 +140,7 @@ def test_genre_joint_step_gradient_reaches_marrnet1_like_the_cpu_chain(genre, or
     from oracle.torch_oracle import GenReCPU
     torch.manual_seed(7)
     opt = GenReOptions(joint_train=True)
-    cpu = _plausible_geometry(GenReNet(opt)).train()
+    cpu = _plausible_geometry(GenReNet(opt)).eval()
     gpu = copy.deepcopy(cpu).to(dev)
     inputs, gt = T.genre_batch(2, "cpu", seed=23)
     idx = torch.randint(0, 256 * 256, (2, 2048), generator=torch.Generator().manual_seed(9))
@@ -142,30 +148,34 @@ def test_genre_joint_step_gradient_reaches_marrnet1_like_the_cpu_chain(genre, or
     to = lambda ns, d: type(ns)(**{k: v.to(d) for k, v in vars(ns).items()})        # noqa: E731
     in_g, gt_g = to(inputs, dev), to(gt, dev)
     chain = GenReCPU(oracle, cpu.depth_and_inpaint.net1, cpu.depth_and_inpaint.net2, cpu.refine_net)
+    stages = ("pred_voxel", "proj_depth", "pred_sph_full", "depth")
 
-    # (a) projection path only: d(voxel + surface + Chamfer) / d(predicted depth map)
+    # ---- CPU: one forward; (a) the projection-path loss, (b) the full joint loss
     pred_c = chain.forward(inputs)
     pts = T.depth_to_points(pred_c["abs_depth"], inputs.silhou, idx=idx).contiguous()
     d1, d2 = chain.nnd(pts, gt.cloud.contiguous())
-    l_c = genre_loss(pred_c, gt, opt, joint=False) + w_ch * (d1.mean() + d2.mean())
-    stages = ("pred_voxel", "pred_proj_depth", "pred_proj_sph_full", "proj_depth", "pred_sph_full", "depth")
-    gs_c = torch.autograd.grad(l_c, [pred_c[k] for k in stages], retain_graph=True, allow_unused=True)
-    gd_c = gs_c[-1]
+    ch_c = w_ch * (d1.mean() + d2.mean())
+    l_c = genre_loss(pred_c, gt, opt, joint=False) + ch_c
+    gs_c = torch.autograd.grad(l_c, [pred_c[k] for k in stages], retain_graph=True)
+    gsph_c, = torch.autograd.grad(F.mse_loss(pred_c["pred_sph_full"], gt.spherical_object), pred_c["depth"], retain_graph=True)
+    loss_c = genre_loss(pred_c, gt, opt, joint=True) + ch_c
+    loss_c.backward()
+    g_cpu = grads(cpu)
+
+    # ---- GPU (a)
     pred_g = gpu(in_g)
     depth = AbsDepth.apply(pred_g["depth"], pred_g["depth_minmax"], in_g.silhou, SCALE_25D)
     e1, e2 = nndistance(T.depth_to_points(depth, in_g.silhou, idx=idx.to(dev)).contiguous(), gt_g.cloud.contiguous())
     l_g = genre_loss(pred_g, gt_g, opt, joint=False) + w_ch * (e1.mean() + e2.mean())
-    gs_g = torch.autograd.grad(l_g, [pred_g[k] for k in stages], retain_graph=True, allow_unused=True)
-    gd_g = gs_g[-1]
+    gs_g = torch.autograd.grad(l_g, [pred_g[k] for k in stages], retain_graph=True)
+    gsph_g, = torch.autograd.grad(F.mse_loss(pred_g["pred_sph_full"], gt_g.spherical_object), pred_g["depth"])
     for k, a, b in zip(stages, gs_g, gs_c):                          # where along the chain the two sides part, if they do
-        if a is None or b is None:
-            print("   d loss / d %-18s gpu %s cpu %s" % (k, "none" if a is None else "ok", "none" if b is None else "ok"))
-            continue
-        dn = (a.cpu().double() - b.double()).norm().item()
-        print("   d loss / d %-18s |cpu| %.3e  |gpu - cpu| / |cpu| %.2e  (forward values: %.2e)" % (
-            k, b.double().norm().item(), dn / max(b.double().norm().item(), 1e-300),
+        nb = max(b.double().norm().item(), 1e-300)
+        print("   d loss / d %-14s |cpu| %.3e  |gpu - cpu| / |cpu| %.2e  (forward values: %.2e)" % (
+            k, nb, (a.cpu().double() - b.double()).norm().item() / nb,
             ((pred_g[k].detach().cpu().double() - pred_c[k].detach().double()).norm() / pred_c[k].detach().double().norm()).item()))
     assert abs(l_g.item() - l_c.item()) <= 1e-4 * max(1.0, abs(l_c.item())), (l_g.item(), l_c.item())
+    gd_g, gd_c = gs_g[-1], gs_c[-1]
     top = gd_c.abs().max().item()
     live = (gd_c != 0).sum().item()
     assert top > 0 and live > 10000, (top, live)                     # the gradient really arrives through cam_bp
@@ -177,22 +187,13 @@ def test_genre_joint_step_gradient_reaches_marrnet1_like_the_cpu_chain(genre, or
     assert off <= 0.005 * live, (off, live)
     assert rel_l2 <= 0.05, rel_l2
     # render_spherical's branch: exactly zero on the CPU chain (saturated clamp), and on the GPU
-    gs_c, = torch.autograd.grad(F.mse_loss(pred_c["pred_sph_full"], gt.spherical_object), pred_c["depth"])
-    gs_g, = torch.autograd.grad(F.mse_loss(pred_g["pred_sph_full"], gt_g.spherical_object), pred_g["depth"])
-    assert gs_c.abs().max().item() == 0 and gs_g.abs().max().item() == 0
-    del pred_c, pred_g, l_c, l_g
+    assert gsph_c.abs().max().item() == 0 and gsph_g.abs().max().item() == 0
+    del pred_g, l_g, gs_g
 
-    # (b) the product's train step (lr 0 keeps the gradients in place) against the CPU chain with the same loss
+    # ---- GPU (b): the product's train step (lr 0 keeps the gradients in place)
     optim = torch.optim.SGD(gpu.parameters(), lr=0.0)
     loss_g = T.genre_train_step(gpu, optim, in_g, gt_g, opt, chamfer_weight=w_ch, chamfer_idx=idx.to(dev))
     g_gpu = grads(gpu)
-    pred = chain.forward(inputs)
-    loss_c = genre_loss(pred, gt, opt, joint=True)
-    pts = T.depth_to_points(pred["abs_depth"], inputs.silhou, idx=idx).contiguous()
-    d1, d2 = chain.nnd(pts, gt.cloud.contiguous())
-    loss_c = loss_c + w_ch * (d1.mean() + d2.mean())
-    loss_c.backward()
-    g_cpu = grads(cpu)
     assert abs(loss_g.item() - loss_c.item()) <= 1e-4 * max(1.0, abs(loss_c.item())), (loss_g.item(), loss_c.item())
     key = "depth_and_inpaint.net1.decoder_depth.4.3.weight"
     a, b = g_gpu[key].double(), g_cpu[key].double()
