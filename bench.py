@@ -239,6 +239,14 @@ def kernel_table(G, dev, B):
             layer = G.Camera_back_projection_layer(batch_minor=True).to(dev)
             with torch.no_grad():
                 proj_bm = layer(d)
+            # the camera forward the batch-minor STEP runs: image-minor volumes have no contiguous z rows, so it is the
+            # three-launch path (fill, tile scatter with global float atomics, per-pixel normalise), not cam_brick_kernel
+            cnt_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
+            t = event_time_us(lambda: cam_bp_lib.back_projection_forward_shifted(d, cd, fl, proj_bm, cnt_bm), iters, 5)
+            rows["cam_bp_fwd_bm"] = dict(us=t, bytes=B * BYTES_CAM_FWD,
+                                         kernels="fill2_vec4_kernel+scatter_tile_kernel<false>+normalise_tile_kernel<false>",
+                                         pmc=["fill2_vec4_kernel", "scatter_tile_kernel<false>", "normalise_tile_kernel<false>"],
+                                         src=("common.hpp", "cam_bp.hip"))
             TB = _fused_render.bm_tables_for(proj_bm.shape, dev, mod._dirs64, mod.depth_weight)
             groups = -(-B // 32)
             ps = torch.empty((groups * TB["segs"].shape[0] * 64,), device=dev)
@@ -685,7 +693,7 @@ def main():
         if not fused:
             in_step = ["cam_bp_fwd", "calc_prob_fwd", "calc_prob_bwd_fused"]
         elif bm:
-            in_step = ["cam_bp_fwd", "render_fwd_bm", "render_bwd_bm"]
+            in_step = ["cam_bp_fwd_bm", "render_fwd_bm", "render_bwd_bm"]
         else:
             in_step = ["cam_bp_fwd", "render_fwd_fused", "render_bwd_fused"]
         dom_name = max(in_step, key=lambda k: rows[k]["us"])
@@ -717,7 +725,8 @@ def main():
             "m2_batch1": {"what": "cam_bp fwd + calc_prob fwd at batch 1 (BASELINE.json: >= 40 % of 8 TB/s), HIP-graph replay",
                           "achieved": b1["GBs"], "unit": "GB/s", "frac": b1["frac"], "us_per_image": b1["us_per_image"],
                           "target_frac": 0.40, "two_streams": b1.get("two_streams")},
-            "kernels": {k: {"us": round(v["us"], 2), "GBs": round(v["GBs"], 1)} for k, v in rows.items()},
+            "kernels": {k: {"us": round(v["us"], 2), "GBs": round(v["GBs"], 1), "in_step": k in in_step}
+                        for k, v in rows.items()},
             "nnd": {"what": "Chamfer forward, both directions, %d x 2048 x 2048; 8 fp32 flops per pair, no fma" % B,
                     "TFLOPs": rows["nnd_fwd"]["TFLOPs"], "peak": 157.3, "frac": rows["nnd_fwd"]["frac_fp32_valu"],
                     "pairs_per_s": rows["nnd_fwd"]["pairs"] / rows["nnd_fwd"]["us"] * 1e6,

@@ -61,3 +61,31 @@ def digest(out):
         step = max(1, f.numel() // 4096)
         res[k] = (f[::step].float().numpy(), float(f.sum()), float(f.abs().sum()))
     return res
+
+
+def genre_plausible_geometry(state):
+    """key-seeded weights make the GenRe networks emit garbage geometry (depths of ~1e4, a spherical map of ~1e3).
+    These edits -- applied to a state_dict by KEY, so to the reference's classes and to ours alike -- keep every network
+    active but put the predicted surfaces inside the voxel cube: MarrNet-1 predicts a near-constant relative depth over the
+    range [1.9, 2.4], the inpainting network a spherical map of ~0.6 (a sphere of radius 0.4 after `1 - x`)."""
+    import torch
+    with torch.no_grad():
+        state["depth_and_inpaint.net1.decoder_depth.4.3.weight"].mul_(1e-5)
+        state["depth_and_inpaint.net1.decoder_minmax.9.weight"].zero_()
+        state["depth_and_inpaint.net1.decoder_minmax.9.bias"].copy_(torch.tensor([1.9, 2.4]))
+        state["depth_and_inpaint.net2.decoder_spherical.4.1.weight"].mul_(1e-3)
+        state["depth_and_inpaint.net2.decoder_spherical.4.1.bias"].fill_(1.0)
+        state["depth_and_inpaint.net2.deconv2.weight"].fill_(0.6 / 1024)
+        state["depth_and_inpaint.net2.decoder_spherical.4.3.weight"].fill_(0.6 / 1024)    # (the same tensor under its second name)
+    return state
+
+
+def genre_inputs(n=1, seed=9):
+    """rgb [n,3,256,256] in [0,1) and a disc silhouette (x100, the data pipeline's scale_25d)"""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(seed)
+    rgb = torch.from_numpy(rng.uniform(0, 1, (n, 3, 256, 256)).astype(np.float32))
+    ax = np.linspace(-1, 1, 256)
+    sil = ((ax[:, None] ** 2 + ax[None, :] ** 2) < 0.5).astype(np.float32)[None, None].repeat(n, 0) * 100
+    return rgb, torch.from_numpy(sil)

@@ -118,27 +118,20 @@ def test_checkpoint_round_trip_keeps_the_training_hyperparameters(tmp_path):
 
 def test_genre_model_state_dict_has_the_reference_keys():
     """models/genre_full_model.py:104-113 + depth_pred_with_sph_inpaint.py:97-105 + marrnet1.py:137-154: the key set is
-    the composition of the network fixtures generated from the reference's classes, the min/max head, the renderer's
-    two buffers and the `grid` buffer"""
+    the composition of the per-network fixtures (generated from the reference's network classes) -- and, as a whole, the
+    fixture generated from the reference's own GenRe model class (tests/test_reference_checkpoint.py)"""
     import genre_shapehd_amd  # noqa: F401
     from genre_shapehd_amd.models import GenReNet
     with open(os.path.join(ROOT, "tests", "golden", "networks_keys.json")) as f:
         nk = json.load(f)
-    want = {"grid": [1, 1, 128, 128, 3], "depth_and_inpaint.render_spherical.depth_weight": [256],
-            "depth_and_inpaint.render_spherical.grid": [128, 128, 256, 3]}
-    want.update({"depth_and_inpaint.net1." + k: v for k, v in nk["uresnet_net"].items()})
-    want.update({"depth_and_inpaint.net2." + k: v for k, v in nk["uresnet_inpaint"].items()})
-    want.update({"refine_net." + k: v for k, v in nk["unet3d"].items()})
-    head = {"0": [512, 512, 2, 2], "1": [512, 512, 4, 4], "3": [256, 512], "6": [128, 256], "9": [2, 128]}
-    for i, shp in head.items():
-        want["depth_and_inpaint.net1.decoder_minmax.%s.weight" % i] = shp
-        want["depth_and_inpaint.net1.decoder_minmax.%s.bias" % i] = shp[:1]
-    for i, c in (("4", 256), ("7", 128)):
-        for name in ("weight", "bias", "running_mean", "running_var"):
-            want["depth_and_inpaint.net1.decoder_minmax.%s.%s" % (i, name)] = [c]
-        want["depth_and_inpaint.net1.decoder_minmax.%s.num_batches_tracked" % i] = []
+    with open(os.path.join(ROOT, "tests", "golden", "genre_reference_keys.json")) as f:
+        full = json.load(f)
     got = {k: list(v.shape) for k, v in GenReNet().state_dict().items()}
-    assert got == want
+    assert got == full
+    for prefix, name in (("depth_and_inpaint.net1.", "uresnet_net"), ("depth_and_inpaint.net2.", "uresnet_inpaint"),
+                         ("refine_net.", "unet3d")):
+        for k, v in nk[name].items():
+            assert full[prefix + k] == v, prefix + k
 
 
 def _gan_worker(rank, world, port, ret):
