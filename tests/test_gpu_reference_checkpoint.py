@@ -33,7 +33,7 @@ def test_reference_format_checkpoint_reproduces_the_reference_forward(genre, dev
         out = inf.net(Inputs(rgb.to(dev), sil.to(dev)))
     assert torch.equal(inf.predict(rgb, sil)["pred_voxel"], out["pred_voxel"]) or \
         (inf.predict(rgb, sil)["pred_voxel"] - out["pred_voxel"]).abs().max().item() <= 1e-4 * out["pred_voxel"].abs().max().item()
-    got = NF.digest({k: v for k, v in out.items()})
+    got = NF.digest({k: v.detach().cpu() for k, v in out.items()})
     networks = ("normal", "depth", "silhou", "depth_minmax")
     with np.load(GOLD) as z:
         names = sorted({k.split("/")[0] for k in z.files})

@@ -208,8 +208,9 @@ def test_clamp_boundary_gradient_is_characterised(genre, oracle, dev):
     decided by that last bit: ATen's summation order and ours disagree on some samples.  This test gives the
     deviation a number on the real chain (analytic sphere depth -> cam_bp -> shift -> x50 -> clamp): the forward maps
     agree to 1e-5, and the gradient w.r.t. the clamped volume differs from the reference's fp32 chain by more than
-    1e-5 * max(1, |g|) on a bounded FRACTION of the voxels (asserted; measured and printed), all of them voxels that a
-    bound-valued sample touches -- everywhere else the two agree."""
+    1e-5 * max(1, |g|) on a bounded FRACTION of the voxels (asserted; measured on MI355X: 254 of 2 097 152 voxels =
+    0.012 %, worst 9e-5, while the reference gradient is non-zero on 1.8 M voxels) -- everywhere else the two agree.
+    (Both bounds take part: the empty voxels hold exactly 1e-5, so the flips are not confined to the solid.)"""
     from oracle.torch_oracle import RenderSphericalCPU
     d = inputs.sphere_depth(noise_seed=2)
     fl, cd = inputs.cam_params(1)
@@ -229,11 +230,9 @@ def test_clamp_boundary_gradient_is_characterised(genre, oracle, dev):
     err = (gk - gr).abs() / gr.abs().clamp(min=1.0)
     differ = err > TOL
     frac = differ.float().mean().item()
-    solid = torch.from_numpy(vol == np.float32(1 - 1e-5))
-    # voxels within one voxel of the solid (the only ones a bound-valued interpolation can reach)
-    near = torch.nn.functional.max_pool3d(solid.float(), 3, 1, 1) > 0
     print("clamp-boundary gradient: %d of %d voxels (%.4f %%) differ from the fp32 reference chain by > 1e-5; "
-          "worst %.2e; %d of them outside the solid's 1-voxel neighbourhood; reference gradient non-zero on %d voxels"
-          % (int(differ.sum()), differ.numel(), 100 * frac, err.max().item(), int((differ & ~near).sum()), int((gr != 0).sum())))
-    assert (differ & ~near).sum().item() == 0          # away from the bound-valued samples: agreement
-    assert frac <= 0.02, frac                          # ... and the deviation stays a small, bounded set
+          "worst %.2e; reference gradient non-zero on %d voxels"
+          % (int(differ.sum()), differ.numel(), 100 * frac, err.max().item(), int((gr != 0).sum())))
+    assert (gr != 0).sum().item() > 1000000             # a real gradient field, not a trivially equal one
+    assert frac <= 1e-3, frac                          # the deviation is a small, bounded set of voxels ...
+    assert err.max().item() <= 1e-3, err.max().item()  # ... by a bounded amount
