@@ -693,8 +693,8 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
     const int g = blockIdx.y, n0 = g * kImgs;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), hw = wave * 2 + half;
-    const int lx = wave >> 1;
-    // voxel v of this half-wave: (lx, ly, lz) = (wave >> 1, (wave & 1) * 4 + (v >> 2), 2 * (v & 3) + half)
+    // voxel v of this half-wave: lx = v >> 2, lz = 2 (v & 3) + half, ly = (wave - 2 (v & 3) - 4 lx) mod 8 -- the waves
+    // interleave the brick (a chunk's contributions concentrate on a part of it; toolbox/_bm_tables.py: hidx)
     for (int i = tid; i < kGDwWords; i += kGThreads) dwl[i] = dw[min(i, D.ZR - 1)];
     const float *stash_g = stash + (size_t)g * D.nslot * kImgs + l;
     const float *tr_g = tr + (size_t)g * D.nseg * 2 * kImgs + l;
@@ -729,20 +729,28 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
         const bool uneven = __builtin_amdgcn_readlane(L, 32) != Lmax;  // ... and usually they are equally long
         float ce[kMaxSeg];
         float Tg = e.T, Rr = e.R;
+        if (uneven) {                                                   // the shorter entry of the wave: no-ops beyond its end
 #pragma unroll
-        for (int j = 0; j < kMaxSeg; j++) {                             // forward: g T_k
-            if (j < Lmax) {
-                if (uneven) e.p[j] = j < L ? e.p[j] : 0.f;              // (the shorter entry of the wave: no-ops beyond its end)
-                ce[j] = Tg;
-                Tg = __builtin_fmaf(-fabsf(e.p[j]), Tg, Tg);
-            }
+            for (int j = 0; j < kMaxSeg; j++) e.p[j] = j < L ? e.p[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxSeg; j++) {                             // forward: g T_k  (four at a time up to the longer entry's end)
+            if ((j & 3) == 0 && j >= Lmax) break;
+            ce[j] = Tg;
+            Tg = __builtin_fmaf(-fabsf(e.p[j]), Tg, Tg);
         }
         float *sb = sbuf + (h.w - i0) * kImgs + l;
         const float *wl = dwl + k0;
+        // reverse: R_k; dL/dp_k of the listed samples.  The depth weight of a sample is requested two samples ahead -- it
+        // is an LDS read in front of a serial chain (R), which would otherwise wait for it at every step
+        float wa = wl[kMaxSeg - 1], wb = wl[kMaxSeg - 2];
 #pragma unroll
-        for (int j = kMaxSeg - 1; j >= 0; j--) {                        // reverse: R_k; dL/dp_k of the listed samples
+        for (int j = kMaxSeg - 1; j >= 0; j--) {
+            const float wj = wa;
+            wa = wb;
+            if (j >= 2) wb = wl[j - 2];
             if (j < Lmax) {
-                const float d = wl[j] - Rr;
+                const float d = wj - Rr;
                 Rr = __builtin_fmaf(fabsf(e.p[j]), d, Rr);
                 const float dp = e.p[j] > 0.f ? ce[j] * d : 0.f;        // the clamp passes the gradient where the saved sample is > 0
                 if ((unsigned)(j - i0) < (unsigned)n_l) sb[j * kImgs] = dp;
@@ -849,12 +857,12 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
             unsigned mword = 0u;                                        // clamp mask of voxel (l & 15)
             if (PS && !(GENRE_G_ABL & 16)) {
                 const int v = l & 15;
-                const int x = ox + lx, y = oy + (wave & 1) * 4 + (v >> 2), z = oz + 2 * (v & 3) + half;
+                const int x = ox + (v >> 2), y = oy + ((wave - 2 * (v & 3) - 4 * (v >> 2)) & 7), z = oz + 2 * (v & 3) + half;
                 if (x < D.X && y < D.Y && z < D.Z) mword = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
             }
 #pragma unroll
             for (int v = 0; v < kGVox; v++) {
-                const int ly = (wave & 1) * 4 + (v >> 2), lz = 2 * (v & 3) + half;
+                const int lx = v >> 2, ly = (wave - 2 * (v & 3) - 4 * lx) & 7, lz = 2 * (v & 3) + half;
                 const int x = ox + lx, y = oy + ly, z = oz + lz, n = n0 + l;
                 const unsigned m = PS ? (unsigned)__shfl((int)mword, (lane & 32) | v) : 0u;
                 if (x < D.X && y < D.Y && z < D.Z && n < D.N) {

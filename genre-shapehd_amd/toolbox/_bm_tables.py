@@ -239,7 +239,7 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
 #                                           are sorted by L, longest first (two entries share a wave)
 #   g_chunks  int32 [C, 4]                (entry begin, entry end, first word of the chunk's blob, words in the blob)
 #   g_blob    int32 [...]                 per chunk: 256 header words -- one per voxel of the brick, at index
-#                                           half_wave * 16 + v (see hidx below): list start | list length << 16, in
+#                                           half_wave * 16 + v (see hidx in _gather_tables): list start | list length << 16, in
 #                                           contributions -- then the lists, 8 bytes per contribution: (byte offset of the
 #                                           sample's line in the sample buffer, weight).  The lists of z-neighbours (the two
 #                                           half-waves of a wave) are padded with zero-weight contributions to the same
@@ -260,11 +260,14 @@ def _gather_tables(pnb, ent, ent_brick, gstart, gcount, i_first, rel, own, wl, e
     raw_l = pc8[own & 255]
     cumL = np.concatenate(([0], np.cumsum(gcount.astype(np.int64))))
     cumC = np.concatenate(([0], np.cumsum(np.add.reduceat(raw_l, gstart)))) if nE else np.zeros(1, np.int64)
-    # header index of voxel vi = (lx*8 + ly)*8 + lz: wave = (lx, ly >> 2), half-wave = lz & 1, v = (ly & 3)*4 + (lz >> 1);
-    # the two half-waves of a wave hold z-neighbours (vi ^ 1), whose lists are alike: they are padded to one length
+    # header index of voxel vi = (lx*8 + ly)*8 + lz: wave = (ly + 2 (lz >> 1) + 4 lx) mod 8, half-wave = lz & 1,
+    # v = lx*4 + (lz >> 1).  The two half-waves of a wave hold z-neighbours (vi ^ 1), whose lists are alike: they are padded to
+    # one length.  The wave index is a skewed interleave of the brick: a chunk's samples are a bundle of neighbouring rays, so
+    # its contributions concentrate on a part of the brick, and the gather phase takes as long as its busiest wave --
+    # compact 4 x 4 x 8 blocks per wave: the busiest has 2.1 x the mean, this map 1.35 x (measured over the 128^3 tables)
     vi_all = np.arange(256)
     lx_, ly_, lz_ = vi_all >> 6, (vi_all >> 3) & 7, vi_all & 7
-    hidx = ((lx_ * 2 + (ly_ >> 2)) * 2 + (lz_ & 1)) * 16 + (ly_ & 3) * 4 + (lz_ >> 1)
+    hidx = (((ly_ + 2 * (lz_ >> 1) + 4 * lx_) & 7) * 2 + (lz_ & 1)) * 16 + lx_ * 4 + (lz_ >> 1)
     # contributions: (listed sample, owned corner) -> (entry, voxel, weight)
     e_of_l = np.repeat(np.arange(nE), gcount)
     i_l = np.arange(nl) - gstart[e_of_l]                                  # position inside the entry's listed run

@@ -158,7 +158,7 @@ def backward_gather(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
     blob = t["g_blob"]
     vi = np.arange(BX * BY * BZ)
     lx, ly, lz = vi // (BY * BZ), (vi // BZ) % BY, vi % BZ
-    hidx = ((lx * 2 + (ly >> 2)) * 2 + (lz & 1)) * 16 + (ly & 3) * 4 + (lz >> 1)      # header slot of voxel vi
+    hidx = (((ly + 2 * (lz >> 1) + 4 * lx) & 7) * 2 + (lz & 1)) * 16 + lx * 4 + (lz >> 1)      # header slot of voxel vi
     acc_shared = {}
     for brick, c0, c1, shared in t["g_rows"]:
         if shared == mod.SKIP:
