@@ -786,9 +786,18 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
     fetch(hA, A);
     bool row_start = true;
     int next_row = nrows;
+    unsigned mword = 0u;                                                // clamp mask of voxel (l & 15) of the current row's brick
     for (;;) {
         // here: the blob of chunk c is in bq (requested a phase ago), round 0 of its entries in hA / hB / A, LDS is free
         if (row_start && tid == 0) s_next = (int)gridDim.x + atomicAdd(row_counter + g, 1);    // the row after this one
+        if (PS && !(GENRE_G_ABL & 16) && row_start) {                   // requested now, used when the row is flushed
+            int ox, oy, oz;
+            brick_origin<4, 8, 8>(D, row.x, ox, oy, oz);
+            const int v = l & 15;
+            const int x = ox + (v >> 2), y = oy + ((wave - 2 * (v & 3) - 4 * (v >> 2)) & 7), z = oz + 2 * (v & 3) + half;
+            mword = 0u;
+            if (x < D.X && y < D.Y && z < D.Z) mword = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
+        }
         blob_store(ck);
         const int rounds = (ck.y - ck.x + kGHW - 1) / kGHW;
         for (int r = 0; r < rounds; r += 2) {                          // phase A: the next round's loads fly during this round's scans
@@ -854,12 +863,6 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
             // ---- every voxel of the brick once: a 128-byte line per half-wave and voxel ----
             int ox, oy, oz;
             brick_origin<4, 8, 8>(D, row.x, ox, oy, oz);
-            unsigned mword = 0u;                                        // clamp mask of voxel (l & 15)
-            if (PS && !(GENRE_G_ABL & 16)) {
-                const int v = l & 15;
-                const int x = ox + (v >> 2), y = oy + ((wave - 2 * (v & 3) - 4 * (v >> 2)) & 7), z = oz + 2 * (v & 3) + half;
-                if (x < D.X && y < D.Y && z < D.Z) mword = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
-            }
 #pragma unroll
             for (int v = 0; v < kGVox; v++) {
                 const int lx = v >> 2, ly = (wave - 2 * (v & 3) - 4 * lx) & 7, lz = 2 * (v & 3) + half;
