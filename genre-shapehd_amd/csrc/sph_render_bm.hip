@@ -671,9 +671,17 @@ constexpr int kGBlobWords = 256 + 2 * kGLCAP, kGDwWords = 256 + kMaxSeg;
 constexpr size_t kGLds = (size_t)(kGBlobWords + kGDwWords) * 4 + (size_t)kGCH * kImgs * 4;
 
 struct GEntry { float p[kMaxSeg]; float T, R; };
+// what the gather kernel needs of BmDims (scalar registers are scarce in it)
+struct GDims { int N, X, Y, Z, nseg, ZR; int64_t nslot, gx, gy, gz; float pre_scale; };
+
+__device__ __forceinline__ void g_brick_origin(const GDims &D, int brick, int &ox, int &oy, int &oz)
+{
+    const int nby = (D.Y + 7) / 8, nbz = (D.Z + 7) / 8;
+    ox = (brick / (nby * nbz)) * 4; oy = ((brick / nbz) % nby) * 8; oz = (brick % nbz) * 8;
+}
 
 template <bool PS>
-__global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const int4 *__restrict__ ents, const int4 *__restrict__ chunks,
+__global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(GDims D, const int4 *__restrict__ ents, const int4 *__restrict__ chunks,
                                                                  const int *__restrict__ blob, const int4 *__restrict__ rows, int nrows,
                                                                  const float *__restrict__ dw, const float *__restrict__ tr,
                                                                  const float *__restrict__ stash, const unsigned *__restrict__ mask,
@@ -790,14 +798,6 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
     for (;;) {
         // here: the blob of chunk c is in bq (requested a phase ago), round 0 of its entries in hA / hB / A, LDS is free
         if (row_start && tid == 0) s_next = (int)gridDim.x + atomicAdd(row_counter + g, 1);    // the row after this one
-        if (PS && !(GENRE_G_ABL & 16) && row_start) {                   // requested now, used when the row is flushed
-            int ox, oy, oz;
-            brick_origin<4, 8, 8>(D, row.x, ox, oy, oz);
-            const int v = l & 15;
-            const int x = ox + (v >> 2), y = oy + ((wave - 2 * (v & 3) - 4 * (v >> 2)) & 7), z = oz + 2 * (v & 3) + half;
-            mword = 0u;
-            if (x < D.X && y < D.Y && z < D.Z) mword = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
-        }
         blob_store(ck);
         const int rounds = (ck.y - ck.x + kGHW - 1) / kGHW;
         for (int r = 0; r < rounds; r += 2) {                          // phase A: the next round's loads fly during this round's scans
@@ -826,6 +826,16 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
             ckn = chunks[cn];
             hA = header(ckn, 0); hB = header(ckn, 1);
             blob_load(ckn);
+        }
+        if (PS && !(GENRE_G_ABL & 16) && row_ends) {                    // the clamp mask of voxel (l & 15): used behind phase B
+            // (requested HERE: a load behind a run-time condition makes the compiler's next wait inexact -- in front of
+            // phase A that serialises the entry pipeline, here the next wait is half a phase away)
+            int ox, oy, oz;
+            g_brick_origin(D, row.x, ox, oy, oz);
+            const int v = l & 15;
+            const int x = ox + (v >> 2), y = oy + ((wave - 2 * (v & 3) - 4 * (v >> 2)) & 7), z = oz + 2 * (v & 3) + half;
+            mword = 0u;
+            if (x < D.X && y < D.Y && z < D.Z) mword = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
         }
         // ---- phase B: this half-wave's sixteen lists are one contiguous stream in the blob (so are its partner's, of the
         // same lengths): four contributions per step, the list words requested two steps ahead ACROSS the voxel boundaries
@@ -862,12 +872,15 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(BmDims D, const
         if (row_ends) {
             // ---- every voxel of the brick once: a 128-byte line per half-wave and voxel ----
             int ox, oy, oz;
-            brick_origin<4, 8, 8>(D, row.x, ox, oy, oz);
+            g_brick_origin(D, row.x, ox, oy, oz);
 #pragma unroll
             for (int v = 0; v < kGVox; v++) {
                 const int lx = v >> 2, ly = (wave - 2 * (v & 3) - 4 * lx) & 7, lz = 2 * (v & 3) + half;
                 const int x = ox + lx, y = oy + ly, z = oz + lz, n = n0 + l;
-                const unsigned m = PS ? (unsigned)__shfl((int)mword, (lane & 32) | v) : 0u;
+                // lane v / 32 + v of the wave hold the mask words of this voxel for the lower / upper half-wave
+                const unsigned m_lo = PS ? (unsigned)__builtin_amdgcn_readlane((int)mword, v) : 0u;
+                const unsigned m_hi = PS ? (unsigned)__builtin_amdgcn_readlane((int)mword, 32 + v) : 0u;
+                const unsigned m = half ? m_hi : m_lo;
                 if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
                     float val = acc[v];
                     if (PS && !(GENRE_G_ABL & 16)) val = ((m >> l) & 1u) ? val * D.pre_scale : 0.f;   // adjoint of clamp(x * pre_scale, lo, hi)
@@ -1096,6 +1109,7 @@ extern "C" int genre_render_bm_backward_gather(const genre_tensor *grad_out, con
     // that lives behind tr_scratch's payload and is reset by the per-ray kernel in front of this one
     const dim3 pgrid((unsigned)(nrows < 2 * kCUs ? nrows : 2 * kCUs), (unsigned)D.groups);
     int *counter = reinterpret_cast<int *>((float *)tr_scratch->data + per);
+    const GDims GD{D.N, D.X, D.Y, D.Z, D.nseg, D.ZR, D.nslot, D.gx, D.gy, D.gz, D.pre_scale};
     if (g_rows->size[0] > nb) {                   // some bricks are split over several rows: those add atomically
         bm_zero_shared_kernel<4, 8, 8><<<grid, kThreads, 0, st>>>(D, (const int4 *)g_rows->data, (float *)grad_vox->data);
         GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");
@@ -1105,7 +1119,7 @@ extern "C" int genre_render_bm_backward_gather(const genre_tensor *grad_out, con
         static std::atomic<uint64_t> done_{0};                                                                            \
         if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_gather_kernel<PSV>), kGLds, done_)) return 0;             \
         bm_gather_kernel<PSV><<<pgrid, kGThreads, kGLds, st>>>(                                                           \
-            D, (const int4 *)g_ent->data, (const int4 *)g_chunks->data, (const int *)g_blob->data,                        \
+            GD, (const int4 *)g_ent->data, (const int4 *)g_chunks->data, (const int *)g_blob->data,                        \
             (const int4 *)g_rows->data, nrows, (const float *)depth_weight->data, (const float *)tr_scratch->data,        \
             (const float *)p_stash->data, pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr,                     \
             (float *)grad_vox->data, counter);                                                                            \

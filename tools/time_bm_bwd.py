@@ -83,3 +83,18 @@ def gather0():
 ts, tg = timeit(scatter0), timeit(gather0)
 rel = ((ga - gb).abs() / ga.abs().clamp(min=1e-3 * ga.abs().max().item())).max().item()
 print("AB bm_bwd(no pre_scale, soft volume) scatter %.1f us gather %.1f us  max rel diff %.3e  max|grad| %.3e" % (ts, tg, rel, ga.abs().max().item()))
+# the same soft volume through the pre_scale code path (pre_scale = 1: clamp mask written and applied): code path vs data
+lib.render_bm_forward(x, out, T["segs"], T["rec_f"], T["fwd_rows"], T["ray_ptr"], T["ray_seg"], T["ray_pre"], ps, stash, mask, 1.0)
+
+
+def scatter1():
+    lib.render_bm_backward(gout, ga, T["segs"], T["ray_ptr"], T["ray_seg"], T["ray_pre"], T["ent"], T["rec_b"],
+                           T["bwd_rows"], mod.depth_weight, ps, tr, stash, mask, 1.0, T["pull_code"])
+
+
+def gather1():
+    lib.render_bm_backward_gather(gout, gb, T["segs"], T["ray_ptr"], T["ray_seg"], T["ray_pre"], T["g_ent"], T["g_chunks"],
+                                  T["g_blob"], T["g_rows"], mod.depth_weight, ps, tr, stash, mask, 1.0)
+
+
+print("AB bm_bwd(pre_scale 1, soft volume) scatter %.1f us gather %.1f us" % (timeit(scatter1), timeit(gather1)))
