@@ -794,7 +794,6 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(GDims D, const 
     fetch(hA, A);
     bool row_start = true;
     int next_row = nrows;
-    unsigned mword = 0u;                                                // clamp mask of voxel (l & 15) of the current row's brick
     for (;;) {
         // here: the blob of chunk c is in bq (requested a phase ago), round 0 of its entries in hA / hB / A, LDS is free
         if (row_start && tid == 0) s_next = (int)gridDim.x + atomicAdd(row_counter + g, 1);    // the row after this one
@@ -827,6 +826,7 @@ __global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(GDims D, const 
             hA = header(ckn, 0); hB = header(ckn, 1);
             blob_load(ckn);
         }
+        unsigned mword = 0u;                                            // (lives from here to the flush below, not across chunks)
         if (PS && !(GENRE_G_ABL & 16) && row_ends) {                    // the clamp mask of voxel (l & 15): used behind phase B
             // (requested HERE: a load behind a run-time condition makes the compiler's next wait inexact -- in front of
             // phase A that serialises the entry pipeline, here the next wait is half a phase away)
