@@ -18,6 +18,8 @@ Besides the contract keys the JSON line carries
   batch1       : the same at batch 1 (launch-bound regime; replayed from a HIP graph)
   cpu_baseline : the same step on the host (reference kernel bodies host-compiled, or the C
                  port), bounded sample, rank 0 only
+  m1           : GenRe full-model forward passes per second (BASELINE's first metric), batch 1 and 8
+  train        : one optimizer step of BASELINE configs[3] / configs[4] at their per-rank shard shapes (DDP when N > 1)
 """
 import argparse
 import json
@@ -29,6 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+import miopen_cache  # noqa: E402
+
+miopen_cache.use()          # compiled MIOpen kernels of the networks (m1, train), if tools/warm_miopen.py left them in the tree
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
+import miopen_cache  # noqa: E402
+
+miopen_cache.use()          # compiled MIOpen kernels of the network tests, if present in the tree (before torch is imported)
 
 
 def pytest_configure(config):
