@@ -104,6 +104,10 @@ def parse():
     ap.add_argument("--no-m1", action="store_true", help="skip the GenRe whole-model forward (M1)")
     ap.add_argument("--no-train", action="store_true", help="skip the configs[3]/[4] train-step timings (`train`)")
     ap.add_argument("--train-steps", type=int, default=8, help="timed optimizer steps per train config")
+    ap.add_argument("--train-configs", default="shapehd,genre",
+                    help="comma-separated subset of shapehd,wgangp,genre (or `all`): the train steps to time.  The 3-D "
+                         "WGAN-GP step is not in the default set: on a fresh box MIOpen spends minutes searching its "
+                         "second-order convolutions (profiles/r03p_bench.json holds its number)")
     ap.add_argument("--eager", action="store_true", help="time eager launches of the step instead of a HIP-graph replay")
     ap.add_argument("--stub", action="store_true", help="launcher self-test: a trivial CPU step over gloo, no GPU")
     return ap.parse_args()
@@ -486,7 +490,7 @@ def m1_genre_forward(G, dev):
     return res
 
 
-def train_bench(dev, dist, du, world, rank, steps):
+def train_bench(dev, dist, du, world, rank, steps, which=("shapehd", "genre")):
     """BASELINE.json configs[3] / configs[4] as per-rank shards of their 8-GPU batches: one optimizer step of
       shapehd_b8      ShapeHD fine-tuning, batch 64 / 8 = 8 per rank (models/shapehd.py:82-118, marrnet2.py:46-54)
       wgangp_b8       3-D WGAN-GP critic + generator step, batch 8 per rank (models/wgangp.py:77-164)
@@ -523,20 +527,25 @@ def train_bench(dev, dist, du, world, rank, steps):
     to = lambda ns: type(ns)(**{k: v.to(dev) for k, v in vars(ns).items()})       # noqa: E731
     torch.manual_seed(1234)                                             # identical initial weights on every rank
     # configs[3]
-    net = MS.ShapeHDNet().to(dev).train()
-    model = T.ddp(net, dev, dist)
-    optim = torch.optim.Adam(net.marrnet2.parameters(), lr=1e-4, betas=(0.5, 0.9))
     ins, vox = T.sketch_batch(8, "cpu", seed=500 + rank)
     ins, vox = to(ins), vox.to(dev)
-    timed("shapehd_b8", 8, lambda: T.shapehd_train_step(model, optim, ins, vox, 1e-3),
-          "MarrNet-2 fine-tuned against the frozen 3-D critic: forward (incl. frozen copy + critic), backward, Adam")
-    del net, model, optim
-    gan = MS.WGANGP(lr=1e-4)
-    gan.net_g.to(dev), gan.net_d.to(dev)
-    gan.net_g, gan.net_d = T.ddp(gan.net_g, dev, dist), T.ddp(gan.net_d, dev, dist)
-    timed("wgangp_b8", 8, lambda: gan.train_on_batch(0, vox),
-          "critic step (real, fake, second-order gradient penalty) + generator step")
-    del gan, ins, vox
+    if "shapehd" in which:
+        net = MS.ShapeHDNet().to(dev).train()
+        model = T.ddp(net, dev, dist)
+        optim = torch.optim.Adam(net.marrnet2.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        timed("shapehd_b8", 8, lambda: T.shapehd_train_step(model, optim, ins, vox, 1e-3),
+              "MarrNet-2 fine-tuned against the frozen 3-D critic: forward (incl. frozen copy + critic), backward, Adam")
+        del net, model, optim
+    if "wgangp" in which:
+        gan = MS.WGANGP(lr=1e-4)
+        gan.net_g.to(dev), gan.net_d.to(dev)
+        gan.net_g, gan.net_d = T.ddp(gan.net_g, dev, dist), T.ddp(gan.net_d, dev, dist)
+        timed("wgangp_b8", 8, lambda: gan.train_on_batch(0, vox),
+              "critic step (real, fake, second-order gradient penalty) + generator step")
+        del gan
+    del ins, vox
+    if "genre" not in which:
+        return res
     # configs[4]
     gopt = GenReOptions(joint_train=True)
     net = GenReNet(gopt).to(dev).train()
@@ -690,7 +699,8 @@ def main():
     train = None
     if not args.no_train:           # every rank takes part (DDP all-reduce); reported in the same JSON line
         torch.cuda.empty_cache()
-        train = train_bench(dev, dist, dist_utils, world, rank, args.train_steps)
+        which = ("shapehd", "wgangp", "genre") if args.train_configs == "all" else tuple(args.train_configs.split(","))
+        train = train_bench(dev, dist, dist_utils, world, rank, args.train_steps, which)
 
     if rank == 0:
         rows = kernel_table(G, dev, B)

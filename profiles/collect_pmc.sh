@@ -27,7 +27,7 @@ S2=$(ls "$OUT"/pmc_s2/sq2_results.db "$OUT"/pmc_s2/*/sq2_results.db 2>/dev/null 
 python "$ROOT/profiles/pmc_sq_table.py" $S1 $S2 -- bm_scatter_kernel bm_gather_kernel bm_sample_kernel bm_combine cam_brick > "$OUT/sq_counters.txt" 2>&1
 # the bench line of the same build reads the table just measured (roofline.traffic must not be null in a committed line)
 cp "$OUT/pmc_hbm_traffic.json" "$ROOT/profiles/${TAG}_pmc_hbm_traffic.json"
-cd "$ROOT" && T0=$(date +%s) && python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench.py wall time: $(( $(date +%s) - T0 )) s" >> "$OUT/bench.err"
+cd "$ROOT" && T0=$(date +%s) && python bench.py --train-configs all > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench.py wall time: $(( $(date +%s) - T0 )) s" >> "$OUT/bench.err"
 if ! python - "$OUT/bench.json" <<'PY'
 import json, sys
 line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
