@@ -310,7 +310,8 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *   p_stash    fp32 [groups*S*32] or NULL: clamped sample values (negated where the clamp blocks the gradient);
  *              pass it when a backward will follow;  mask int32 [groups*X*Y*Z] (with p_stash and pre_scale != 0):
  *              bit i = image i passes clamp(vox*pre_scale)
- *   tr_scratch fp32 [groups*nseg*64]: backward only
+ *   tr_scratch fp32 [groups*nseg*64]: backward only (genre_render_bm_backward_gather: + groups more elements behind it, the
+ *                             row counters of its persistent workgroups)
  * out / grad_out [N,1,R+2p,R+2p] (p = padding margin as above, any strides); pre_scale as above.
  * grad_vox must be batch-minor too (stride[0] == 1); every element is written exactly once. */
 int genre_render_bm_forward(const genre_tensor *vox, const genre_tensor *out, const genre_tensor *segs,
