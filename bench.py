@@ -521,44 +521,55 @@ def train_bench(dev, dist, du, world, rank, steps, which=("shapehd", "genre")):
             res[name] = {"batch_per_gpu": batch, "ms_per_step": el * 1e3 / steps,
                          "samples_per_s": world * batch * steps / el, "what": note}
         except Exception as e:      # pragma: no cover -- never fatal for the bench line
-            res[name] = {"error": str(e)[:300]}
+            res[name] = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
 
     to = lambda ns: type(ns)(**{k: v.to(dev) for k, v in vars(ns).items()})       # noqa: E731
     torch.manual_seed(1234)                                             # identical initial weights on every rank
-    # configs[3]
-    ins, vox = T.sketch_batch(8, "cpu", seed=500 + rank)
-    ins, vox = to(ins), vox.to(dev)
-    if "shapehd" in which:
+    # Every config builds its networks inside its own try block: a failure (out of memory, a DDP construction error) is
+    # reported in the JSON line under that config's key and never takes the bench line with it.
+    def config(name, build):
+        try:
+            build()
+        except Exception as e:      # pragma: no cover
+            res.setdefault(name, {"error": repr(e)[:300]})
+        torch.cuda.empty_cache()
+
+    def shapehd():      # configs[3]
+        ins, vox = T.sketch_batch(8, "cpu", seed=500 + rank)
+        ins, vox = to(ins), vox.to(dev)
         net = MS.ShapeHDNet().to(dev).train()
         model = T.ddp(net, dev, dist)
         optim = torch.optim.Adam(net.marrnet2.parameters(), lr=1e-4, betas=(0.5, 0.9))
         timed("shapehd_b8", 8, lambda: T.shapehd_train_step(model, optim, ins, vox, 1e-3),
               "MarrNet-2 fine-tuned against the frozen 3-D critic: forward (incl. frozen copy + critic), backward, Adam")
-        del net, model, optim
-    if "wgangp" in which:
+
+    def wgangp():       # configs[3]'s critic
+        _, vox = T.sketch_batch(8, "cpu", seed=500 + rank)
+        vox = vox.to(dev)
         gan = MS.WGANGP(lr=1e-4)
         gan.net_g.to(dev), gan.net_d.to(dev)
         gan.net_g, gan.net_d = T.ddp(gan.net_g, dev, dist), T.ddp(gan.net_d, dev, dist)
         timed("wgangp_b8", 8, lambda: gan.train_on_batch(0, vox),
               "critic step (real, fake, second-order gradient penalty) + generator step")
-        del gan
-    del ins, vox
-    if "genre" not in which:
-        return res
-    # configs[4]
-    gopt = GenReOptions(joint_train=True)
-    net = GenReNet(gopt).to(dev).train()
-    with torch.no_grad():                                               # a depth range that puts the surface in the cube
-        head = net.depth_and_inpaint.net1.decoder_minmax[9]
-        head.weight.zero_()
-        head.bias.copy_(torch.tensor([1.9, 2.4]))
-    model = T.ddp(net, dev, dist)
-    optim = torch.optim.Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.9))
-    gin, gt = T.genre_batch(4, "cpu", seed=600 + rank)
-    gin, gt = to(gin), to(gt)
-    timed("genre_joint_b4", 4, lambda: T.genre_train_step(model, optim, gin, gt, gopt, chamfer_weight=0.1),
-          "all three modules + cam_bp / render_spherical / spherical back-projection / Chamfer in the graph, Adam")
+
+    def genre():        # configs[4]
+        gopt = GenReOptions(joint_train=True)
+        net = GenReNet(gopt).to(dev).train()
+        with torch.no_grad():                                           # a depth range that puts the surface in the cube
+            head = net.depth_and_inpaint.net1.decoder_minmax[9]
+            head.weight.zero_()
+            head.bias.copy_(torch.tensor([1.9, 2.4]))
+        model = T.ddp(net, dev, dist)
+        optim = torch.optim.Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.9))
+        gin, gt = T.genre_batch(4, "cpu", seed=600 + rank)
+        gin, gt = to(gin), to(gt)
+        timed("genre_joint_b4", 4, lambda: T.genre_train_step(model, optim, gin, gt, gopt, chamfer_weight=0.1),
+              "all three modules + cam_bp / render_spherical / spherical back-projection / Chamfer in the graph, Adam")
+
+    for name, key, build in (("shapehd", "shapehd_b8", shapehd), ("wgangp", "wgangp_b8", wgangp), ("genre", "genre_joint_b4", genre)):
+        if name in which:
+            config(key, build)
     return res
 
 
