@@ -19,3 +19,35 @@ def test_bench_spawns_its_own_ranks():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["value"] > 0
+
+
+def _train_worker(rank, world, port, ret):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    torch.set_num_threads(4)
+    torch.cuda.synchronize = lambda *a, **k: None                       # the section's device fences: no device here
+    torch.cuda.empty_cache = lambda *a, **k: None
+    import bench
+    from genre_shapehd_amd import dist_utils
+    dist = dist_utils.init_from_env("gloo")
+    res = bench.train_bench(torch.device("cpu"), dist, dist_utils, world, rank, 1, which=("shapehd",))
+    ret[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_section_runs_on_every_rank_under_ddp():
+    """bench.py's `train` section at N = 2 (gloo, CPU): every rank builds the full-width ShapeHD step under
+    DistributedDataParallel, the timing is barrier-bracketed and the maximum over ranks -- both ranks report the SAME
+    whole-job figure -- and a config that is not selected leaves no key"""
+    import torch.multiprocessing as mp
+    world, port = 2, 32600 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_train_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    assert set(a) == {"what", "steps", "shapehd_b8"} and "error" not in a["shapehd_b8"], a
+    assert a["shapehd_b8"]["batch_per_gpu"] == 8 and a["shapehd_b8"]["samples_per_s"] > 0
+    assert a["shapehd_b8"]["ms_per_step"] == b["shapehd_b8"]["ms_per_step"]             # max over ranks: one number
+    assert abs(a["shapehd_b8"]["samples_per_s"] * a["shapehd_b8"]["ms_per_step"] / 1e3 - world * 8) < 1e-6
