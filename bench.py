@@ -261,7 +261,7 @@ def kernel_table(G, dev, B):
             ps = torch.empty((groups * TB["segs"].shape[0] * 64,), device=dev)
             tr = torch.empty((ps.numel() + 64,), device=dev)          # + the gather kernel's row counters (one per group)
             stash = torch.empty((groups * TB["rec_f"].shape[0] * 32,), device=dev)
-            mask = torch.empty((groups * 128 ** 3,), dtype=torch.int32, device=dev)
+            mask = torch.empty((groups * 128 ** 3 + groups,), dtype=torch.int32, device=dev)
             out_p = torch.empty((B, 1, 160, 160), device=dev)
             gout_p = torch.randn_like(out_p)
             gvox_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgenre_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 _MAX_DIMS = 5
 _F32, _I32 = 0, 1
 

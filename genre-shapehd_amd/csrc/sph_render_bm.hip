@@ -150,8 +150,14 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
             bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
             bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x141, 0xf, 0xf, true);     // row_half_mirror
             const int x = xyz[j] & 1023, y = (xyz[j] >> 10) & 1023, z = xyz[j] >> 20;
-            if (piece == 0 && in && x - ox < kBX && y - oy < kBY && z - oz < kBZ)
+            if (piece == 0 && in && x - ox < kBX && y - oy < kBY && z - oz < kBZ) {
                 mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] = bits;
+                // one word per image group behind the masks: "some voxel of this group passes the clamp" (cleared by the
+                // host entry in front of this launch; every writer stores the same 1).  The backward of a group whose word
+                // is still 0 -- GenRe's own chain: every occupied voxel saturates the x50 clamp, every empty one sits below
+                // its lower bound (depth_pred_with_sph_inpaint.py:124) -- is identically zero and skips all of its work.
+                if (bits != 0u) mask[(size_t)D.groups * D.X * D.Y * D.Z + g] = 1u;
+            }
         }
     }
     __syncthreads();
@@ -298,9 +304,11 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
                                                              const int *__restrict__ ray_ptr,
                                                              const int *__restrict__ ray_seg,
                                                              const double2 *__restrict__ ray_pre, View4 gout,
-                                                             float *__restrict__ tr, int *__restrict__ row_counter)
+                                                             float *__restrict__ tr, int *__restrict__ row_counter,
+                                                             const unsigned *__restrict__ group_any)
 {
     if (row_counter && blockIdx.x == 0 && threadIdx.x == 0) row_counter[blockIdx.y] = 0;   // for the gather kernel behind this one
+    if (group_any && group_any[blockIdx.y] == 0u) return;              // no voxel of this group passes the clamp: nothing reads tr
     const int q = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     if (q >= D.R * D.R) return;
     const int g = blockIdx.y, n = g * kImgs + l;
@@ -462,12 +470,51 @@ __global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scat
     const int g = blockIdx.y, n0 = g * kImgs;
     int ox, oy, oz;
     brick_origin<PX, PY, PZ>(D, row.x, ox, oy, oz);
-    for (int line = threadIdx.x; PS && line < kLinesB; line += kThreadsB) {  // in flight while the samples are scattered
-        const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
-        mlds[line] = (x < D.X && y < D.Y && z < D.Z) ? mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] : 0u;
+    if (PS) {
+        // The clamp adjoint decides first.  A brick none of whose voxels passes clamp(x * pre_scale, lo, hi) in any of the 32
+        // images has an identically zero gradient whatever the samples say (the flush multiplies by the mask): it writes
+        // its zeros and is done -- no entries, no scans, no atomics.  On GenRe's own chain (x50 of a saturated or empty
+        // voxel) that is every brick; the group word behind the masks says so without reading them.
+        static_assert(kLinesB <= kThreadsB && kLinesB % 256 == 0, "one mask word per thread, four summary words per read");
+        const bool group_live = mask[(size_t)D.groups * D.X * D.Y * D.Z + g] != 0u;
+        unsigned m = 0u;
+        if (group_live && (int)threadIdx.x < kLinesB) {
+            const int line = threadIdx.x;
+            const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
+            if (x < D.X && y < D.Y && z < D.Z) m = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
+        }
+        for (int e = threadIdx.x; e < kLinesB * kImgs / 2; e += kThreadsB) reinterpret_cast<double2 *>(tile)[e] = make_double2(0.0, 0.0);
+        if ((int)threadIdx.x < kLinesB) {
+            mlds[threadIdx.x] = m;
+            const unsigned long long hit = __ballot(m != 0u);          // the waves that carry mask words: one summary word each
+            if ((threadIdx.x & 63) == 0) mlds[kLinesB + (threadIdx.x >> 6)] = hit ? 1u : 0u;
+        }
+        __syncthreads();
+        unsigned brick_live = 0u;
+#pragma unroll
+        for (int i = 0; i < kLinesB / 64; i += 4) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(mlds + kLinesB + i);
+            brick_live |= w.x | w.y | w.z | w.w;
+        }
+        if (!brick_live) {
+            if (row.w != 0) return;                                     // a shared brick: bm_zero_shared_kernel wrote its zeros
+            for (int q = threadIdx.x; q < kLinesB * (kImgs / 4); q += kThreadsB) {
+                const int line = q >> 3, n = n0 + (q & 7) * 4;
+                const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
+                if (x >= D.X || y >= D.Y || z >= D.Z) continue;
+                float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
+                if ((D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(gvox) & 15) == 0 && n + 3 < D.N)
+                    *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+                else
+                    for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] = 0.f;
+            }
+            return;
+        }
+    } else {
+        for (int e = threadIdx.x; e < kLinesB * kImgs / 2; e += kThreadsB) reinterpret_cast<double2 *>(tile)[e] = make_double2(0.0, 0.0);
+        __syncthreads();
     }
-    for (int e = threadIdx.x; e < kLinesB * kImgs / 2; e += kThreadsB) reinterpret_cast<double2 *>(tile)[e] = make_double2(0.0, 0.0);
-    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int half = lane >> 5, l = lane & 31;
     // A wave's records in LDS: slot = sample index inside the segment, 64 bytes per slot = one 32-byte part per half-wave,
@@ -973,6 +1020,10 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
                       "%s: pre_scale with a saved state needs mask int32 [groups*X*Y*Z]", op);
     }
     hipStream_t st = (hipStream_t)stream;
+    if (save && pre_scale != 0.0f) {          // the groups' "some voxel passes the clamp" words behind the masks (set by the sampler)
+        GENRE_REQUIRE(hipMemsetAsync((unsigned *)mask->data + (int64_t)D.groups * D.X * D.Y * D.Z, 0, (size_t)D.groups * 4, st) == hipSuccess,
+                      "%s: hipMemsetAsync of the group words failed", op);
+    }
     // 1024 threads: 16 waves share one tile, two workgroups per CU = 8 waves per SIMD (measured 257 us against 318 with 512)
     constexpr int nt = 1024;
     const size_t lds = (size_t)kLinesF * kImgs * 4 + (size_t)(nt / 64) * 64 * 16;
@@ -1029,12 +1080,13 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
     GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] % kImgs == 0 && D.groups > 0 &&
                       p_stash->size[0] / kImgs % D.groups == 0, "%s: p_stash must be the forward's [groups*S*32] buffer", op);
     D.nslot = p_stash->size[0] / kImgs / D.groups;
-    GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) && mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z),
-                  "%s: pre_scale needs the forward's mask int32 [groups*X*Y*Z]", op);
+    GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) && mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z + D.groups),
+                  "%s: pre_scale needs the forward's mask int32 [groups*X*Y*Z + groups]", op);
     hipStream_t st = (hipStream_t)stream;
     bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
         D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
-        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data, nullptr);
+        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data, nullptr,
+        pre_scale != 0.0f ? (const unsigned *)mask->data + (int64_t)D.groups * D.X * D.Y * D.Z : nullptr);
     GENRE_LAUNCH_CHECK("render_bm backward (rays)");
     const int nb = ((D.X + px - 1) / px) * ((D.Y + 7) / 8) * ((D.Z + 7) / 8);
     const dim3 grid((unsigned)bwd_rows->size[0], (unsigned)D.groups);
@@ -1048,7 +1100,7 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
                                                                         (float *)grad_vox->data);                         \
             GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");                                                \
         }                                                                                                                 \
-        constexpr size_t lds = (size_t)PXV * 64 * kImgs * 8 + (size_t)(NTV / 64) * kMaxSeg * kRecL * 4 + (size_t)PXV * 64 * 4; \
+        constexpr size_t lds = (size_t)PXV * 64 * kImgs * 8 + (size_t)(NTV / 64) * kMaxSeg * kRecL * 4 + (size_t)PXV * 64 * 4 + PXV * 4; \
         static std::atomic<uint64_t> done_{0};                                                                            \
         if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_scatter_kernel<PSV, PXV, 8, 8, NTV>), lds, done_)) return 0; \
         bm_scatter_kernel<PSV, PXV, 8, 8, NTV><<<grid, NTV, lds, st>>>(                                                   \
@@ -1094,13 +1146,13 @@ extern "C" int genre_render_bm_backward_gather(const genre_tensor *grad_out, con
     GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] % kImgs == 0 && D.groups > 0 &&
                       p_stash->size[0] / kImgs % D.groups == 0, "%s: p_stash must be the forward's [groups*S*32] buffer", op);
     D.nslot = p_stash->size[0] / kImgs / D.groups;
-    GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) && mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z),
-                  "%s: pre_scale needs the forward's mask int32 [groups*X*Y*Z]", op);
+    GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) && mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z + D.groups),
+                  "%s: pre_scale needs the forward's mask int32 [groups*X*Y*Z + groups]", op);
     hipStream_t st = (hipStream_t)stream;
     bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
         D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
         (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data,
-        reinterpret_cast<int *>((float *)tr_scratch->data + per));
+        reinterpret_cast<int *>((float *)tr_scratch->data + per), nullptr);
     GENRE_LAUNCH_CHECK("render_bm backward (rays)");
     const int nb = ((D.X + 3) / 4) * ((D.Y + 7) / 8) * ((D.Z + 7) / 8);
     const dim3 grid((unsigned)g_rows->size[0], (unsigned)D.groups);

@@ -266,7 +266,7 @@ class RenderSphericalFused(Function):
             if ctx.needs_input_grad[0]:
                 stash = torch.empty((groups * t["rec_f"].shape[0] * 32,), **f32)
                 if pre_scale:
-                    mask = torch.empty((groups * vox.shape[2] * vox.shape[3] * vox.shape[4],), dtype=torch.int32,
+                    mask = torch.empty((groups * vox.shape[2] * vox.shape[3] * vox.shape[4] + groups,), dtype=torch.int32,
                                        device=vox.device)
             lib.render_bm_forward(vox, out, t["segs"], t["rec_f"], t["fwd_rows"], t["ray_ptr"], t["ray_seg"],
                                   t["ray_pre"], ps, stash, mask, ctx.pre_scale)

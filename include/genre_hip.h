@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GENRE_ABI_VERSION 2
+#define GENRE_ABI_VERSION 3
 #define GENRE_MAX_DIMS 5
 
 enum { GENRE_F32 = 0, GENRE_I32 = 1 };
@@ -308,8 +308,10 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *   ps_scratch fp32 [groups*nseg*64]: per segment (in ray order) and image (prod(1-p), sum T p w) -- forward output,
  *                             backward input
  *   p_stash    fp32 [groups*S*32] or NULL: clamped sample values (negated where the clamp blocks the gradient);
- *              pass it when a backward will follow;  mask int32 [groups*X*Y*Z] (with p_stash and pre_scale != 0):
- *              bit i = image i passes clamp(vox*pre_scale)
+ *              pass it when a backward will follow;  mask int32 [groups*X*Y*Z + groups] (with p_stash and pre_scale != 0):
+ *              bit i = image i passes clamp(vox*pre_scale); the trailing `groups` words (ABI 3) say whether ANY voxel of
+ *              the group passes it -- cleared and set by the forward, read by the backward: a group (or a brick) whose
+ *              masks are all zero has an identically zero gradient and the backward only writes its zeros
  *   tr_scratch fp32 [groups*nseg*64]: backward only (genre_render_bm_backward_gather: + groups more elements behind it, the
  *                             row counters of its persistent workgroups)
  * out / grad_out [N,1,R+2p,R+2p] (p = padding margin as above, any strides); pre_scale as above.

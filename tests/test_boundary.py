@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libgenre_hip.so does not export %s" % s
     lib.genre_abi_version.restype = C.c_int
-    assert lib.genre_abi_version() == 2
+    assert lib.genre_abi_version() == 3
 
 
 def test_every_symbol_cites_the_reference_interface():

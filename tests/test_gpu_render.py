@@ -180,6 +180,36 @@ def test_batch_minor_layout_matches_standard(n, pre_scale, pad, genre, dev):
     assert (a.grad - b.grad).abs().max().item() <= 1e-5 * max(1.0, scale)
 
 
+def test_batch_minor_backward_skips_what_the_clamp_blocks(genre, dev):
+    """the backward of a group of 32 images none of whose voxels passes clamp(x * pre_scale) -- GenRe's own chain:
+    every occupied voxel saturates the x50 clamp, every empty one lies below its lower bound
+    (depth_pred_with_sph_inpaint.py:124) -- and of every brick whose masks are all zero writes zeros and does nothing
+    else (csrc/sph_render_bm.hip: group word behind the masks, per-brick test in bm_scatter_kernel).  Group 0 = 32
+    volumes of the real chain, group 1 = 8 volumes with a gradient everywhere but inside a saturated block: group 0's
+    gradient is exactly zero (also under a NaN upstream gradient: the clamp adjoint is a select, not a product), group
+    1's equals the standard-layout path's."""
+    rng = np.random.default_rng(37)
+    d = torch.from_numpy(inputs.batch_depth(32)).to(dev)
+    with torch.no_grad():
+        proj = genre.Camera_back_projection_layer().to(dev)(d)                       # 1 - 128 tdf: 0 or >= 0.13
+    soft = torch.from_numpy(rng.uniform(0.001, 0.019, (8, 1, 128, 128, 128)).astype(np.float32)).to(dev)
+    soft[:, :, 40:60, 50:70, 30:90] = 0.9
+    vox = torch.cat((proj, soft), 0)
+    mod = genre.render_spherical().to(dev)
+    a = vox.clone().requires_grad_(True)
+    b = _batch_minor(vox).requires_grad_(True)
+    out_a, out_b = mod(a, pre_scale=50.0, pad=16), mod(b, pre_scale=50.0, pad=16)
+    assert (out_a - out_b).abs().max().item() <= 1e-6
+    g = torch.from_numpy(rng.standard_normal(tuple(out_a.shape)).astype(np.float32)).to(dev)
+    g[3] = float("nan")
+    out_a.backward(g)
+    out_b.backward(g)
+    assert torch.count_nonzero(b.grad[:32]).item() == 0 and torch.count_nonzero(a.grad[:32]).item() == 0
+    scale = a.grad[32:].abs().max().item()
+    assert scale > 0 and torch.count_nonzero(b.grad[32:, :, 44:56, 56:64, 40:80]).item() == 0
+    assert (a.grad[32:] - b.grad[32:]).abs().max().item() <= 1e-5 * max(1.0, scale)
+
+
 def test_camera_layer_batch_minor_option(genre, dev):
     """Camera_back_projection_layer(batch_minor=True): same values, image-minor memory; the chain through the
     renderer equals the standard-layout chain"""

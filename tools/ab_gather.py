@@ -33,7 +33,7 @@ def worker(tag):
     ps = torch.empty((T["segs"].shape[0] * 64,), **f32)
     tr = torch.empty((ps.numel() + 64,), **f32)
     stash = torch.empty((T["rec_f"].shape[0] * 32,), **f32)
-    mask = torch.empty((128 ** 3,), dtype=torch.int32, device=dev)
+    mask = torch.empty((128 ** 3 + 1,), dtype=torch.int32, device=dev)
     out = torch.empty((B, 1, 160, 160), **f32)
     gout = torch.randn_like(out)
     gb = _fused_render.empty_batch_minor(proj.shape, torch.float32, dev)

@@ -56,7 +56,7 @@ def worker_bm(tag):
     ps = torch.empty((groups * TB["segs"].shape[0] * 64,), device=dev)
     tr = torch.empty_like(ps)
     stash = torch.empty((groups * TB["rec_f"].shape[0] * 32,), device=dev)
-    mask = torch.empty((groups * 128 ** 3,), dtype=torch.int32, device=dev)
+    mask = torch.empty((groups * 128 ** 3 + groups,), dtype=torch.int32, device=dev)
     out = torch.empty((B, 1, 160, 160), device=dev)
     torch.manual_seed(0)
     gout = torch.randn_like(out)

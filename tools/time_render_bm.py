@@ -27,7 +27,7 @@ f32 = dict(dtype=torch.float32, device=dev)
 ps = torch.empty((groups * T["segs"].shape[0] * 64,), **f32)
 tr = torch.empty_like(ps)
 stash = torch.empty((groups * T["rec_f"].shape[0] * 32,), **f32)
-mask = torch.empty((groups * 128 ** 3,), dtype=torch.int32, device=dev)
+mask = torch.empty((groups * 128 ** 3 + groups,), dtype=torch.int32, device=dev)
 out = torch.empty((B, 1, 160, 160), **f32)
 gout = torch.randn_like(out)
 gvox = _fused_render.empty_batch_minor(proj.shape, torch.float32, dev)
