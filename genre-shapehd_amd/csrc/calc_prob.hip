@@ -33,7 +33,13 @@
 namespace genre {
 namespace {
 
-constexpr int kBlock = 256;                    // 4 waves = 4 rays in flight per block
+#ifndef GENRE_CP_BLOCK
+#define GENRE_CP_BLOCK 256                     // tools/ab_round4.py: workgroup size of the stop-probability kernels
+#endif
+#ifndef GENRE_CP_NT
+#define GENRE_CP_NT 3                          // bit 0: nontemporal loads, bit 1: nontemporal stores
+#endif
+constexpr int kBlock = GENRE_CP_BLOCK;         // 4 waves = 4 rays in flight per block
 constexpr int kWavesPerBlock = kBlock / 64;
 
 struct RayDims { int NC, X, Y, Z; int64_t rays; };
@@ -73,13 +79,15 @@ __device__ __forceinline__ int64_t ray_base(const RayDims &D, const RayView &v, 
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 nt_load4(const float *p)
 {
-    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    const v4f v = (GENRE_CP_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p))
+                                    : *reinterpret_cast<const v4f *>(p);
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void nt_store4(float *p, const float4 &s)
 {
     const v4f v = {s.x, s.y, s.z, s.w};
-    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+    if (GENRE_CP_NT & 2) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+    else *reinterpret_cast<v4f *>(p) = v;
 }
 
 // ---- forward, float4 path: z stride 1, Z % 4 == 0, 16-B aligned rays ----------------

@@ -580,7 +580,29 @@ __device__ __forceinline__ void divmod_px(int t, int d, float inv_d, int &r, int
 // BYVAL: focal length and camera distance are kernel arguments (one value for every image -- what
 // Camera_back_projection_layer fills its [N,1] tensors with, camera_backprojection_module.py:16-21) instead of two loads
 // in front of the footprint: one dependent memory round trip less before a workgroup knows its pixels.
-template <bool BYVAL>
+// PIXELSCREEN (small batches): no block-wide depth-range screen.  The footprint's depth range costs a wave reduction and a
+// barrier BEHIND the pixel loads, on the critical path of every brick, live or not; here the tile is cleared and the barrier
+// passed while the loads are in flight, every pixel goes through the per-pixel plane-depth test the live bricks apply
+// anyway (a dozen vector instructions), and "live" is whether any pixel landed -- one barrier behind the loads instead of
+// two and a reduction.  Same output bit for bit: a brick the range screen calls dead has no landing pixel
+// (tests/test_cam_brick_screens.py), and a live brick without hits writes the fill values from its empty tile.  At batch
+// 32 the kernel is bandwidth-bound and the extra per-pixel arithmetic of the 77 % dead bricks costs more than the barrier.
+#ifndef GENRE_CAMQ_PIXELSCREEN_MAXN
+#define GENRE_CAMQ_PIXELSCREEN_MAXN 0              // images per launch up to which the PIXELSCREEN instantiation is used
+#endif
+#ifndef GENRE_CAMQ_NT
+#define GENRE_CAMQ_NT 0                            // tools/ab_round4.py: 1 = nontemporal stores of the brick
+#endif
+template <typename T>
+__device__ __forceinline__ void camq_store4(float *p, const T &v)
+{
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const v4f_ q = {v.x, v.y, v.z, v.w};
+    if (GENRE_CAMQ_NT) __builtin_nontemporal_store(q, reinterpret_cast<v4f_ *>(p));
+    else *reinterpret_cast<v4f_ *>(p) = q;
+}
+
+template <bool BYVAL, bool PIXELSCREEN = false>
 __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, View2 camdist, View2 fl, View5 vox,
                                                             View5 cnt, float prefill, float bias, float post_scale,
                                                             float post_bias, float fill_val, int vec_ok, float fl_val,
@@ -590,6 +612,7 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
     __shared__ unsigned s_cnt[kQVox];
     __shared__ float s_min[kBlock / 64], s_max[kBlock / 64];
     __shared__ int s_any[kBlock / 64];
+    __shared__ int s_hit;
     const int nbz = (D.Z + kQZ - 1) / kQZ, nby = (D.Y + kQY - 1) / kQY;
     const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
     const int img = blockIdx.y, n = img / D.NC, c = img % D.NC;
@@ -624,23 +647,37 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
         if (d > 0.0f) { bb.dmin = fminf(bb.dmin, d); bb.dmax = fmaxf(bb.dmax, d); }
         else if (!(d < 0.0f)) bb.any_zero = 1;          // d == 0 (or NaN): lands at x = -cam_dist
     };
-#pragma unroll
-    for (int u = 0; u < kQDeep; u++)
-        if ((int)threadIdx.x + u * kBlock < area) screen(dv[u]);
-    for (int t = threadIdx.x + kQDeep * kBlock; t < area; t += kBlock) screen(fetch(t));
-    // positive floats order like their bit patterns: min / max of the depths as integers (dmin starts at 3e38, dmax at 0)
-    bb.dmin = __int_as_float(wave_reduce_bits(__float_as_int(bb.dmin), 0x7f7fffff, [](int a, int b) { return a < b ? a : b; }));
-    bb.dmax = __int_as_float(wave_reduce_bits(__float_as_int(bb.dmax), 0, [](int a, int b) { return a > b ? a : b; }));
-    bb.any_zero = wave_reduce_bits(bb.any_zero, 0, [](int a, int b) { return a | b; });
-    if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = bb.dmin; s_max[threadIdx.x >> 6] = bb.dmax; s_any[threadIdx.x >> 6] = bb.any_zero; }
-    // the tile is cleared before the brick is known to be live: the stores ride under the reduction's barrier
-    for (int e = threadIdx.x; e < kQVox; e += kBlock) { s_sum[e] = 0.0; s_cnt[e] = 0u; }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kBlock / 64; i++) { bb.dmin = fminf(bb.dmin, s_min[i]); bb.dmax = fmaxf(bb.dmax, s_max[i]); bb.any_zero |= s_any[i]; }
     float blo, bhi;
-    bool bspecial;
-    const bool live = slab_live(bb, bw, bxlo, bxhi, cam_dist, f, blo, bhi, bspecial);
+    bool bspecial, live;
+    if (PIXELSCREEN) {
+        // the tile is cleared and the barrier passed while the pixel loads are in flight (a workgroup barrier does not wait
+        // for outstanding loads); "special" from the geometry alone: the slab contains the plane x = -cam_dist, or the
+        // camera is inside the grid -- then no per-pixel shortcut is safe (slab_live)
+        for (int e = threadIdx.x; e < kQVox; e += kBlock) { s_sum[e] = 0.0; s_cnt[e] = 0u; }
+        if (threadIdx.x == 0) s_hit = 0;
+        __syncthreads();
+        const float eps = 1e-4f;
+        bspecial = !(f > 0.0f) || !(bxlo + cam_dist > 1e-3f) ||
+                   (bxlo + cam_dist - eps <= 0.0f && bxhi + cam_dist + eps >= 0.0f);
+        live = true;
+    } else {
+#pragma unroll
+        for (int u = 0; u < kQDeep; u++)
+            if ((int)threadIdx.x + u * kBlock < area) screen(dv[u]);
+        for (int t = threadIdx.x + kQDeep * kBlock; t < area; t += kBlock) screen(fetch(t));
+        // positive floats order like their bit patterns: min / max of the depths as integers (dmin starts at 3e38, dmax at 0)
+        bb.dmin = __int_as_float(wave_reduce_bits(__float_as_int(bb.dmin), 0x7f7fffff, [](int a, int b) { return a < b ? a : b; }));
+        bb.dmax = __int_as_float(wave_reduce_bits(__float_as_int(bb.dmax), 0, [](int a, int b) { return a > b ? a : b; }));
+        bb.any_zero = wave_reduce_bits(bb.any_zero, 0, [](int a, int b) { return a | b; });
+        if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = bb.dmin; s_max[threadIdx.x >> 6] = bb.dmax; s_any[threadIdx.x >> 6] = bb.any_zero; }
+        // the tile is cleared before the brick is known to be live: the stores ride under the reduction's barrier
+        for (int e = threadIdx.x; e < kQVox; e += kBlock) { s_sum[e] = 0.0; s_cnt[e] = 0u; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kBlock / 64; i++) { bb.dmin = fminf(bb.dmin, s_min[i]); bb.dmax = fmaxf(bb.dmax, s_max[i]); bb.any_zero |= s_any[i]; }
+        live = slab_live(bb, bw, bxlo, bxhi, cam_dist, f, blo, bhi, bspecial);
+    }
+    bool hit = false;
     if (live) {
         // ---- (b) every footprint pixel once, by the thread that fetched it: a cheap plane-depth test first (1-ulp
         // rsqrt, generous margin, as in cam_gather_kernel -- only ~1/16 of the footprint's points lie in this brick's x
@@ -663,12 +700,15 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
             const int l = ((ix - x0) * kQY + (iy - y0)) * kQZ + (iz - z0);
             unsafeAtomicAdd(&s_sum[l], (double)dist);                       // :273
             atomicAdd(&s_cnt[l], 1u);                                       // :274
+            hit = true;
         };
 #pragma unroll
         for (int u = 0; u < kQDeep; u++)
             if ((int)threadIdx.x + u * kBlock < area) pixel(threadIdx.x + u * kBlock, dv[u]);
         for (int t = threadIdx.x + kQDeep * kBlock; t < area; t += kBlock) pixel(t, fetch(t));
+        if (PIXELSCREEN && __ballot(hit) != 0ull && (threadIdx.x & 63) == 0) s_hit = 1;
         __syncthreads();
+        if (PIXELSCREEN) live = s_hit != 0;
     }
     // ---- (c) normalise (:291-305) and write the brick; a dead brick streams the fill values ---------------------
     auto value = [&](int l, float &k) {
@@ -686,8 +726,8 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
                 const int l = xy * kQZ + z4;
                 tv.x = value(l, kv.x); tv.y = value(l + 1, kv.y); tv.z = value(l + 2, kv.z); tv.w = value(l + 3, kv.w);
             }
-            *reinterpret_cast<float4 *>(vimg + ix * vox.s2 + iy * vox.s3 + (z0 + z4)) = tv;
-            *reinterpret_cast<float4 *>(cimg + ix * cnt.s2 + iy * cnt.s3 + (z0 + z4)) = kv;
+            camq_store4(vimg + ix * vox.s2 + iy * vox.s3 + (z0 + z4), tv);
+            camq_store4(cimg + ix * cnt.s2 + iy * cnt.s3 + (z0 + z4), kv);
         }
     } else {
         const int lz = threadIdx.x & (kQZ - 1), iz = z0 + lz;
@@ -1051,12 +1091,14 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
             const int64_t bricks = (int64_t)((D.X + kQX - 1) / kQX) * ((D.Y + kQY - 1) / kQY) * ((D.Z + kQZ - 1) / kQZ);
             GENRE_REQUIRE(bricks < ((int64_t)1 << 31), "%s: volume too large", op);
             const dim3 bgrid((unsigned)bricks, D.N * D.NC);
-            if (byval)
-                cam_brick_kernel<true><<<bgrid, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias,
-                                                                 post_scale, post_bias, fill_val, vec_ok, byval[0], byval[1]);
-            else
-                cam_brick_kernel<false><<<bgrid, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias,
-                                                                  post_scale, post_bias, fill_val, vec_ok, 0.0f, 0.0f);
+            // small batches are bound by the chain behind the pixel loads, large ones by bandwidth (cam_brick_kernel: PIXELSCREEN)
+            const bool pixelscreen = D.N * D.NC <= GENRE_CAMQ_PIXELSCREEN_MAXN;
+#define GENRE_CAMQ_LAUNCH(BV, PXS, A, B_)                                                                                 \
+            cam_brick_kernel<BV, PXS><<<bgrid, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias, \
+                                                                post_scale, post_bias, fill_val, vec_ok, A, B_)
+            if (byval) { if (pixelscreen) GENRE_CAMQ_LAUNCH(true, true, byval[0], byval[1]); else GENRE_CAMQ_LAUNCH(true, false, byval[0], byval[1]); }
+            else { if (pixelscreen) GENRE_CAMQ_LAUNCH(false, true, 0.0f, 0.0f); else GENRE_CAMQ_LAUNCH(false, false, 0.0f, 0.0f); }
+#undef GENRE_CAMQ_LAUNCH
             GENRE_LAUNCH_CHECK("projection forward (bricks)");
             return 1;
         }

@@ -433,6 +433,12 @@ __device__ __forceinline__ void both_halves(float v, float &lower, float &upper)
 }
 
 constexpr int kHalfSeg = kMaxSeg / 2;
+#ifndef GENRE_BM_SCATTER_NT
+#define GENRE_BM_SCATTER_NT 768                // threads of the 4x8x8 pull-brick scatter kernel (tools/ab_round4.py: 1024)
+#endif
+#ifndef GENRE_BM_SCATTER_WAVES
+#define GENRE_BM_SCATTER_WAVES 8               // waves per SIMD the 1024-thread variant is compiled for (<= 64 VGPRs)
+#endif
 
 // A lane-uniform ownership bit pair (lower half-wave, upper half-wave) as an execution mask: two s_bfe_i32 and the
 // s_and_saveexec of the `if` -- no vector instruction and no branch, so the compiler counts the LDS operations in flight
@@ -455,7 +461,7 @@ struct BmEntryRegs {
 
 // 768 threads: two workgroups per CU = 6 waves per SIMD, which the register allocation must respect (<= 80 VGPRs)
 template <bool PS, int PX, int PY, int PZ, int kThreadsB>
-__global__ __launch_bounds__(kThreadsB, (kThreadsB <= 768 ? 6 : 4)) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
+__global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE_BM_SCATTER_WAVES) : 4)) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
                                                                const int4 *__restrict__ rows, const float *__restrict__ dw,
                                                                const float *__restrict__ tr, const float *__restrict__ stash,
                                                                const unsigned *__restrict__ mask, float *__restrict__ gvox)
@@ -1108,7 +1114,7 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
             (const float *)depth_weight->data, (const float *)tr_scratch->data, (const float *)p_stash->data,             \
             pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr, (float *)grad_vox->data);                         \
     } while (0)
-    if (px == 4) { if (pre_scale != 0.0f) GENRE_BM_SCATTER(true, 4, 768); else GENRE_BM_SCATTER(false, 4, 768); }
+    if (px == 4) { if (pre_scale != 0.0f) GENRE_BM_SCATTER(true, 4, GENRE_BM_SCATTER_NT); else GENRE_BM_SCATTER(false, 4, GENRE_BM_SCATTER_NT); }
     else { if (pre_scale != 0.0f) GENRE_BM_SCATTER(true, 8, 1024); else GENRE_BM_SCATTER(false, 8, 1024); }
 #undef GENRE_BM_SCATTER
     GENRE_LAUNCH_CHECK("render_bm backward (bricks)");

@@ -12,10 +12,12 @@ import torch
 from torch import nn
 
 from .resnet import resnet18
+from .thin_conv import ThinConv3d, ThinConvTranspose3d
 
 
 def _up3(cin, cout, bias):                 # x2
-    return nn.ConvTranspose3d(cin, cout, 4, 2, 1, bias=bias)
+    # one output channel at 128^3: MIOpen's weight gradient is its naive reference kernel (283 ms at batch 8) -- thin_conv.py
+    return (ThinConvTranspose3d if cout == 1 else nn.ConvTranspose3d)(cin, cout, 4, 2, 1, bias=bias)
 
 
 def _grow3(cin, cout, bias):               # 1^3 -> 4^3
@@ -102,7 +104,8 @@ class VoxelDiscriminator(nn.Module):
 class Conv3d_block(nn.Module):
     def __init__(self, ncin, ncout, kernel_size, stride, pad, dropout=False):
         super().__init__()
-        self.net = nn.Sequential(nn.Conv3d(ncin, ncout, kernel_size, stride, pad), nn.BatchNorm3d(ncout), nn.LeakyReLU())
+        conv = ThinConv3d if ncin <= 2 else nn.Conv3d               # two input channels at 128^3: thin_conv.py
+        self.net = nn.Sequential(conv(ncin, ncout, kernel_size, stride, pad), nn.BatchNorm3d(ncout), nn.LeakyReLU())
 
     def forward(self, x):
         return self.net(x)
@@ -111,7 +114,7 @@ class Conv3d_block(nn.Module):
 class Deconv3d_skip(nn.Module):
     def __init__(self, ncin, ncout, kernel_size, stride, pad, extra=0, is_activate=True):
         super().__init__()
-        up = nn.ConvTranspose3d(ncin, ncout, kernel_size, stride, pad, extra)
+        up = (ThinConvTranspose3d if ncout == 1 else nn.ConvTranspose3d)(ncin, ncout, kernel_size, stride, pad, extra)
         self.net = nn.Sequential(up, nn.BatchNorm3d(ncout), nn.LeakyReLU()) if is_activate else up
 
     def forward(self, x, skip_in):
