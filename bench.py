@@ -212,7 +212,7 @@ def kernel_table(G, dev, B):
     rows["cam_bp_fwd"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="cam_brick_kernel (dense NCXYZ outputs: one launch)",
                               pmc=["cam_brick_kernel"], src=("common.hpp", "cam_bp.hip"))
     t = event_time_us(lambda: calc_prob_lib.calc_prob_forward(p, s), iters, 5)
-    rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel", pmc=["stop_fwd_vec4_kernel"],
+    rows["calc_prob_fwd"] = dict(us=t, bytes=B * BYTES_CP_FWD, kernels="stop_fwd_vec4_kernel", pmc=["stop_fwd_vec4_kernel<true>" if B * BYTES_CP_FWD // 2 > (128 << 20) else "stop_fwd_vec4_kernel<false>"],
                                  src=("common.hpp", "wave_scan.hpp", "calc_prob.hip"))
     t = event_time_us(lambda: calc_prob_lib.calc_prob_backward_fused(p, s, g, o), iters, 5)
     rows["calc_prob_bwd_fused"] = dict(us=t, bytes=B * BYTES_CP_BWD_FUSED, kernels="stop_bwd_vec4_kernel<fused>",
@@ -285,6 +285,17 @@ def kernel_table(G, dev, B):
                 render_lib.render_bm_backward_gather(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"],
                                                      TB["ray_pre"], TB["g_ent"], TB["g_chunks"], TB["g_blob"],
                                                      TB["g_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0)
+            # The same kernels on a volume whose every sample passes the clamps (`soft`: uniform(0.05, 0.95) / 50 under
+            # pre_scale 50 -- the instantiation the step runs, with a gradient everywhere).  On GenRe's own volume the clamp
+            # blocks every voxel (saturated or empty, depth_pred_with_sph_inpaint.py:124), the backward is identically zero
+            # and the kernels only write zeros (render_bwd_bm below): the roofline of the kernel group is quoted on `soft`.
+            gsoft = torch.Generator(device="cpu").manual_seed(1)
+            soft_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
+            soft_bm.copy_(((torch.rand(proj_bm.shape, generator=gsoft) * 0.9 + 0.05) * 0.02).to(dev))
+
+            def bm_fwd_soft():
+                render_lib.render_bm_forward(soft_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"],
+                                             TB["ray_seg"], TB["ray_pre"], ps, stash, mask, 50.0)
             gather = "g_ent" in TB and _fused_render.bm_backward_mode() == "gather"     # what the step's autograd runs
             rows["render_bwd_bm"] = dict(
                 us=event_time_us(bm_bwd_gather if gather else bm_bwd_scatter, iters, 5),
@@ -293,6 +304,17 @@ def kernel_table(G, dev, B):
                 pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel<4, 8, 8>",
                      "bm_gather_kernel<true>" if gather else "bm_scatter_kernel<true, 4, 8, 8, 768>"],
                 src=("common.hpp", "sph_render_bm.hip"))
+            bm_fwd(True)                                            # (the saved state of the GenRe volume again)
+            rows["render_bwd_bm"]["us"] = event_time_us(bm_bwd_gather if gather else bm_bwd_scatter, iters, 5)
+            rows["render_fwd_bm_soft"] = dict(us=event_time_us(bm_fwd_soft, iters, 5), bytes=B * BYTES_RENDER_FUSED,
+                                              kernels="bm_sample_kernel+bm_combine_fwd_kernel (soft volume)")
+            bm_fwd_soft()
+            rows["render_bwd_bm_soft"] = dict(
+                us=event_time_us(bm_bwd_gather if gather else bm_bwd_scatter, iters, 5),
+                bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
+                kernels=rows["render_bwd_bm"]["kernels"] + " on the soft volume (gradient everywhere)",
+                pmc=rows["render_bwd_bm"]["pmc"], src=("common.hpp", "sph_render_bm.hip"))
+            bm_fwd(True)
             if gather:      # the scatter form (LDS atomics), for comparison
                 rows["render_bwd_bm_scatter"] = dict(us=event_time_us(bm_bwd_scatter, iters, 5),
                                                      bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
@@ -466,26 +488,33 @@ def batch1_graph(G, dev):
     return res
 
 
-def m1_genre_forward(G, dev):
+def m1_capture(G, dev, batches=(1, 8)):
     """BASELINE.json metric, first half: GenRe forward passes per second, 256x256 RGB -> 128^3 voxels, on one GPU.
     The reference's full model (models/genre_full_model.py:116-132: MarrNet-1, the geometric ops, the inpainting
     U-ResNet, the spherical back-projection, Unet_3D) with seeded random weights (no checkpoint ships),
-    eval mode, no_grad; batch 1 and batch 8, each captured once in a HIP graph and replayed."""
+    eval mode, no_grad; each batch size captured once in a HIP graph.  -> {batch: (replay, eager)}"""
     from genre_shapehd_amd.models import GenReNet, GenReInference
     torch.manual_seed(0)
     net = GenReNet().to(dev).eval()
-    res = {"what": "GenRe full-model forward (3 networks + geometric ops), random weights, fp32, HIP-graph replay",
-           "target_fwd_per_s_batch1": 50.0}
-    for n in (1, 8):
+    out = {}
+    for n in batches:
         inf = GenReInference(net, device=dev, graph=True)
         rgb = torch.rand(n, 3, 256, 256, device=dev)
         sil = torch.zeros(n, 1, 256, 256, device=dev)
         sil[:, :, 48:208, 48:208] = 100.0
         inf.predict(rgb, sil)                                             # capture
         g = inf._captured[tuple(rgb.shape)][0]
-        us = event_time_us(g.replay, 10, 2)
         eager = GenReInference(net, device=dev, graph=False)
-        us_eager = event_time_us(lambda: eager.predict(rgb, sil), 10, 2)
+        out[n] = (g.replay, lambda eager=eager, rgb=rgb, sil=sil: eager.predict(rgb, sil), inf)
+    return out
+
+
+def m1_table(cap):
+    res = {"what": "GenRe full-model forward (3 networks + geometric ops), random weights, fp32, HIP-graph replay",
+           "target_fwd_per_s_batch1": 50.0}
+    for n, (replay, eager, _) in cap.items():
+        us = event_time_us(replay, 10, 2)
+        us_eager = event_time_us(eager, 10, 2)
         res["batch%d" % n] = {"ms_per_forward": us / 1e3, "shapes_per_s": n / us * 1e6, "eager_ms": us_eager / 1e3}
     return res
 
@@ -508,50 +537,94 @@ def train_bench(dev, dist, du, world, rank, steps, which=("shapehd", "genre")):
     def fence():
         du.fence(dist, torch.cuda.synchronize)
 
+    def agree(ok):
+        return du.all_agree(dist, ok, dev)
+
     def timed(name, batch, fn, note):
+        """Failures are made COLLECTIVE: a rank whose warm-up or timed loop raised says so in a MIN all-reduce that
+        every rank enters, and all of them drop the config together -- nobody is left waiting in a barrier or in DDP's
+        all-reduce for a rank that has moved on.  (A rank that dies INSIDE a step is bounded by the process group's time-out,
+        dist_utils.init_from_env.)"""
+        err = None
         try:
             for _ in range(2):
                 fn()                                                    # MIOpen find, allocator, DDP bucket build
-            fence()
-            t0 = time.perf_counter()
+        except Exception as e:      # pragma: no cover
+            err = repr(e)[:300]
+        if not agree(err is None):
+            res[name] = {"error": err or "another rank failed in the warm-up steps"}
+            torch.cuda.empty_cache()
+            return
+        fence()
+        t0 = time.perf_counter()
+        try:
             for _ in range(steps):
                 fn()
-            fence()
-            el = du.max_over_ranks(dist, time.perf_counter() - t0, dev)
-            res[name] = {"batch_per_gpu": batch, "ms_per_step": el * 1e3 / steps,
-                         "samples_per_s": world * batch * steps / el, "what": note}
-        except Exception as e:      # pragma: no cover -- never fatal for the bench line
-            res[name] = {"error": repr(e)[:300]}
+        except Exception as e:      # pragma: no cover
+            err = repr(e)[:300]
+        if not agree(err is None):
+            res[name] = {"error": err or "another rank failed in the timed steps"}
+            torch.cuda.empty_cache()
+            return
+        fence()
+        el = du.max_over_ranks(dist, time.perf_counter() - t0, dev)
+        res[name] = {"batch_per_gpu": batch, "ms_per_step": el * 1e3 / steps,
+                     "samples_per_s": world * batch * steps / el, "what": note}
         torch.cuda.empty_cache()
 
     to = lambda ns: type(ns)(**{k: v.to(dev) for k, v in vars(ns).items()})       # noqa: E731
     torch.manual_seed(1234)                                             # identical initial weights on every rank
-    # Every config builds its networks inside its own try block: a failure (out of memory, a DDP construction error) is
-    # reported in the JSON line under that config's key and never takes the bench line with it.
+
+    # Every config builds its networks inside its own try block and the ranks agree on the outcome before anyone runs a step:
+    # a failure (out of memory, a DDP construction error) is reported in the JSON line under that config's key and never
+    # takes the bench line -- or another rank -- with it.
     def config(name, build):
+        """`build` is a generator: everything local to the rank (networks, batch, optimizer) before its `yield`, the DDP
+        wrappers -- whose construction is itself collective -- behind it; the ranks agree in between"""
+        holder = {}
+        gen = build()
         try:
-            build()
+            if os.environ.get("GENRE_BENCH_INJECT_FAILURE") == "%d:%s" % (rank, name):      # tests/test_bench_launcher.py
+                raise RuntimeError("injected failure on rank %d" % rank)
+            next(gen)
         except Exception as e:      # pragma: no cover
-            res.setdefault(name, {"error": repr(e)[:300]})
+            holder["err"] = repr(e)[:300]
+        if not agree("err" not in holder):
+            res[name] = {"error": holder.get("err", "another rank failed to build this config")}
+            torch.cuda.empty_cache()
+            return
+        try:
+            next(gen)
+            holder["err"] = "builder did not finish"
+        except StopIteration as fin:
+            holder["step"] = fin.value
+        except Exception as e:      # pragma: no cover
+            holder["err"] = repr(e)[:300]
+        if agree("step" in holder):
+            timed(name, *holder["step"])
+        else:
+            res[name] = {"error": holder.get("err", "another rank failed to wrap this config")}
         torch.cuda.empty_cache()
 
     def shapehd():      # configs[3]
         ins, vox = T.sketch_batch(8, "cpu", seed=500 + rank)
         ins, vox = to(ins), vox.to(dev)
         net = MS.ShapeHDNet().to(dev).train()
-        model = T.ddp(net, dev, dist)
         optim = torch.optim.Adam(net.marrnet2.parameters(), lr=1e-4, betas=(0.5, 0.9))
-        timed("shapehd_b8", 8, lambda: T.shapehd_train_step(model, optim, ins, vox, 1e-3),
-              "MarrNet-2 fine-tuned against the frozen 3-D critic: forward (incl. frozen copy + critic), backward, Adam")
+        yield
+        model = T.ddp(net, dev, dist)
+        return (8, lambda: T.shapehd_train_step(model, optim, ins, vox, 1e-3),
+                "MarrNet-2 fine-tuned against the frozen 3-D critic: forward (incl. frozen copy + critic), backward, Adam")
 
     def wgangp():       # configs[3]'s critic
         _, vox = T.sketch_batch(8, "cpu", seed=500 + rank)
         vox = vox.to(dev)
         gan = MS.WGANGP(lr=1e-4)
         gan.net_g.to(dev), gan.net_d.to(dev)
+        yield
         gan.net_g, gan.net_d = T.ddp(gan.net_g, dev, dist), T.ddp(gan.net_d, dev, dist)
-        timed("wgangp_b8", 8, lambda: gan.train_on_batch(0, vox),
-              "critic step (real, fake, second-order gradient penalty) + generator step")
+        return (8, lambda: gan.train_on_batch(0, vox),
+                "critic step (real, fake, second-order gradient penalty) + generator step")
 
     def genre():        # configs[4]
         gopt = GenReOptions(joint_train=True)
@@ -560,12 +633,13 @@ def train_bench(dev, dist, du, world, rank, steps, which=("shapehd", "genre")):
             head = net.depth_and_inpaint.net1.decoder_minmax[9]
             head.weight.zero_()
             head.bias.copy_(torch.tensor([1.9, 2.4]))
-        model = T.ddp(net, dev, dist)
         optim = torch.optim.Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.9))
         gin, gt = T.genre_batch(4, "cpu", seed=600 + rank)
         gin, gt = to(gin), to(gt)
-        timed("genre_joint_b4", 4, lambda: T.genre_train_step(model, optim, gin, gt, gopt, chamfer_weight=0.1),
-              "all three modules + cam_bp / render_spherical / spherical back-projection / Chamfer in the graph, Adam")
+        yield
+        model = T.ddp(net, dev, dist)
+        return (4, lambda: T.genre_train_step(model, optim, gin, gt, gopt, chamfer_weight=0.1),
+                "all three modules + cam_bp / render_spherical / spherical back-projection / Chamfer in the graph, Adam")
 
     for name, key, build in (("shapehd", "shapehd_b8", shapehd), ("wgangp", "wgangp_b8", wgangp), ("genre", "genre_joint_b4", genre)):
         if name in which:
@@ -678,6 +752,7 @@ def main():
     # allocator, ctypes) are ~10 % of it.  Capture forward + backward once in a HIP graph and replay it -- the same
     # kernels on the same data, without the gaps (--eager times the plain launches instead).
     run, launch = step, "eager launches"
+    graph_holder = []
     if not args.eager:
         try:
             side = torch.cuda.Stream()
@@ -692,21 +767,49 @@ def main():
             with torch.cuda.graph(graph):
                 out_g = model(depth)
                 out_g.backward(grad_out)
+            graph_holder.append(graph)
             run, launch = graph.replay, "HIP-graph replay of forward + backward"
         except Exception as e:      # pragma: no cover -- fall back to eager launches
             launch = "eager launches (graph capture failed: %s)" % str(e)[:120]
             torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        run()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    fence()
-    elapsed = time.perf_counter() - t0
-    elapsed = dist_utils.max_over_ranks(dist, elapsed, dev)
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = world * B * args.steps / elapsed
+    def timed_steps(fn):
+        """W untimed + exactly K timed calls, barrier + synchronize on both sides, the maximum over ranks"""
+        for _ in range(args.warmup):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        fence()
+        return dist_utils.max_over_ranks(dist, time.perf_counter() - t0, dev)
+
+    hot_elapsed = timed_steps(run)
+    hot = {"what": "configs[1]: 256x256 depth -> cam_bp -> 128^3 voxel -> clamp(x50) -> render_spherical (calc_prob) -> 160x160 "
+                   "spherical map, forward + backward, inputs resident in HBM",
+           "shapes_per_s": world * B * args.steps / hot_elapsed, "ms_per_step": hot_elapsed * 1e3 / args.steps,
+           "batch_per_gpu": B, "steps": args.steps, "step_launch": launch,
+           "render_spherical": "fused" if fused else "reference op sequence (grid_sample + CalcStopProb)",
+           "volume_layout": "batch-minor (image index fastest)" if bm else "NCXYZ",
+           "note": "on GenRe's own volume the x50 clamp blocks every voxel: the gradient through render_spherical is "
+                   "identically zero (as in the reference) and its backward only writes zeros; kernels.render_bwd_bm_soft "
+                   "and `roofline` describe the same kernels where they do work"}
+    # ---- the headline: BASELINE.json's metric -- GenRe full-model forward passes per second, batch 1 per GPU -------
+    del graph_holder[:]
+    torch.cuda.empty_cache()
+    cap, value, ms_per_step, m1_err = None, None, None, None
+    if not args.no_m1:
+        try:
+            cap = m1_capture(G, dev)
+        except Exception as e:      # pragma: no cover
+            m1_err = repr(e)[:300]
+        ok = dist_utils.all_agree(dist, cap is not None, dev)
+        if ok:
+            el = timed_steps(cap[1][0])
+            value, ms_per_step = world * 1 * args.steps / el, el * 1e3 / args.steps
+        elif m1_err is None:
+            m1_err = "another rank failed to build the GenRe forward"
+    if value is None:                      # --no-m1 (or the networks could not be built): the hot-path step is what was timed
+        value, ms_per_step = hot["shapes_per_s"], hot["ms_per_step"]
     train = None
     if not args.no_train:           # every rank takes part (DDP all-reduce); reported in the same JSON line
         torch.cuda.empty_cache()
@@ -715,36 +818,46 @@ def main():
 
     if rank == 0:
         rows = kernel_table(G, dev, B)
-        # kernel groups that are part of the timed step in this mode; the dominant one = the one taking the most time
+        # kernel groups that are part of the hot-path step in this mode
         if not fused:
             in_step = ["cam_bp_fwd", "calc_prob_fwd", "calc_prob_bwd_fused"]
         elif bm:
             in_step = ["cam_bp_fwd_bm", "render_fwd_bm", "render_bwd_bm"]
         else:
             in_step = ["cam_bp_fwd", "render_fwd_fused", "render_bwd_fused"]
-        dom_name = max(in_step, key=lambda k: rows[k]["us"])
+        # the dominant hand-written kernel group: the renderer's backward where it does work (the soft volume); on GenRe's own
+        # volume its gradient is identically zero and the group only writes zeros -- then the slowest group of the step
+        dom_name = "render_bwd_bm_soft" if (bm and "render_bwd_bm_soft" in rows) else max(in_step, key=lambda k: rows[k]["us"])
         dom = rows[dom_name]
         traffic, traffic_src = pmc_traffic(dom.get("pmc", []), B, dom.get("src", ("common.hpp",)))
         m2_us = rows["cam_bp_fwd"]["us"] + rows["calc_prob_fwd"]["us"]
         m2_bytes = rows["cam_bp_fwd"]["bytes"] + rows["calc_prob_fwd"]["bytes"]
         b1 = batch1_graph(G, dev)
+        headline_is_m1 = cap is not None and ms_per_step is not None and value != hot["shapes_per_s"]
         out = {
-            "metric": "hot-path shapes/sec (256x256 depth -> 128^3 vox -> 160x160 sph, fwd+bwd) ; "
-                      "GenRe fwd shapes/sec in m1 ; cam_bp+calc_prob HBM GB/s vs roofline in m2 / m2_batch1",
+            "metric": "GenRe fwd shapes/sec (256\u00b2 RGB\u2192128\u00b3 vox) @1 GPU; cam_bp+calc_prob HBM GB/s vs roofline"
+                      if headline_is_m1 else "hot-path shapes/sec (configs[1] fwd+bwd); GenRe forward not timed (--no-m1)",
             "value": value, "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: cam_bp + calc_prob fwd/bwd, 256x256 depth -> 128^3 voxel -> "
-                                   "128x128x256 rays -> 160x160 spherical", "batch_per_gpu": B,
-                       "render_spherical": "fused" if fused else "reference op sequence (grid_sample + CalcStopProb)",
-                       "volume_layout": "batch-minor (image index fastest)" if bm else "NCXYZ",
-                       "step_launch": launch,
+            "config": {"workload": ("configs[2]-shape GenRe full_model forward (MarrNet-1 + depth_pred_with_sph_inpaint + voxel "
+                                    "refiner, geometric ops in-stream), batch 1 per GPU, HIP-graph replay, seeded random weights "
+                                    "(batch 8 in m1.batch8); the configs[1] hot-path step is `hot_path`") if headline_is_m1
+                       else hot["what"],
+                       "batch_per_gpu": 1 if headline_is_m1 else B, "target_fwd_per_s": 50.0,
                        "parallelism": "batch-sharded x%d, no collective" % world},
+            "hot_path": hot,
             "roofline": {"bound": "hbm", "kernel": dom_name + " (" + dom["kernels"] + ")",
                          "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["us"]},
+            "roofline_m2": {"what": "BASELINE.json's second quantity: cam_bp fwd + calc_prob fwd, algorithmic bytes (50 593 792 "
+                                    "per image) / time against 8 TB/s; target >= 0.40 at batch 1",
+                            "batch1": {"frac": b1["frac"], "GBs": b1["GBs"], "us_per_image": b1["us_per_image"],
+                                       "launch": "HIP-graph replay, one stream", "target_frac": 0.40},
+                            "batch%d" % B: {"frac": m2_bytes / m2_us / 1e3 / HBM_PEAK_GBS, "GBs": m2_bytes / m2_us / 1e3,
+                                            "us_per_image": m2_us / B}},
             "m2": {"what": "cam_bp fwd + calc_prob fwd, algorithmic bytes / time, batch %d" % B,
                    "achieved": m2_bytes / m2_us / 1e3, "unit": "GB/s", "frac": m2_bytes / m2_us / 1e3 / HBM_PEAK_GBS,
                    "us_per_image": m2_us / B},
@@ -766,15 +879,20 @@ def main():
             "batch1": b1,
         }
         if not args.no_m1:
-            try:
-                m1 = m1_genre_forward(G, dev)
-                geo = b1.get("genre_geometry_fwd_us_per_image")
-                if geo:
-                    m1["geometry_us_batch1"] = geo
-                    m1["geometry_share_batch1"] = geo / (m1["batch1"]["ms_per_forward"] * 1e3)
-                out["m1"] = m1
-            except Exception as e:          # pragma: no cover -- never fatal for the bench line
-                out["m1"] = {"error": str(e)[:300]}
+            if cap is not None:
+                try:
+                    m1 = m1_table(cap)
+                    m1["timed_region"] = {"steps": args.steps, "warmup": args.warmup, "ms_per_forward": ms_per_step,
+                                          "shapes_per_s": value, "note": "the bench line's `value`: barrier-bracketed, max over ranks"}
+                    geo = b1.get("genre_geometry_fwd_us_per_image")
+                    if geo:
+                        m1["geometry_us_batch1"] = geo
+                        m1["geometry_share_batch1"] = geo / (m1["batch1"]["ms_per_forward"] * 1e3)
+                    out["m1"] = m1
+                except Exception as e:          # pragma: no cover -- never fatal for the bench line
+                    out["m1"] = {"error": str(e)[:300]}
+            else:
+                out["m1"] = {"error": m1_err}
         if train is not None:
             out["train"] = train
         if not args.no_cpu_baseline:

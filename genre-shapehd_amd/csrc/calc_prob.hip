@@ -37,8 +37,12 @@ namespace {
 #define GENRE_CP_BLOCK 256                     // tools/ab_round4.py: workgroup size of the stop-probability kernels
 #endif
 #ifndef GENRE_CP_NT
-#define GENRE_CP_NT 3                          // bit 0: nontemporal loads, bit 1: nontemporal stores
+#define GENRE_CP_NT 3                          // bit 1: nontemporal stores; bit 0 CLEARED: plain loads at every size (A/B)
 #endif
+// The forward's loads are nontemporal only when the tensor cannot stay in the 256 MiB Infinity Cache between launches.
+// Measured (profiles/r04b_ab_experiments.txt): one image (16 MiB of prob_in, re-read by every request of a serving loop)
+// 5.86 us with nontemporal loads, 4.73 us with plain ones; batch 32 (512 MiB) 165 us nontemporal, 170 us plain.
+constexpr int64_t kStreamBytes = (int64_t)128 << 20;
 constexpr int kBlock = GENRE_CP_BLOCK;         // 4 waves = 4 rays in flight per block
 constexpr int kWavesPerBlock = kBlock / 64;
 
@@ -77,10 +81,11 @@ __device__ __forceinline__ int64_t ray_base(const RayDims &D, const RayView &v, 
 
 // streaming accesses: every byte is touched exactly once, keep it out of the way of L2
 typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT = true>
 __device__ __forceinline__ float4 nt_load4(const float *p)
 {
-    const v4f v = (GENRE_CP_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p))
-                                    : *reinterpret_cast<const v4f *>(p);
+    const v4f v = (NT && (GENRE_CP_NT & 1)) ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p))
+                                            : *reinterpret_cast<const v4f *>(p);
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void nt_store4(float *p, const float4 &s)
@@ -91,6 +96,7 @@ __device__ __forceinline__ void nt_store4(float *p, const float4 &s)
 }
 
 // ---- forward, float4 path: z stride 1, Z % 4 == 0, 16-B aligned rays ----------------
+template <bool NTLOAD>
 __global__ __launch_bounds__(kBlock) void stop_fwd_vec4_kernel(RayDims D, RayView pin, RayView pout)
 {
     const int lane = threadIdx.x & 63;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void stop_fwd_vec4_kernel(RayDims D, RayVie
             const int z = z0 + lane * 4;
             const bool live = z < D.Z;
             float4 p = make_float4(0.f, 0.f, 0.f, 0.f);       // p = 0 -> factor 1 (neutral)
-            if (live) p = nt_load4(src + z);
+            if (live) p = nt_load4<NTLOAD>(src + z);
             const double q0 = 1.0 - (double)p.x, q1 = 1.0 - (double)p.y;
             const double q2 = 1.0 - (double)p.z, q3 = 1.0 - (double)p.w;
             const double e1 = q0, e2 = q0 * q1, e3 = e2 * q2, tot = e3 * q3;
@@ -294,8 +300,12 @@ extern "C" int genre_calc_prob_forward(const genre_tensor *prob_in, const genre_
     const RayDims D = ray_dims(prob_in);
     if (D.rays == 0 || D.Z == 0) return 1;
     hipStream_t st = (hipStream_t)stream;
-    if (vec4_ok(prob_in) && vec4_ok(prob_out))
-        stop_fwd_vec4_kernel<<<grid_for_rays(D.rays), kBlock, 0, st>>>(D, ray_view(prob_in), ray_view(prob_out));
+    if (vec4_ok(prob_in) && vec4_ok(prob_out)) {
+        if (D.rays * D.Z * 4 > kStreamBytes)
+            stop_fwd_vec4_kernel<true><<<grid_for_rays(D.rays), kBlock, 0, st>>>(D, ray_view(prob_in), ray_view(prob_out));
+        else
+            stop_fwd_vec4_kernel<false><<<grid_for_rays(D.rays), kBlock, 0, st>>>(D, ray_view(prob_in), ray_view(prob_out));
+    }
     else
         stop_fwd_generic_kernel<<<grid_for_rays(D.rays), kBlock, 0, st>>>(D, ray_view(prob_in), ray_view(prob_out));
     GENRE_LAUNCH_CHECK("calc_prob forward");

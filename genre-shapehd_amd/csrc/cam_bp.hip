@@ -585,13 +585,20 @@ __device__ __forceinline__ void divmod_px(int t, int d, float inv_d, int &r, int
 // passed while the loads are in flight, every pixel goes through the per-pixel plane-depth test the live bricks apply
 // anyway (a dozen vector instructions), and "live" is whether any pixel landed -- one barrier behind the loads instead of
 // two and a reduction.  Same output bit for bit: a brick the range screen calls dead has no landing pixel
-// (tests/test_cam_brick_screens.py), and a live brick without hits writes the fill values from its empty tile.  At batch
-// 32 the kernel is bandwidth-bound and the extra per-pixel arithmetic of the 77 % dead bricks costs more than the barrier.
+// (tests/test_cam_brick_screens.py), and a live brick without hits writes the fill values from its empty tile.
+// Measured (tools/ab_round4.py, profiles/r04b_ab_experiments.txt; one MI355X, HIP-graph replay at batch 1, events at batch 32):
+//   variant                                   batch 1           batch 32
+//   range screen, plain stores (round 3)      9.63 us           150.1 us
+//   pixel screen                              9.00 us           144.5 us
+//   range screen, nontemporal stores          8.13 us           143.9 us
+//   pixel screen, nontemporal stores          7.49 us           143.7 us      <- the build default
+// (outputs bit-identical in all four).  The 16 MB of the two volumes are written once and read by another kernel much
+// later: kept out of L2 they do not have to be written back at the end of the kernel, where nothing overlaps it.
 #ifndef GENRE_CAMQ_PIXELSCREEN_MAXN
-#define GENRE_CAMQ_PIXELSCREEN_MAXN 0              // images per launch up to which the PIXELSCREEN instantiation is used
+#define GENRE_CAMQ_PIXELSCREEN_MAXN 0x7fffffff     // images per launch up to which the PIXELSCREEN instantiation is used
 #endif
 #ifndef GENRE_CAMQ_NT
-#define GENRE_CAMQ_NT 0                            // tools/ab_round4.py: 1 = nontemporal stores of the brick
+#define GENRE_CAMQ_NT 1                            // nontemporal stores of the brick (0: plain stores, for the A/B)
 #endif
 template <typename T>
 __device__ __forceinline__ void camq_store4(float *p, const T &v)
@@ -1091,7 +1098,6 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
             const int64_t bricks = (int64_t)((D.X + kQX - 1) / kQX) * ((D.Y + kQY - 1) / kQY) * ((D.Z + kQZ - 1) / kQZ);
             GENRE_REQUIRE(bricks < ((int64_t)1 << 31), "%s: volume too large", op);
             const dim3 bgrid((unsigned)bricks, D.N * D.NC);
-            // small batches are bound by the chain behind the pixel loads, large ones by bandwidth (cam_brick_kernel: PIXELSCREEN)
             const bool pixelscreen = D.N * D.NC <= GENRE_CAMQ_PIXELSCREEN_MAXN;
 #define GENRE_CAMQ_LAUNCH(BV, PXS, A, B_)                                                                                 \
             cam_brick_kernel<BV, PXS><<<bgrid, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias, \

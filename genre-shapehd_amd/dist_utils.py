@@ -25,7 +25,9 @@ def init_from_env(backend="nccl", device=None):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    kw = {}
+    import datetime
+    # a rank that dies inside a step leaves the others in a collective it never joins: bounded, not forever
+    kw = {"timeout": datetime.timedelta(minutes=int(os.environ.get("GENRE_DIST_TIMEOUT_MIN", "15")))}
     if backend == "nccl" and device is not None:
         kw["device_id"] = device
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
@@ -60,6 +62,16 @@ def max_over_ranks(dist, value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
+
+
+def all_agree(dist, ok, device="cpu"):
+    """True iff `ok` holds on EVERY rank (a MIN all-reduce): a rank that failed to build a model or ran out of memory tells the
+    others before they enter a collective it would never join"""
+    if dist is None:
+        return bool(ok)
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t.item() > 0.5
 
 
 def gather_batch(dist, local, total):

@@ -16,8 +16,9 @@ from .thin_conv import ThinConv3d, ThinConvTranspose3d
 
 
 def _up3(cin, cout, bias):                 # x2
-    # one output channel at 128^3: MIOpen's weight gradient is its naive reference kernel (283 ms at batch 8) -- thin_conv.py
-    return (ThinConvTranspose3d if cout == 1 else nn.ConvTranspose3d)(cin, cout, 4, 2, 1, bias=bias)
+    # at >= 64^3 MIOpen's weight gradient is its naive reference kernel (283 ms for the 1-channel output layer at batch 8) or a
+    # 40 ms CK kernel: thin_conv.py computes it as a blocked GEMM there and is nn.ConvTranspose3d everywhere else
+    return ThinConvTranspose3d(cin, cout, 4, 2, 1, bias=bias)
 
 
 def _grow3(cin, cout, bias):               # 1^3 -> 4^3
@@ -104,8 +105,7 @@ class VoxelDiscriminator(nn.Module):
 class Conv3d_block(nn.Module):
     def __init__(self, ncin, ncout, kernel_size, stride, pad, dropout=False):
         super().__init__()
-        conv = ThinConv3d if ncin <= 2 else nn.Conv3d               # two input channels at 128^3: thin_conv.py
-        self.net = nn.Sequential(conv(ncin, ncout, kernel_size, stride, pad), nn.BatchNorm3d(ncout), nn.LeakyReLU())
+        self.net = nn.Sequential(ThinConv3d(ncin, ncout, kernel_size, stride, pad), nn.BatchNorm3d(ncout), nn.LeakyReLU())
 
     def forward(self, x):
         return self.net(x)
@@ -114,7 +114,7 @@ class Conv3d_block(nn.Module):
 class Deconv3d_skip(nn.Module):
     def __init__(self, ncin, ncout, kernel_size, stride, pad, extra=0, is_activate=True):
         super().__init__()
-        up = (ThinConvTranspose3d if ncout == 1 else nn.ConvTranspose3d)(ncin, ncout, kernel_size, stride, pad, extra)
+        up = ThinConvTranspose3d(ncin, ncout, kernel_size, stride, pad, extra)
         self.net = nn.Sequential(up, nn.BatchNorm3d(ncout), nn.LeakyReLU()) if is_activate else up
 
     def forward(self, x, skip_in):

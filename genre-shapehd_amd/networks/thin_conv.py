@@ -1,5 +1,6 @@
-"""3-D convolutions with ONE thin channel dimension at 128^3 -- the layers on which MIOpen has no usable weight-gradient
-solver on gfx950 (ROCm 7.2).  Measured (profiles/r04a_train_*_kernel_stats.txt, fp32, one MI355X):
+"""Weight gradients of the 3-D convolutions at 64^3 and 128^3 as blocked GEMMs -- the layers on which MIOpen has no usable
+weight-gradient solver on gfx950 (ROCm 7.2).  Measured (profiles/r04a_train_*_kernel_stats.txt, fp32, one MI355X; the
+find-db entries of the same run):
 
     layer (reference: networks/networks.py, networks/uresnet.py)     weight gradient, stock            here
     ConvTranspose3d(32 -> 1, k4 s2 p1) 64^3 -> 128^3, batch 8      283 ms  ConvDirectNaiveConvWrw     GEMM
@@ -7,6 +8,10 @@ solver on gfx950 (ROCm 7.2).  Measured (profiles/r04a_train_*_kernel_stats.txt, 
     ConvTranspose3d(64 -> 1), batch 8  (3-D GAN generator output)   283 ms  ConvDirectNaiveConvWrw
     ConvTranspose3d(40 -> 1), batch 4  (Unet_3D dec6)               132 ms  ConvDirectNaiveConvWrw
     Conv3d(2 -> 20, k8 s2 p3) 128^3 -> 64^3, batch 4 (Unet_3D enc1) 155 ms  ConvHipImplicitGemm3DGroupWrwXdlops
+    ConvTranspose3d(64 -> 32, k4 s2 p1) 32^3 -> 64^3, batch 8       40 ms  ConvHipImplicitGemm3DGroupWrwXdlops (CK batched GEMM)
+    ConvTranspose3d(64 -> 64), batch 8 (generator)                   41 ms  same
+    Conv3d(20 -> 40, k4 s2 p1) 64^3 -> 32^3, batch 4 (Unet_3D enc2)  20 ms  same
+    ConvTranspose3d(80 -> 20, k8 s2 p3) 32^3 -> 64^3 (Unet_3D dec5)  20 ms  same
 
 MIOpen's find step ranks a *naive reference kernel* first for them (the implicit-GEMM and GEMM solvers are slower still):
 with one output (or two input) channels the weight gradient is a [C x taps] matrix reduced over 2-17 M voxels, a shape
@@ -145,26 +150,34 @@ class _ThinConv3dFn(Function):
         return gx, gw, gb, None, None
 
 
-def _custom_path(x, mod):
-    """the GEMM weight gradient serves fp32 training on the GPU; everything else (CPU, float64, inference, graphs that will be
-    differentiated twice -- the WGAN-GP penalty) keeps the stock operator"""
+_BIG = 64 ** 3              # voxels per sample (of the larger side) from which MIOpen's weight-gradient solvers fall off
+
+
+def _custom_path(x, mod, voxels):
+    """the GEMM weight gradient serves fp32 training on the GPU at >= 64^3; everything else (CPU, float64, inference, small
+    volumes, graphs that will be differentiated twice -- the WGAN-GP penalty runs through the critic, which keeps
+    nn.Conv3d) takes the stock operator"""
+    if getattr(mod, "force_custom", False):
+        return True
     return (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and mod.weight.requires_grad
-            and not getattr(mod, "force_stock", False) and mod.dilation == (1, 1, 1) and mod.groups == 1)
+            and voxels >= _BIG and not getattr(mod, "force_stock", False) and mod.dilation == (1, 1, 1) and mod.groups == 1)
 
 
 class ThinConvTranspose3d(nn.ConvTranspose3d):
-    """nn.ConvTranspose3d whose weight gradient is the blocked GEMM above (thin OUTPUT channels)"""
+    """nn.ConvTranspose3d whose weight gradient is the blocked GEMM above when its OUTPUT has >= 64^3 voxels"""
 
     def forward(self, x, output_size=None):
-        if output_size is not None or self.output_padding != (0, 0, 0) or not (_custom_path(x, self) or getattr(self, "force_custom", False)):
+        vox = x.shape[2] * x.shape[3] * x.shape[4] * self.stride[0] * self.stride[1] * self.stride[2] if x.dim() == 5 else 0
+        if output_size is not None or self.output_padding != (0, 0, 0) or not _custom_path(x, self, vox):
             return super().forward(x, output_size)
         return _ThinConvTranspose3dFn.apply(x, self.weight, self.bias, self.stride, self.padding)
 
 
 class ThinConv3d(nn.Conv3d):
-    """nn.Conv3d whose weight gradient is the blocked GEMM above (thin INPUT channels)"""
+    """nn.Conv3d whose weight gradient is the blocked GEMM above when its INPUT has >= 64^3 voxels"""
 
     def forward(self, x):
-        if self.padding_mode != "zeros" or not (_custom_path(x, self) or getattr(self, "force_custom", False)):
+        vox = x.shape[2] * x.shape[3] * x.shape[4] if x.dim() == 5 else 0
+        if self.padding_mode != "zeros" or not _custom_path(x, self, vox):
             return super().forward(x)
         return _ThinConv3dFn.apply(x, self.weight, self.bias, self.stride, self.padding)

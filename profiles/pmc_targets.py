@@ -50,6 +50,12 @@ if TB is not None:
     out_p = torch.empty((B, 1, 160, 160), device=dev)
     gout_p = torch.randn_like(out_p)
     gvox_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
+    # the batch-minor renderer is profiled on the SOFT volume (every sample passes the clamps: a gradient everywhere) --
+    # bench.py: kernels.render_bwd_bm_soft, what `roofline` is quoted on.  On GenRe's own volume the x50 clamp blocks every
+    # voxel and the backward kernels only write zeros (kernels.render_bwd_bm).
+    gsoft = torch.Generator(device="cpu").manual_seed(1)
+    soft_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
+    soft_bm.copy_(((torch.rand(proj_bm.shape, generator=gsoft) * 0.9 + 0.05) * 0.02).to(dev))
 for _ in range(3):
     cam_bp_lib.back_projection_forward_shifted(d, cd, fl, tdf, cnt)
     calc_prob_lib.calc_prob_forward(p, s)
@@ -58,7 +64,7 @@ for _ in range(3):
     lib.render_spherical_backward(tdf, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"],
                                   vbuf, T["kin"], 50.0)
     if TB is not None:
-        lib.render_bm_forward(proj_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"], TB["ray_seg"],
+        lib.render_bm_forward(soft_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"], TB["ray_seg"],
                               TB["ray_pre"], ps, stash, mask, 50.0)
         lib.render_bm_backward(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"],
                                TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, trs, stash, mask, 50.0, TB["pull_code"])

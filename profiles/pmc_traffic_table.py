@@ -2,8 +2,12 @@
 usage: python profiles/pmc_traffic_table.py fetch_results.db write_results.db [out.json batch]
 With out.json: also writes the table bench.py reads for roofline.traffic -- per kernel the corrected HBM bytes per
 launch, stamped with the sha256 of the kernel sources it was measured on (bench.py: source_sha) and the batch size.
-gfx950 correction (MI355X_MICROARCH.md): FETCH_SIZE reports half the bytes of a wide coalesced read stream, so it is
-doubled; units are KB."""
+gfx950 correction: FETCH_SIZE reports HALF the bytes read, whatever the access shape -- settled in round 4 with
+tools/fetch_size_bench.hip, four kernels that read the same 256 MiB exactly once (profiles/r04b_fetch_size_probe.txt):
+    16 B / lane consecutive 0.500, 4 B / lane consecutive 0.500, scattered 128-byte lines read 4 B / lane 0.500, the same lines
+    read 16 B / lane 0.500 of the true byte count
+-- so it is doubled for EVERY kernel (rounds 1-3 doubled it only for the wide streams of WIDE_STREAMS below and under-counted
+the reads of the gather-type kernels by half); units are KB."""
 import collections
 import json
 import os
@@ -11,10 +15,10 @@ import re
 import sqlite3
 import sys
 
-# kernels whose reads are wide (16 B / lane) coalesced streams: FETCH_SIZE doubled (MI355X_MICROARCH.md, "HBM"); for the
-# others -- 4 B / lane gathers and line reads -- the counter was found NOT to be halved (profiles/r01g_pmc_hbm_traffic.txt)
+# (kept for the record: the kernels rounds 1-3 doubled; everything else was taken at face value then)
 WIDE_STREAMS = ("fill2_vec4_kernel", "stop_fwd_vec4_kernel", "stop_bwd_vec4_kernel", "render_scan_fwd_kernel",
                 "render_scan_bwd_kernel", "bm_sample_kernel")
+FETCH_FACTOR = 2
 
 
 def per_kernel(db, counter):
@@ -44,7 +48,7 @@ for k in sorted(set(fetch) | set(write), key=short):
         continue
     f = sum(fetch.get(k, [0])) / max(1, len(fetch.get(k, [0])))
     w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
-    factor = 2 if short(k).split("<")[0] in WIDE_STREAMS else 1
+    factor = FETCH_FACTOR
     hbm = (factor * f + w) * 1024
     table[short(k)] = dict(dispatches=len(fetch.get(k, [])), fetch_kb=f, write_kb=w, fetch_factor=factor, hbm_bytes=hbm)
     print("%-40s %10d %14.0f %14.0f %6d %12.1f" % (short(k)[:40], len(fetch.get(k, [])), f, w, factor, hbm / 1e6))

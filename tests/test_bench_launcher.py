@@ -51,3 +51,20 @@ def test_train_section_runs_on_every_rank_under_ddp():
     assert a["shapehd_b8"]["batch_per_gpu"] == 8 and a["shapehd_b8"]["samples_per_s"] > 0
     assert a["shapehd_b8"]["ms_per_step"] == b["shapehd_b8"]["ms_per_step"]             # max over ranks: one number
     assert abs(a["shapehd_b8"]["samples_per_s"] * a["shapehd_b8"]["ms_per_step"] / 1e3 - world * 8) < 1e-6
+
+
+def _failing_worker(rank, world, port, ret):
+    os.environ["GENRE_BENCH_INJECT_FAILURE"] = "1:shapehd_b8"           # rank 1 cannot build the config
+    _train_worker(rank, world, port, ret)
+
+
+def test_a_failure_on_one_rank_drops_the_config_on_every_rank():
+    """the train section runs on every rank before rank 0 prints the bench line; a rank that fails must not leave
+    the others in a barrier / all-reduce.  Rank 1's build raises: both ranks agree (MIN all-reduce), both report the config
+    as failed, and both reach the end of the section."""
+    import torch.multiprocessing as mp
+    world, port = 2, 34600 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_failing_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert "error" in ret[0]["shapehd_b8"] and "error" in ret[1]["shapehd_b8"], dict(ret)
+    assert "injected" in ret[1]["shapehd_b8"]["error"] and "another rank" in ret[0]["shapehd_b8"]["error"]

@@ -42,7 +42,7 @@ def test_thin_modules_keep_the_state_dict_and_the_stock_path_off_the_gpu():
     b.load_state_dict(a.state_dict())
     x = torch.randn(2, 4, 3, 3, 3)
     assert torch.equal(a(x), b(x))
-    assert not TC._custom_path(x, a)                           # CPU tensors: stock operator, differentiable twice
+    assert not TC._custom_path(x, a, 128 ** 3)                 # CPU tensors: stock operator, differentiable twice
     y = a(x.requires_grad_(True))
     gx, = torch.autograd.grad(y.sum(), x, create_graph=True)
     gx.pow(2).sum().backward()
