@@ -37,6 +37,7 @@
 //    (pre_scale); its adjoint mask is one bit per voxel and image, written by the forward (the brick that owns the
 //    voxel), read by the backward's flush -- the volume itself is not read again.
 #include "common.hpp"
+#include <type_traits>
 
 namespace genre {
 namespace {
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
             }
         }
     }
+    unsigned tile_bits = 0u;                                           // OR of every mask bit this thread staged (halo included)
 #pragma unroll
     for (int j = 0; j < kIter; j++) {
         const int t = threadIdx.x + j * NT;
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
             }
         }
         if (t < kLinesF * 8) *reinterpret_cast<float4 *>(tile + line * kImgs + piece * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        tile_bits |= bits;
         if (PS && SAVE) {
             // the 8 threads of a line sit in 8 consecutive lanes: OR their nibbles together with DPP
             bits <<= piece * 4;
@@ -160,7 +163,29 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
             }
         }
     }
+    // SAVED STATE ONLY WHERE A GRADIENT CAN COME BACK.  With pre_scale the backward multiplies every voxel's sum by its clamp
+    // mask; a segment of this brick touches voxels of this tile (brick + high halo) only, so if NO voxel of the staged tile
+    // passes the clamp in any image, nothing that is computed from these segments' saved samples survives the backward's
+    // flush -- their 4 B per sample and image (the forward's only per-sample stream: 117 us of 277 at batch 32) are not
+    // written.  (A neighbouring brick that is live may still pull such a segment and scan whatever the buffer holds: its
+    // contributions land on voxels of THIS tile, all of which the mask zeroes -- by a select, so not even a NaN survives.)
+    // On GenRe's own volume (x50 of a saturated or empty voxel, depth_pred_with_sph_inpaint.py:124) that is every tile.
+    unsigned *wflags = reinterpret_cast<unsigned *>(recs + (NT / 64) * 64 * 4);      // one word per wave
+    if (PS && SAVE) {
+        const unsigned long long hit = __ballot(tile_bits != 0u);
+        if ((threadIdx.x & 63) == 0) wflags[threadIdx.x >> 6] = hit ? 1u : 0u;
+    }
     __syncthreads();
+    bool save_rt = SAVE;
+    if (PS && SAVE) {
+        unsigned any = 0u;
+#pragma unroll
+        for (int i = 0; i < NT / 64; i += 4) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(wflags + i);
+            any |= w.x | w.y | w.z | w.w;
+        }
+        save_rt = __builtin_amdgcn_readfirstlane((int)any) != 0;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int half = lane >> 5, l = lane & 31;
     // A wave's records in LDS: the 48-byte table records of the segment, as they come -- every lane parks its 16 bytes
@@ -189,13 +214,17 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     int4 sg = segs[s];
     int4 sg1 = segs[min(s + NW, s_last)];
     int4 rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)sg.w * kRec)[lane];     // lane's 16 bytes of the records
+    // the march, compiled twice where SAVE: with and without the stores of the saved samples (the choice is per workgroup and
+    // made once, outside the loop: every wait inside stays exact)
+    auto march = [&](auto save_c) {
+    constexpr bool SV = decltype(save_c)::value;
     float sp[kMaxSeg / 2];                                             // this half-wave's saved sample of pair j
     float ps_val = 0.f;
     int Lprev = 0;
     float *stp_prev = nullptr, *ps_prev = nullptr;
     auto flush_prev = [&]() {                                          // the previous segment's stores
         if (Lprev == 0) return;
-        if (SAVE) {
+        if (SV) {
 #pragma unroll
             for (int j = 0; j < kMaxSeg / 2; j++)      // samples 2j (lower half-wave) and 2j + 1 (upper): one 256-byte store
                 if (2 * j < Lprev && (2 * j + 1 < Lprev || half == 0)) (stp_prev + (2 * j) * kImgs)[lo_st] = sp[j];
@@ -236,12 +265,15 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
         }
         ps_val = half ? S : T;
         Lprev = L;
-        stp_prev = SAVE ? stash + ((size_t)g * D.nslot + slot0) * kImgs : nullptr;
+        stp_prev = SV ? stash + ((size_t)g * D.nslot + slot0) * kImgs : nullptr;
         ps_prev = ps + (size_t)(g * D.nseg + __builtin_amdgcn_readfirstlane(sg.x)) * 2 * kImgs;   // its line: ray order
         wave_lds_fence();                                                             // records are overwritten next
         sg = sg1; sg1 = sg2;
     }
     flush_prev();
+    };
+    if (SAVE && save_rt) march(std::true_type{});
+    else march(std::false_type{});
 }
 
 // sph_pad (spherical_proj.py:21-28) as a fan-out of map pixel (i, j): see sph_render.hip: pad_span
@@ -1032,7 +1064,7 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
     }
     // 1024 threads: 16 waves share one tile, two workgroups per CU = 8 waves per SIMD (measured 257 us against 318 with 512)
     constexpr int nt = 1024;
-    const size_t lds = (size_t)kLinesF * kImgs * 4 + (size_t)(nt / 64) * 64 * 16;
+    const size_t lds = (size_t)kLinesF * kImgs * 4 + (size_t)(nt / 64) * 64 * 16 + (size_t)(nt / 64) * 4;   // tile, records, wave flags
     const dim3 grid((unsigned)fwd_rows->size[0], (unsigned)D.groups);
 #define GENRE_BM_SAMPLE_NT(PSV, SV, NTV)                                                                                  \
     do {                                                                                                                  \

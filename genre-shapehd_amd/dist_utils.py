@@ -74,6 +74,21 @@ def all_agree(dist, ok, device="cpu"):
     return t.item() > 0.5
 
 
+def average_float_buffers(dist, nets):
+    """BatchNorm running statistics stay PER RANK during training (train.py: broadcast_buffers=False, no SyncBN -- the reference
+    has neither).  A checkpoint is written by rank 0 only, so without this it would carry rank 0's statistics alone and every
+    rank would resume from them: the launcher calls this once before saving / evaluating -- floating-point buffers are
+    replaced by their mean over the ranks (integer buffers such as num_batches_tracked are identical already)."""
+    if dist is None:
+        return
+    world = dist.get_world_size()
+    for net in nets:
+        for b in net.buffers():
+            if b.is_floating_point():
+                dist.all_reduce(b, op=dist.ReduceOp.SUM)
+                b.div_(world)
+
+
 def gather_batch(dist, local, total):
     """assemble variable-size batch shards into [total, ...] on every rank (a convenience for
     callers; the hot path itself never needs it)"""

@@ -26,7 +26,7 @@ def _grow3(cin, cout, bias):               # 1^3 -> 4^3
 
 
 def _down3(cin, cout, bias):               # /2
-    return nn.Conv3d(cin, cout, 4, 2, 1, bias=bias)
+    return ThinConv3d(cin, cout, 4, 2, 1, bias=bias)
 
 
 def _bn_relu3(c):

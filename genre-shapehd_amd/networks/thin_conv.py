@@ -25,8 +25,9 @@ once per call by the contraction: <= 0.55 GB at the shapes above, in chunks of t
 into blocks that run as a batched GEMM (a single [32 x 64] output tile would occupy one workgroup of the chip).  Forward and
 data gradient stay MIOpen's (its solvers for those directions are fine: 0.3-4 ms).
 
-The modules are drop-in subclasses: same parameters, same state_dict keys, same forward values; float64 / CPU tensors and
-double-backward graphs (create_graph=True) take the stock path."""
+The modules are drop-in subclasses: same parameters, same state_dict keys, same forward values; float64 / CPU tensors take
+the stock path.  The data gradient can be differentiated a second time (the WGAN-GP gradient penalty), and that second
+differentiation meets the GEMM weight gradient again; the weight gradient itself is first order."""
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -103,30 +104,61 @@ def regular_weight_grad(x, gy, weight_shape, stride, padding):
     return out
 
 
-class _ThinConvTranspose3dFn(Function):
+class _TransposedWgradFn(Function):
+    """the weight gradient itself as an opaque op: under create_graph=True (the WGAN-GP penalty differentiates the critic's INPUT
+    gradient a second time, not this) no graph is recorded through the unfold / GEMM and nothing but x and gy is kept"""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding):
-        ctx.save_for_backward(x, weight)
-        ctx.cfg = (stride, padding, bias is not None)
-        return F.conv_transpose3d(x, weight, bias, stride, padding)
+    def forward(ctx, x, gy, weight_shape, stride, padding):
+        return transposed_weight_grad(x, gy, weight_shape, stride, padding)
 
     @staticmethod
     @once_differentiable
+    def backward(ctx, g):
+        raise NotImplementedError("thin_conv: the weight gradient is not differentiable a second time (use nn.ConvTranspose3d)")
+
+
+class _RegularWgradFn(Function):
+    @staticmethod
+    def forward(ctx, x, gy, weight_shape, stride, padding):
+        return regular_weight_grad(x, gy, weight_shape, stride, padding)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        raise NotImplementedError("thin_conv: the weight gradient is not differentiable a second time (use nn.Conv3d)")
+
+
+class _ThinConvTranspose3dFn(Function):
+    """y = conv_transpose3d(x, w, b).  The backward is written with differentiable operators -- the data gradient is the adjoint
+    convolution THROUGH _ThinConv3dFn, so that a second differentiation (create_graph=True: the gradient penalty of the 3-D
+    WGAN-GP runs the critic's input gradient through autograd once more, models/wgangp.py:131-147) meets the GEMM weight
+    gradient again instead of MIOpen's; the weight gradient is opaque (first order only)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, output_padding=(0, 0, 0)):
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, output_padding, bias is not None)
+        return F.conv_transpose3d(x, weight, bias, stride, padding, output_padding)
+
+    @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        stride, padding, has_bias = ctx.cfg
+        stride, padding, output_padding, has_bias = ctx.cfg
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:                                   # adjoint of a transposed convolution: a convolution
-            gx = F.conv3d(gy, weight, None, stride, padding)
+            gx = _ThinConv3dFn.apply(gy, weight, None, stride, padding)
         if ctx.needs_input_grad[1]:
-            gw = transposed_weight_grad(x, gy, weight.shape, stride, padding)
+            gw = _TransposedWgradFn.apply(x, gy, tuple(weight.shape), stride, padding)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3, 4))
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 class _ThinConv3dFn(Function):
+    """y = conv3d(x, w, b); see _ThinConvTranspose3dFn (its mirror image)"""
+
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding):
         ctx.save_for_backward(x, weight)
@@ -134,17 +166,16 @@ class _ThinConv3dFn(Function):
         return F.conv3d(x, weight, bias, stride, padding)
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         stride, padding, has_bias = ctx.cfg
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            opad = [x.shape[2 + d] - ((gy.shape[2 + d] - 1) * stride[d] - 2 * padding[d] + weight.shape[2 + d]) for d in range(3)]
-            gx = F.conv_transpose3d(gy, weight, None, stride, padding, output_padding=opad)
+            opad = tuple(x.shape[2 + d] - ((gy.shape[2 + d] - 1) * stride[d] - 2 * padding[d] + weight.shape[2 + d]) for d in range(3))
+            gx = _ThinConvTranspose3dFn.apply(gy, weight, None, stride, padding, opad)
         if ctx.needs_input_grad[1]:
-            gw = regular_weight_grad(x, gy, weight.shape, stride, padding)
+            gw = _RegularWgradFn.apply(x, gy, tuple(weight.shape), stride, padding)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3, 4))
         return gx, gw, gb, None, None
@@ -155,8 +186,7 @@ _BIG = 64 ** 3              # voxels per sample (of the larger side) from which 
 
 def _custom_path(x, mod, voxels):
     """the GEMM weight gradient serves fp32 training on the GPU at >= 64^3; everything else (CPU, float64, inference, small
-    volumes, graphs that will be differentiated twice -- the WGAN-GP penalty runs through the critic, which keeps
-    nn.Conv3d) takes the stock operator"""
+    volumes) takes the stock operator"""
     if getattr(mod, "force_custom", False):
         return True
     return (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and mod.weight.requires_grad

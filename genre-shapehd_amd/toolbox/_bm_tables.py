@@ -351,6 +351,9 @@ def _gather_tables(pnb, ent, ent_brick, gstart, gcount, i_first, rel, own, wl, e
     rb = np.searchsorted(chunk_brick, np.arange(pnb), side="left")
     re_ = np.searchsorted(chunk_brick, np.arange(pnb), side="right")
     g_rows = _split_rows(rb, re_, np.concatenate(([0], np.cumsum(lis_c))), split_b, 1)
+    # the XCD interleave (ROW_ORDER = 'xcd') pads the table with SKIP rows; bm_gather_kernel's persistent workgroups take rows
+    # from a counter and do not test for them (a SKIP row would be read as chunk `row.y` of another brick): none here
+    g_rows = np.ascontiguousarray(g_rows[g_rows[:, 3] != SKIP])
     # a brick that no sample touches still has to be written (zeros): its row gets one chunk without entries, whose blob
     # is 256 empty lists -- the kernel walks the chunks of its rows as one stream and never meets a row without one
     g_chunks = np.concatenate((g_chunks, np.asarray([[0, 0, int(base[-1]), 256]], np.int32)))

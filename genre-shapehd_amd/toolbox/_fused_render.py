@@ -34,21 +34,24 @@ def _remember(key, t):
 
 
 def _content_of(buf):
-    """(sha1, numpy copy) of a small device buffer, read back once per (address, version): a buffer that is rewritten
+    """(sha1, numpy copy) of a small device buffer, read back once per (tensor object, version): a buffer that is rewritten
     with the same values (DDP's buffer broadcast, load_state_dict) costs one device -> host copy per rewrite but maps to
-    the same table entry, and a different buffer at a recycled address cannot alias an old entry once its version or
-    contents differ."""
+    the same table entry.  The memo holds a WEAK reference to the tensor it read: a different tensor that the allocator
+    later places at the same address (a fresh model's depth_weight at version 0) is a different object -- or finds the
+    reference dead -- and is read again (the address alone is not an identity)."""
     import hashlib
+    import weakref
     ident = (buf.data_ptr(), buf._version, buf.numel(), str(buf.device))
     c = _CONTENT.get(ident)
+    if c is not None and c[2]() is not buf:
+        c = None
     if c is None:
         host = buf.detach().cpu().numpy().copy()
-        c = (hashlib.sha1(host.tobytes()).hexdigest(), host)
+        c = (hashlib.sha1(host.tobytes()).hexdigest(), host, weakref.ref(buf))
         if len(_CONTENT) >= 64:
             _CONTENT.clear()
         _CONTENT[ident] = c
-    return c
-
+    return c[0], c[1]
 
 
 def available():

@@ -16,6 +16,18 @@ from torch.autograd.function import once_differentiable
 from .._ext import cam_bp_lib
 
 
+_CAM_MODE = None
+
+
+def _cam_mode():
+    """GENRE_CAMBP_MODE as the LIBRARY sees it: read once per process (csrc/cam_bp.hip caches it at its first call), so that the
+    Python-side routing and the C side never disagree when the variable changes mid-process"""
+    global _CAM_MODE
+    if _CAM_MODE is None:
+        _CAM_MODE = os.environ.get("GENRE_CAMBP_MODE", "")
+    return _CAM_MODE
+
+
 class CameraBackProjection(Function):
 
     @staticmethod
@@ -72,8 +84,12 @@ class ShiftedCameraBackProjection(Function):
         else:
             out = torch.empty((n, nc, res, res, res), dtype=depth_t.dtype, device=depth_t.device)
             cnt = torch.empty_like(out)
-        if (const is not None and not (batch_minor and nc == 1) and n * nc <= 65535
-                and os.environ.get("GENRE_CAMBP_MODE", "") in ("", "auto", "brick")):
+        # the by-value entry runs the single-launch brick kernel only: dense NCXYZ outputs whose z rows are float4-aligned
+        # (res % 4 == 0 for the tensors allocated above), at most 65535 images, brick / auto mode -- the library's own
+        # preconditions (csrc/cam_bp.hip: forward_impl), checked HERE so that every other case (res = 30, 126, ...; the
+        # scatter / gather modes) takes the tensor entry instead of an error
+        if (const is not None and not (batch_minor and nc == 1) and n * nc <= 65535 and res % 4 == 0
+                and _cam_mode() in ("", "auto", "brick")):
             cam_bp_lib.back_projection_forward_const(depth_t, const[1], const[0], out, cnt, shifted=True)
         else:
             cam_bp_lib.back_projection_forward_shifted(depth_t, cam_dist, fl, out, cnt)

@@ -183,6 +183,11 @@ def main(argv=None):
             loss = loss / world
         if rank == 0:
             print("step %d loss %.6f" % (step, loss.item()), flush=True)
+    if args.save:
+        # per-rank BatchNorm statistics (ddp(): broadcast_buffers=False) -> their mean over the ranks, on every rank, before
+        # rank 0 writes the checkpoint (dist_utils.average_float_buffers)
+        with torch.no_grad():
+            dist_utils.average_float_buffers(dist, nets)
     if args.save and rank == 0:
         checkpoint.save_state_dict(args.save, nets, optims, epoch=start + args.steps, loss_eval=float(loss))
     if dist is not None:

@@ -351,3 +351,10 @@ def test_by_value_camera_entry_equals_the_tensor_entry(genre, oracle, dev):
     y1.backward(g)
     y2.backward(g)
     assert torch.equal(x1.grad, x2.grad)
+    # ... and a resolution whose rows are not float4-aligned takes the tensor entry instead of raising
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp.functions.cam_back_projection import ShiftedCameraBackProjection
+    flt, cdt = torch.full((1, 1), 418.3, device=dev), torch.full((1, 1), 2.2, device=dev)
+    for res in (30, 126):
+        ya = ShiftedCameraBackProjection.apply(d1, flt, cdt, res, False, (418.3, 2.2))
+        yb = ShiftedCameraBackProjection.apply(d1, flt, cdt, res, False, None)
+        assert ya.shape == (1, 1, res, res, res) and torch.equal(ya, yb)

@@ -199,7 +199,7 @@ def test_batch_minor_backward_skips_what_the_clamp_blocks(genre, dev):
     a = vox.clone().requires_grad_(True)
     b = _batch_minor(vox).requires_grad_(True)
     out_a, out_b = mod(a, pre_scale=50.0, pad=16), mod(b, pre_scale=50.0, pad=16)
-    assert (out_a - out_b).abs().max().item() <= 1e-6
+    assert (out_a - out_b).abs().max().item() <= 1e-5                  # (near-binary volumes: the two scan orders, 3e-6)
     g = torch.from_numpy(rng.standard_normal(tuple(out_a.shape)).astype(np.float32)).to(dev)
     g[3] = float("nan")
     out_a.backward(g)

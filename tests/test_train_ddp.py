@@ -152,9 +152,13 @@ def _gan_worker(rank, world, port, ret):
     for step in range(2):
         real = (torch.rand(2, 1, 64, 64, 64, generator=rng) > 0.7).float()
         gan.train_on_batch(step, real)
-    ret[rank] = {"g": [p.detach().numpy().copy() for p in raw_g.parameters()],
-                 "d": [p.detach().numpy().copy() for p in raw_d.parameters()],
-                 "bn": [b.detach().numpy().copy() for k, b in raw_g.named_buffers() if k.endswith("running_mean")]}
+    out = {"g": [p.detach().numpy().copy() for p in raw_g.parameters()],
+           "d": [p.detach().numpy().copy() for p in raw_d.parameters()],
+           "bn": [b.detach().numpy().copy() for k, b in raw_g.named_buffers() if k.endswith("running_mean")]}
+    with torch.no_grad():                                               # what the launcher does before rank 0 saves
+        dist_utils.average_float_buffers(dist, [raw_g, raw_d])
+    out["bn_avg"] = [b.detach().numpy().copy() for k, b in raw_g.named_buffers() if k.endswith("running_mean")]
+    ret[rank] = out
     dist.barrier()
     dist.destroy_process_group()
 
@@ -174,6 +178,9 @@ def test_wgangp_under_ddp_keeps_parameters_in_sync_and_batchnorm_statistics_per_
         for x, y in zip(a[net], b[net]):
             assert np.array_equal(x, y), net
     assert len(a["bn"]) > 0 and any(not np.array_equal(x, y) for x, y in zip(a["bn"], b["bn"]))
+    # ... and a checkpoint carries their mean over the ranks, the same on every rank (dist_utils.average_float_buffers)
+    for x, y, m, n in zip(a["bn"], b["bn"], a["bn_avg"], b["bn_avg"]):
+        assert np.array_equal(m, n) and np.allclose(m, (x + y) / 2, rtol=1e-6, atol=1e-7)
 
 
 def test_back_projection_layer_constants_survive_a_change_of_batch_size():
