@@ -104,10 +104,8 @@ def parse():
     ap.add_argument("--no-m1", action="store_true", help="skip the GenRe whole-model forward (M1)")
     ap.add_argument("--no-train", action="store_true", help="skip the configs[3]/[4] train-step timings (`train`)")
     ap.add_argument("--train-steps", type=int, default=8, help="timed optimizer steps per train config")
-    ap.add_argument("--train-configs", default="shapehd,genre",
-                    help="comma-separated subset of shapehd,wgangp,genre (or `all`): the train steps to time.  The 3-D "
-                         "WGAN-GP step is not in the default set: on a fresh box MIOpen spends minutes searching its "
-                         "second-order convolutions (profiles/r03p_bench.json holds its number)")
+    ap.add_argument("--train-configs", default="all",
+                    help="comma-separated subset of shapehd,wgangp,genre (or `all`, the default): the train steps to time")
     ap.add_argument("--eager", action="store_true", help="time eager launches of the step instead of a HIP-graph replay")
     ap.add_argument("--stub", action="store_true", help="launcher self-test: a trivial CPU step over gloo, no GPU")
     return ap.parse_args()

@@ -204,7 +204,11 @@ def test_batch_minor_backward_skips_what_the_clamp_blocks(genre, dev):
     g[3] = float("nan")
     out_a.backward(g)
     out_b.backward(g)
-    assert torch.count_nonzero(b.grad[:32]).item() == 0 and torch.count_nonzero(a.grad[:32]).item() == 0
+    assert torch.count_nonzero(b.grad[:32]).item() == 0
+    # (the standard-layout path turns the whole gradient of the image with the NaN upstream gradient into NaN -- its per-image
+    # fixed-point scale is NaN; PyTorch 0.4.1's clamp backward, a product with the mask, does the same -- the others are zero)
+    others = [i for i in range(32) if i != 3]
+    assert torch.count_nonzero(a.grad[others]).item() == 0 and torch.isnan(a.grad[3]).all()
     scale = a.grad[32:].abs().max().item()
     assert scale > 0 and torch.count_nonzero(b.grad[32:, :, 44:56, 56:64, 40:80]).item() == 0
     assert (a.grad[32:] - b.grad[32:]).abs().max().item() <= 1e-5 * max(1.0, scale)
