@@ -40,7 +40,7 @@ def _load():
     T, V = C.POINTER(GenreTensor), C.c_void_p
     scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float],
                "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float, C.c_int],
-               "genre_render_bm_backward_gather": [C.c_float],
+               "genre_render_bm_backward_gather": [C.c_float], "genre_render_bm_backward_halo": [C.c_float],
                "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float],
                "genre_back_projection_forward_const": [C.c_float, C.c_float, C.c_int]}
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
@@ -53,7 +53,7 @@ def _load():
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
                         ("genre_render_spherical_forward", 8), ("genre_render_spherical_backward", 10),
                         ("genre_render_bm_forward", 11), ("genre_render_bm_backward", 14),
-                        ("genre_render_bm_backward_gather", 15),
+                        ("genre_render_bm_backward_gather", 15), ("genre_render_bm_backward_halo", 15),
                         ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4),
                         ("genre_nnd_forward_host", 6), ("genre_nnd_backward_host", 8)):
         fn = getattr(lib, name, None)
@@ -236,6 +236,16 @@ class _RenderLib:
         """the backward in gather form (voxel sums in registers, per-voxel contribution lists; no LDS atomics)"""
         return _call("genre_render_bm_backward_gather", grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32,
                      g_ent, g_chunks, g_blob, g_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask,
+                     scalars=(C.c_float(pre_scale),))
+
+
+    @staticmethod
+    def render_bm_backward_halo(grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, h_ent, rec_f, h_rows,
+                                depth_weight, ps_scratch, tr_scratch, p_stash, mask, halo_scratch, pre_scale=0.0):
+        """the backward in halo form (every brick scatters its own segments into a tile with halo; a second kernel adds the
+        neighbours' halo lines): halo_scratch fp32 [groups * bricks * 149 * 32]"""
+        return _call("genre_render_bm_backward_halo", grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32,
+                     h_ent, rec_f, h_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask, halo_scratch,
                      scalars=(C.c_float(pre_scale),))
 
 

@@ -140,8 +140,8 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const float raw = v[c] * D.pre_scale;
-                bits |= (raw >= D.lo && raw <= D.hi) ? (1u << c) : 0u;
                 v[c] = fminf(fmaxf(raw, D.lo), D.hi);
+                bits |= (v[c] == raw) ? (1u << c) : 0u;                // lo <= raw <= hi: the clamp passes the gradient
             }
         }
         if (t < kLinesF * 8) *reinterpret_cast<float4 *>(tile + line * kImgs + piece * 4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -441,8 +441,19 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
 // ---- backward: brick-owned pull scatter ----------------------------------------------------------------
 // The backward's bricks ("pull bricks", PX x PY x PZ voxels) need not be the forward's: a bigger one lowers the number of
 // bricks a segment touches (every touching brick re-reads the segment's saved samples) at the price of LDS.
+constexpr int kHaloLines = kTX * kTY * kTZ - kBX * kBY * kBZ;         // 149 lines of a 5 x 9 x 9 tile outside its 4 x 8 x 8 brick
+
+// line (tx, ty, tz) of a halo tile that lies outside the brick -> 0 .. 148: the x = BX slab first, then the y = BY face, then z = BZ
+__device__ __forceinline__ int halo_index(int tx, int ty, int tz)
+{
+    if (tx == kBX) return ty * kTZ + tz;
+    if (ty == kBY) return kTY * kTZ + tx * kTZ + tz;
+    return kTY * kTZ + kBX * kTZ + tx * kBY + ty;
+}
+
 template <int PX, int PY, int PZ>
-__global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, float *__restrict__ gvox)
+__global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, float *__restrict__ gvox,
+                                                                  float *__restrict__ halo = nullptr, int nb = 0)
 {
     const int4 row = rows[blockIdx.x];
     if (row.w != 1) return;
@@ -453,6 +464,10 @@ __global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, cons
         const int line = e >> 5, n = n0 + (e & 31);
         const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
         if (x < D.X && y < D.Y && z < D.Z && n < D.N) gvox[x * D.gx + y * D.gy + z * D.gz + n] = 0.f;
+    }
+    if (halo) {                                                         // the halo lines of a brick several rows add onto
+        float *h = halo + ((size_t)blockIdx.y * nb + row.x) * kHaloLines * kImgs;
+        for (int e = threadIdx.x; e < kHaloLines * kImgs; e += kThreads) h[e] = 0.f;
     }
 }
 
@@ -492,17 +507,26 @@ struct BmEntryRegs {
 };
 
 // 768 threads: two workgroups per CU = 6 waves per SIMD, which the register allocation must respect (<= 80 VGPRs)
-template <bool PS, int PX, int PY, int PZ, int kThreadsB>
-__global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE_BM_SCATTER_WAVES) : 4)) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
+// HALO (round 4, "owner computes"): the tile is the brick PLUS its high halo (5 x 9 x 9 lines, as the forward sampler's), a
+// workgroup scatters the segments of ITS OWN brick only -- every sample exactly once (2.52 M per image group instead of the
+// 4.34 M the pull form lists), all eight corners, no ownership masks -- writes the brick's lines to grad_vox and the 149 halo
+// lines to a scratch buffer, and bm_halo_combine_kernel adds each brick's <= 7 neighbours' halo lines onto its low faces.
+// Entries = the forward's segments (h_ent: i0 = 0, i1 = L), records = the forward's rec_f (tile offsets in the fp32 tile:
+// doubled when they are staged), rows = h_rows.
+template <bool PS, int PX, int PY, int PZ, int kThreadsB, bool HALO = false>
+__global__ __launch_bounds__(kThreadsB, (HALO ? 4 : (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE_BM_SCATTER_WAVES) : 4))) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
                                                                const int4 *__restrict__ rows, const float *__restrict__ dw,
                                                                const float *__restrict__ tr, const float *__restrict__ stash,
-                                                               const unsigned *__restrict__ mask, float *__restrict__ gvox)
+                                                               const unsigned *__restrict__ mask, float *__restrict__ gvox,
+                                                               float *__restrict__ halo = nullptr, int nb = 0)
 {
-    constexpr int kLinesB = PX * PY * PZ, kWavesB = kThreadsB / 64;
+    constexpr int QX = PX + (HALO ? 1 : 0), QY = PY + (HALO ? 1 : 0), QZ = PZ + (HALO ? 1 : 0);     // tile dimensions in lines
+    constexpr int kLinesB = QX * QY * QZ, kWavesB = kThreadsB / 64;
+    constexpr int kMaskThreads = (kLinesB + 255) / 256 * 256;           // threads that carry a mask word (whole waves)
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     double *tile = lds_d;                                               // [kLinesB][32]
     int *recs = reinterpret_cast<int *>(lds_d + kLinesB * kImgs);       // [kWavesB][kMaxSeg * kRecL]
-    unsigned *mlds = reinterpret_cast<unsigned *>(recs + kWavesB * kMaxSeg * kRecL);    // [kLinesB] clamp masks
+    unsigned *mlds = reinterpret_cast<unsigned *>(recs + kWavesB * kMaxSeg * kRecL);    // [kMaskThreads] clamp masks + summary words
     const int4 row = rows[blockIdx.x];
     if (row.w == 2) return;                                             // padding row of the XCD interleave
     const int g = blockIdx.y, n0 = g * kImgs;
@@ -513,39 +537,43 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
         // images has an identically zero gradient whatever the samples say (the flush multiplies by the mask): it writes
         // its zeros and is done -- no entries, no scans, no atomics.  On GenRe's own chain (x50 of a saturated or empty
         // voxel) that is every brick; the group word behind the masks says so without reading them.
-        static_assert(kLinesB <= kThreadsB && kLinesB % 256 == 0, "one mask word per thread, four summary words per read");
+        static_assert(kMaskThreads <= kThreadsB, "one mask word per thread");
         const bool group_live = mask[(size_t)D.groups * D.X * D.Y * D.Z + g] != 0u;
         unsigned m = 0u;
         if (group_live && (int)threadIdx.x < kLinesB) {
             const int line = threadIdx.x;
-            const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
+            const int x = ox + line / (QY * QZ), y = oy + (line / QZ) % QY, z = oz + line % QZ;
             if (x < D.X && y < D.Y && z < D.Z) m = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
         }
         for (int e = threadIdx.x; e < kLinesB * kImgs / 2; e += kThreadsB) reinterpret_cast<double2 *>(tile)[e] = make_double2(0.0, 0.0);
-        if ((int)threadIdx.x < kLinesB) {
+        if ((int)threadIdx.x < kMaskThreads) {
             mlds[threadIdx.x] = m;
             const unsigned long long hit = __ballot(m != 0u);          // the waves that carry mask words: one summary word each
-            if ((threadIdx.x & 63) == 0) mlds[kLinesB + (threadIdx.x >> 6)] = hit ? 1u : 0u;
+            if ((threadIdx.x & 63) == 0) mlds[kMaskThreads + (threadIdx.x >> 6)] = hit ? 1u : 0u;
         }
         __syncthreads();
         unsigned brick_live = 0u;
 #pragma unroll
-        for (int i = 0; i < kLinesB / 64; i += 4) {
-            const uint4 w = *reinterpret_cast<const uint4 *>(mlds + kLinesB + i);
+        for (int i = 0; i < kMaskThreads / 64; i += 4) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(mlds + kMaskThreads + i);
             brick_live |= w.x | w.y | w.z | w.w;
         }
         if (!brick_live) {
             if (row.w != 0) return;                                     // a shared brick: bm_zero_shared_kernel wrote its zeros
-            for (int q = threadIdx.x; q < kLinesB * (kImgs / 4); q += kThreadsB) {
+            const bool v4 = (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
+                            (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
+            for (int q = threadIdx.x; q < PX * PY * PZ * (kImgs / 4); q += kThreadsB) {
                 const int line = q >> 3, n = n0 + (q & 7) * 4;
                 const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
                 if (x >= D.X || y >= D.Y || z >= D.Z) continue;
                 float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
-                if ((D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
-                    (reinterpret_cast<uintptr_t>(gvox) & 15) == 0 && n + 3 < D.N)
-                    *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v4 && n + 3 < D.N) *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
                 else
                     for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] = 0.f;
+            }
+            if (HALO && group_live) {                                   // (a dead GROUP: the combine kernel does not run either)
+                float4 *h = reinterpret_cast<float4 *>(halo + ((size_t)g * nb + row.x) * kHaloLines * kImgs);
+                for (int q = threadIdx.x; q < kHaloLines * (kImgs / 4); q += kThreadsB) h[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             return;
         }
@@ -565,7 +593,7 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
     const int stage_rec = lane / 3, stage_part = lane - stage_rec * 3;   // staging: lane -> (record, 16-byte chunk)
     int *stage_to = myrec + stage_rec * kRecL + (stage_part == 0 ? 0 : stage_part == 1 ? 4 : 12);
     char *tl = reinterpret_cast<char *>(tile + half * kImgs + l);
-    constexpr int kXS = PY * PZ * kImgs, kYS = PZ * kImgs;           // doubles between x / y neighbours
+    constexpr int kXS = QY * QZ * kImgs, kYS = QZ * kImgs;           // doubles between x / y neighbours
     // entry = (segment, stash slot of its first sample, i0 | i1 << 6 | L << 12 | k0 << 18, rec_b slot of sample i0).
     // Software pipeline: while entry e is scattered, the saved samples, the two ray scalars, the depth weights and the
     // records of entry e + kWavesB are in flight to registers (two register sets, used alternately: no copies) and the
@@ -605,8 +633,10 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
         const int i0 = pk & 63, i1 = (pk >> 6) & 63, L = (pk >> 12) & 63;
         if (lane < (i1 - i0) * 3) {
             int4 *to = reinterpret_cast<int4 *>(stage_to + i0 * kRecL);
-            *to = cur.rq;
-            if (stage_part == 0) to[2] = cur.rq;                        // the header, again, for the upper half-wave
+            int4 rv = cur.rq;
+            if (HALO && stage_part == 0) rv.x *= 2;                     // rec_f: byte offset in the fp32 tile -> in the fp64 tile
+            *to = rv;
+            if (stage_part == 0) to[2] = rv;                            // the header, again, for the upper half-wave
         }
         wave_lds_fence();                                               // (headers first: they carry zeros where w_k goes)
         if (lane < kMaxSeg) {
@@ -645,12 +675,19 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
             }
             if (i < i1) {
                 const float dp = ps > 0.f ? c * d : 0.f;                // the clamp passes the gradient where the saved sample is > 0
-                const unsigned own = (unsigned)__builtin_amdgcn_readfirstlane(hc.y);
                 double *a = reinterpret_cast<double *>(tl + hc.x);
-                if (owned(own, 0)) unsafeAtomicAdd(a, (double)(wc.x * dp));                // ds_add_f64
-                if (owned(own, 1)) unsafeAtomicAdd(a + kXS, (double)(wc.y * dp));
-                if (owned(own, 2)) unsafeAtomicAdd(a + kYS, (double)(wc.z * dp));
-                if (owned(own, 3)) unsafeAtomicAdd(a + kXS + kYS, (double)(wc.w * dp));
+                if (HALO) {                                             // every corner line is in the tile: no masks
+                    unsafeAtomicAdd(a, (double)(wc.x * dp));
+                    unsafeAtomicAdd(a + kXS, (double)(wc.y * dp));
+                    unsafeAtomicAdd(a + kYS, (double)(wc.z * dp));
+                    unsafeAtomicAdd(a + kXS + kYS, (double)(wc.w * dp));
+                } else {
+                    const unsigned own = (unsigned)__builtin_amdgcn_readfirstlane(hc.y);
+                    if (owned(own, 0)) unsafeAtomicAdd(a, (double)(wc.x * dp));                // ds_add_f64
+                    if (owned(own, 1)) unsafeAtomicAdd(a + kXS, (double)(wc.y * dp));
+                    if (owned(own, 2)) unsafeAtomicAdd(a + kYS, (double)(wc.z * dp));
+                    if (owned(own, 3)) unsafeAtomicAdd(a + kXS + kYS, (double)(wc.w * dp));
+                }
             }
         };
 #pragma unroll
@@ -694,6 +731,48 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
     __syncthreads();
     // Flush: every voxel of the brick exactly once.  Four images per thread (two 16-byte LDS reads, one 16-byte store) when
     // the layout allows; rows that share their brick with other rows add atomically onto pre-zeroed voxels.
+    if (HALO) {
+        // the brick's lines to grad_vox (clamp adjoint applied), the 149 halo lines UNMASKED to this brick's slice of the
+        // scratch buffer (bm_halo_combine_kernel applies the receiving voxel's mask); shared rows add atomically to both
+        const bool v4 = (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
+                        (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
+        float *hb = halo + ((size_t)g * nb + row.x) * kHaloLines * kImgs;
+        for (int q = threadIdx.x; q < kLinesB * (kImgs / 4); q += kThreadsB) {
+            const int line = q >> 3, piece = (q & 7) * 4, n = n0 + piece;
+            const int tx = line / (QY * QZ), ty = (line / QZ) % QY, tz = line % QZ;
+            const double2 t01 = *reinterpret_cast<const double2 *>(tile + line * kImgs + piece);
+            const double2 t23 = *reinterpret_cast<const double2 *>(tile + line * kImgs + piece + 2);
+            float4 v = make_float4((float)t01.x, (float)t01.y, (float)t23.x, (float)t23.y);
+            if (tx < PX && ty < PY && tz < PZ) {
+                const int x = ox + tx, y = oy + ty, z = oz + tz;
+                if (x >= D.X || y >= D.Y || z >= D.Z || n >= D.N) continue;
+                if (PS) {
+                    const unsigned m = mlds[line] >> piece;
+                    v.x = (m & 1u) ? v.x * D.pre_scale : 0.f;
+                    v.y = (m & 2u) ? v.y * D.pre_scale : 0.f;
+                    v.z = (m & 4u) ? v.z * D.pre_scale : 0.f;
+                    v.w = (m & 8u) ? v.w * D.pre_scale : 0.f;
+                }
+                float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                if (row.w == 0) {
+                    if (v4 && n + 3 < D.N) *reinterpret_cast<float4 *>(dst) = v;
+                    else
+                        for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] = vv[c];
+                } else {
+                    for (int c = 0; c < 4; c++) if (n + c < D.N && vv[c] != 0.f) unsafeAtomicAdd(dst + c, vv[c]);
+                }
+            } else {
+                float *dst = hb + halo_index(tx, ty, tz) * kImgs + piece;
+                if (row.w == 0) *reinterpret_cast<float4 *>(dst) = v;
+                else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    for (int c = 0; c < 4; c++) if (vv[c] != 0.f) unsafeAtomicAdd(dst + c, vv[c]);
+                }
+            }
+        }
+        return;
+    }
     const bool vec4 = row.w == 0 && (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
                       (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
     if (vec4) {
@@ -726,6 +805,57 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
             float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
             if (row.w == 0) *dst = val;
             else if (val != 0.f) unsafeAtomicAdd(dst, val);
+        }
+    }
+}
+
+// ---- backward, halo form: every brick collects what its neighbours scattered onto its low faces -----------------------
+// grid = (bricks, groups).  A voxel with local coordinate 0 along x / y / z receives from the brick below it along that axis
+// (and along two / three axes at once for edge / corner voxels): <= 7 neighbours, whose halo lines lie in the scratch buffer
+// as bm_scatter_kernel<HALO> left them.  The receiving voxel's clamp mask is applied here.
+template <bool PS>
+__global__ __launch_bounds__(256) void bm_halo_combine_kernel(BmDims D, const float *__restrict__ halo, const unsigned *__restrict__ mask,
+                                                            float *__restrict__ gvox, int nb)
+{
+    const int g = blockIdx.y, n0 = g * kImgs, brick = blockIdx.x;
+    if (PS && mask[(size_t)D.groups * D.X * D.Y * D.Z + g] == 0u) return;      // nothing of this group passes the clamp
+    const int nby = (D.Y + kBY - 1) / kBY, nbz = (D.Z + kBZ - 1) / kBZ;
+    const int bx = brick / (nby * nbz), by = (brick / nbz) % nby, bz = brick % nbz;
+    const int ox = bx * kBX, oy = by * kBY, oz = bz * kBZ;
+    const bool v4 = (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
+    for (int q = threadIdx.x; q < kBX * kBY * kBZ * (kImgs / 4); q += 256) {
+        const int line = q >> 3, piece = (q & 7) * 4, n = n0 + piece;
+        const int lx = line / (kBY * kBZ), ly = (line / kBZ) % kBY, lz = line % kBZ;
+        if (lx && ly && lz) continue;                                   // an inner voxel: only its own brick touches it
+        const int x = ox + lx, y = oy + ly, z = oz + lz;
+        if (x >= D.X || y >= D.Y || z >= D.Z || n >= D.N) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int d = 1; d < 8; d++) {
+            const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
+            if ((dx && lx) || (dy && ly) || (dz && lz)) continue;
+            if ((dx && bx == 0) || (dy && by == 0) || (dz && bz == 0)) continue;
+            const int nbrick = ((bx - dx) * nby + (by - dy)) * nbz + (bz - dz);
+            const int hidx = halo_index(dx ? kBX : lx, dy ? kBY : ly, dz ? kBZ : lz);
+            const float4 h = *reinterpret_cast<const float4 *>(halo + (((size_t)g * nb + nbrick) * kHaloLines + hidx) * kImgs + piece);
+            acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
+        }
+        if (PS) {
+            const unsigned m = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] >> piece;
+            acc.x = (m & 1u) ? acc.x * D.pre_scale : 0.f;
+            acc.y = (m & 2u) ? acc.y * D.pre_scale : 0.f;
+            acc.z = (m & 4u) ? acc.z * D.pre_scale : 0.f;
+            acc.w = (m & 8u) ? acc.w * D.pre_scale : 0.f;
+        }
+        float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
+        if (v4 && n + 3 < D.N) {
+            float4 o = *reinterpret_cast<float4 *>(dst);
+            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+            *reinterpret_cast<float4 *>(dst) = o;
+        } else {
+            const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+            for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] += a4[c];
         }
     }
 }
@@ -1138,7 +1268,7 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
                                                                         (float *)grad_vox->data);                         \
             GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");                                                \
         }                                                                                                                 \
-        constexpr size_t lds = (size_t)PXV * 64 * kImgs * 8 + (size_t)(NTV / 64) * kMaxSeg * kRecL * 4 + (size_t)PXV * 64 * 4 + PXV * 4; \
+        constexpr size_t lds = (size_t)PXV * 64 * kImgs * 8 + (size_t)(NTV / 64) * kMaxSeg * kRecL * 4 + (size_t)(PXV * 64 + PXV + 4) * 4; \
         static std::atomic<uint64_t> done_{0};                                                                            \
         if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_scatter_kernel<PSV, PXV, 8, 8, NTV>), lds, done_)) return 0; \
         bm_scatter_kernel<PSV, PXV, 8, 8, NTV><<<grid, NTV, lds, st>>>(                                                   \
@@ -1150,6 +1280,76 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
     else { if (pre_scale != 0.0f) GENRE_BM_SCATTER(true, 8, 1024); else GENRE_BM_SCATTER(false, 8, 1024); }
 #undef GENRE_BM_SCATTER
     GENRE_LAUNCH_CHECK("render_bm backward (bricks)");
+    return 1;
+}
+
+extern "C" int genre_render_bm_backward_halo(const genre_tensor *grad_out, const genre_tensor *grad_vox,
+                                             const genre_tensor *segs, const genre_tensor *ray_ptr,
+                                             const genre_tensor *ray_seg, const genre_tensor *ray_pre,
+                                             const genre_tensor *h_ent, const genre_tensor *rec_f,
+                                             const genre_tensor *h_rows, const genre_tensor *depth_weight,
+                                             const genre_tensor *ps_scratch, const genre_tensor *tr_scratch,
+                                             const genre_tensor *p_stash, const genre_tensor *mask,
+                                             const genre_tensor *halo_scratch, float pre_scale, void *stream)
+{
+    const char *op = "render_bm_backward_halo";
+    BmDims D{};
+    if (!check_bm(op, grad_vox, grad_out, segs, ray_ptr, ray_seg, ray_pre, D, true)) return 0;
+    if (!check_rows(op, D, h_rows)) return 0;
+    D.gx = grad_vox->stride[2]; D.gy = grad_vox->stride[3]; D.gz = grad_vox->stride[4];
+    D.pre_scale = pre_scale;
+    GENRE_REQUIRE(is_i32(h_ent, 2) && h_ent->size[1] == 4 && is_contiguous(h_ent) && aligned16(h_ent->data) &&
+                      h_ent->size[0] == D.nseg, "%s: h_ent must be int32 [nseg,4]", op);
+    GENRE_REQUIRE(is_i32(rec_f, 2) && rec_f->size[1] == kRec && is_contiguous(rec_f) && aligned16(rec_f->data),
+                  "%s: rec_f must be a contiguous int32 [S,12] tensor", op);
+    GENRE_REQUIRE(is_f32(depth_weight, 1) && is_contiguous(depth_weight) && depth_weight->size[0] >= 1 &&
+                      depth_weight->size[0] <= 256, "%s: depth_weight must be fp32 [ZR], 1 <= ZR <= 256", op);
+    D.ZR = (int)depth_weight->size[0];
+    D.nslot = rec_f->size[0];
+    const int64_t per = (int64_t)D.groups * D.nseg * 2 * kImgs;
+    GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ps_scratch->size[0] >= per &&
+                      is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && tr_scratch->size[0] >= per,
+                  "%s: ps_scratch / tr_scratch must hold groups*nseg*64 floats", op);
+    GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] >= (int64_t)D.groups * D.nslot * kImgs,
+                  "%s: p_stash must be the forward's [groups*S*32] buffer", op);
+    GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) && mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z + D.groups),
+                  "%s: pre_scale needs the forward's mask int32 [groups*X*Y*Z + groups]", op);
+    const int nb = ((D.X + kBX - 1) / kBX) * ((D.Y + kBY - 1) / kBY) * ((D.Z + kBZ - 1) / kBZ);
+    GENRE_REQUIRE(is_f32(halo_scratch, 1) && is_contiguous(halo_scratch) && aligned16(halo_scratch->data) &&
+                      halo_scratch->size[0] >= (int64_t)D.groups * nb * kHaloLines * kImgs,
+                  "%s: halo_scratch must hold groups*bricks*149*32 floats", op);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned *group_any = pre_scale != 0.0f ? (const unsigned *)mask->data + (int64_t)D.groups * D.X * D.Y * D.Z : nullptr;
+    bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
+        D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
+        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data, nullptr, group_any);
+    GENRE_LAUNCH_CHECK("render_bm backward (rays)");
+    const dim3 grid((unsigned)h_rows->size[0], (unsigned)D.groups);
+    if (h_rows->size[0] > nb) {                   // some bricks are split over several rows: those add atomically
+        bm_zero_shared_kernel<kBX, kBY, kBZ><<<grid, kThreads, 0, st>>>(D, (const int4 *)h_rows->data, (float *)grad_vox->data,
+                                                                        (float *)halo_scratch->data, nb);
+        GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");
+    }
+    constexpr int NTH = 1024;
+    constexpr int kLinesH = kTX * kTY * kTZ, kMaskH = (kLinesH + 255) / 256 * 256;
+    constexpr size_t lds = (size_t)kLinesH * kImgs * 8 + (size_t)(NTH / 64) * kMaxSeg * kRecL * 4 + (size_t)(kMaskH + kMaskH / 64 + 4) * 4;
+#define GENRE_BM_HALO(PSV)                                                                                                \
+    do {                                                                                                                  \
+        static std::atomic<uint64_t> done_{0};                                                                            \
+        if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_scatter_kernel<PSV, kBX, kBY, kBZ, NTH, true>), lds, done_)) return 0; \
+        bm_scatter_kernel<PSV, kBX, kBY, kBZ, NTH, true><<<grid, NTH, lds, st>>>(                                         \
+            D, (const int4 *)h_ent->data, (const int *)rec_f->data, (const int4 *)h_rows->data,                           \
+            (const float *)depth_weight->data, (const float *)tr_scratch->data, (const float *)p_stash->data,             \
+            pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr, (float *)grad_vox->data,                          \
+            (float *)halo_scratch->data, nb);                                                                             \
+        GENRE_LAUNCH_CHECK("render_bm backward (bricks, halo form)");                                                     \
+        bm_halo_combine_kernel<PSV><<<dim3((unsigned)nb, (unsigned)D.groups), 256, 0, st>>>(                              \
+            D, (const float *)halo_scratch->data, pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr,             \
+            (float *)grad_vox->data, nb);                                                                                 \
+    } while (0)
+    if (pre_scale != 0.0f) GENRE_BM_HALO(true); else GENRE_BM_HALO(false);
+#undef GENRE_BM_HALO
+    GENRE_LAUNCH_CHECK("render_bm backward (halo combine)");
     return 1;
 }
 

@@ -49,6 +49,7 @@ LINE_F = 128                    # bytes of one voxel line in the forward tile (3
 LINE_B = 256                    # ... in the backward tile (32 images x fp64)
 SPLIT_F = 4096                  # samples per forward row
 SPLIT_B = 2048                  # listed samples per backward row
+SPLIT_H = 2048                  # samples per row of the halo-form backward
 LO = np.float32(1e-5)           # spherical_proj.py:66
 
 
@@ -220,8 +221,14 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     cumb = np.concatenate(([0], np.cumsum((i_last + 1 - i_first).astype(np.int64))))
     bwd_rows = _split_rows(eb, ee, cumb, split_b, 1)
 
+    # ---- backward, halo form ("owner computes": csrc/sph_render_bm.hip, bm_scatter_kernel<HALO>): a brick scatters its OWN
+    # segments into a tile with halo -- the forward's segments and records serve as they are; an entry lists the whole segment
+    h_pack = (segs[:, 2] << 6) | (segs[:, 2] << 12) | (segs[:, 1] << 18)
+    h_ent = np.stack([segs[:, 0], segs[:, 3], h_pack, segs[:, 3]], 1).astype(np.int32)
+    h_rows = _split_rows(sb, se, cum, SPLIT_H, 1)
+
     out = dict(segs=segs, rec_f=rec_f, fwd_rows=fwd_rows, ray_ptr=ray_ptr, ray_seg=ray_seg, ray_pre=ray_pre,
-               ent=ent, rec_b=rec_b, bwd_rows=bwd_rows, kin=kin, pull=np.asarray(pull, np.int32))
+               ent=ent, rec_b=rec_b, bwd_rows=bwd_rows, kin=kin, pull=np.asarray(pull, np.int32), h_ent=h_ent, h_rows=h_rows)
     if tuple(pull) == GATHER_BRICK and gather:
         out.update(_gather_tables(pnb, ent, ent_brick, gstart, gcount, i_first, rel, own, wts[s_id], eb, ee, split_b))
     return out

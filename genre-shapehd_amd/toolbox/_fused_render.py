@@ -207,7 +207,7 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
                                               gather=gather)
         build.__module__ = _bm_tables.__name__
         np_t = _disk_cached("bm", (tuple(vox_shape[2:]), pull, _bm_tables.ROW_ORDER, _bm_tables.SPLIT_F,
-                                   _bm_tables.SPLIT_B, _bm_tables.MAXSEG, gather), [d64, dw], build)
+                                   _bm_tables.SPLIT_B, _bm_tables.SPLIT_H, _bm_tables.MAXSEG, gather, "r4"), [d64, dw], build)
         t = {"pull_code": int(np_t["pull"][0]) * 100 + int(np_t["pull"][1]) * 10 + int(np_t["pull"][2])}
         for k, v in np_t.items():
             if k == "pull":
@@ -227,7 +227,7 @@ def bm_backward_mode():
     at every call"""
     import os
     mode = os.environ.get("GENRE_BM_BWD", "scatter")
-    assert mode in ("gather", "scatter"), "GENRE_BM_BWD must be gather or scatter"
+    assert mode in ("gather", "scatter", "halo"), "GENRE_BM_BWD must be scatter, gather or halo"
     return mode
 
 
@@ -294,7 +294,13 @@ class RenderSphericalFused(Function):
             t = bm_tables_for(ctx.vox_shape, grad_out.device, dirs64, depth_weight)
             grad_vox = empty_batch_minor(ctx.vox_shape, grad_out.dtype, grad_out.device)
             groups = -(-ctx.vox_shape[0] // 32)
-            if "g_ent" in t and bm_backward_mode() == "gather":
+            if bm_backward_mode() == "halo":
+                nb = -(-ctx.vox_shape[2] // 4) * -(-ctx.vox_shape[3] // 8) * -(-ctx.vox_shape[4] // 8)
+                lib.render_bm_backward_halo(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"],
+                                            t["h_ent"], t["rec_f"], t["h_rows"], depth_weight, ps, torch.empty_like(ps), stash,
+                                            ctx.mask, torch.empty((groups * nb * 149 * 32,), dtype=ps.dtype, device=ps.device),
+                                            ctx.pre_scale)
+            elif "g_ent" in t and bm_backward_mode() == "gather":
                 lib.render_bm_backward_gather(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"],
                                               t["g_ent"], t["g_chunks"], t["g_blob"], t["g_rows"], depth_weight, ps,
                                               torch.empty((ps.numel() + groups,), dtype=ps.dtype, device=ps.device),

@@ -343,6 +343,22 @@ int genre_render_bm_backward_gather(const genre_tensor *grad_out, const genre_te
                                     const genre_tensor *tr_scratch, const genre_tensor *p_stash,
                                     const genre_tensor *mask, float pre_scale, void *stream);
 
+/* The same backward in HALO form ("owner computes", round 4; csrc/sph_render_bm.hip: bm_scatter_kernel<HALO> +
+ * bm_halo_combine_kernel): every 4x8x8 brick scatters the segments of its OWN samples -- each sample once, all eight corners,
+ * no ownership masks -- into a 5x9x9-line fp64 tile, writes its brick to grad_vox and the 149 halo lines to halo_scratch;
+ * a second kernel adds each brick's <= 7 neighbours' halo lines onto its low faces (and applies the clamp mask there).
+ * Tables: the forward's segs / rec_f, h_ent int32 [nseg,4] = (scratch line, slot, L<<6 | L<<12 | k0<<18, slot) and h_rows
+ * int32 [rows,4] = (brick, segment begin, segment end, shared) of toolbox/_bm_tables.py.
+ * halo_scratch fp32 [groups * bricks * 149 * 32] (bricks = ceil(X/4) ceil(Y/8) ceil(Z/8)); other buffers as above. */
+int genre_render_bm_backward_halo(const genre_tensor *grad_out, const genre_tensor *grad_vox,
+                                  const genre_tensor *segs, const genre_tensor *ray_ptr,
+                                  const genre_tensor *ray_seg, const genre_tensor *ray_pre,
+                                  const genre_tensor *h_ent, const genre_tensor *rec_f,
+                                  const genre_tensor *h_rows, const genre_tensor *depth_weight,
+                                  const genre_tensor *ps_scratch, const genre_tensor *tr_scratch,
+                                  const genre_tensor *p_stash, const genre_tensor *mask,
+                                  const genre_tensor *halo_scratch, float pre_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

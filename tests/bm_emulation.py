@@ -209,3 +209,92 @@ def backward_gather(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
         _flush(grad, written, tile, brick, (BX, BY, BZ), nby, nbz, mask, pre_scale)
     assert (written == 1).all(), "every voxel must be written exactly once"
     return grad
+
+
+def halo_index(mod, tx, ty, tz):
+    """csrc/sph_render_bm.hip: halo_index -- line (tx, ty, tz) of a tile that lies outside its brick -> 0 .. 148"""
+    if tx == mod.BX:
+        return ty * mod.TZ + tz
+    if ty == mod.BY:
+        return mod.TY * mod.TZ + tx * mod.TZ + tz
+    return mod.TY * mod.TZ + mod.BX * mod.TZ + tx * mod.BY + ty
+
+
+def backward_halo(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
+    """the halo ("owner computes") form of the backward: every brick scatters its OWN segments (h_ent over the forward's
+    rec_f) into a tile with halo, writes its brick, leaves the 149 halo lines in a scratch buffer, and a second pass adds the
+    <= 7 neighbours' halo lines onto each brick's low faces -- the data flow of bm_scatter_kernel<HALO> and
+    bm_halo_combine_kernel, indices included.  g [RR] -> grad_vox [X,Y,Z] (float64)"""
+    X, Y, Z = shape
+    BX, BY, BZ, TX, TY, TZ = mod.BX, mod.BY, mod.BZ, mod.TX, mod.TY, mod.TZ
+    nbx, nby, nbz = -(-X // BX), -(-Y // BY), -(-Z // BZ)
+    segs = t["segs"]
+    TR = np.zeros((segs.shape[0], 2))
+    rr = t["ray_ptr"].shape[0] - 1
+    for q in range(rr):
+        ids = range(t["ray_ptr"][q], t["ray_ptr"][q + 1])
+        T = t["ray_pre"][q][0]
+        for s in ids:
+            TR[s, 0] = g[q] * T
+            T *= PS[s, 0]
+        Rr = 1.0
+        for s in ids[::-1]:
+            TR[s, 1] = Rr
+            Rr = PS[s, 1] + PS[s, 0] * Rr
+    rec = t["rec_f"]
+    w = rec[:, 4:12].view(np.float32).astype(np.float64)
+    corner = np.array([(c & 1) * TY * TZ + ((c >> 1) & 1) * TZ + (c >> 2) for c in range(8)])
+    nb = nbx * nby * nbz
+    tiles = np.zeros((nb, TX * TY * TZ))
+    seen = np.zeros(nb, np.int32)
+    for brick, e0, e1, shared in t["h_rows"]:
+        if shared == mod.SKIP:
+            continue
+        seen[brick] += 1
+        live = t["h_rows"][t["h_rows"][:, 3] != mod.SKIP]
+        assert shared == (1 if (live[:, 0] == brick).sum() > 1 else 0)
+        for e in range(e0, e1):
+            s, slot0, pk, rs = t["h_ent"][e]
+            i0, i1, L, k0 = pk & 63, (pk >> 6) & 63, (pk >> 12) & 63, (pk >> 18) & 255
+            assert i0 == 0 and i1 == L and rs == slot0 and tuple(segs[e]) == (s, k0, L, slot0)
+            p = stash[slot0:slot0 + L]
+            Tg, Rr = TR[s]
+            c = np.zeros(L)
+            for i in range(L):
+                c[i] = Tg if p[i] > 0 else 0.0
+                Tg *= 1.0 - abs(p[i])
+            for i in range(L - 1, -1, -1):
+                wk = float(dw[k0 + i])
+                dp = c[i] * (wk - Rr)
+                Rr = Rr + abs(p[i]) * (wk - Rr)
+                line = 2 * rec[rs + i, 0] // mod.LINE_B                      # fp32 tile offset doubled = fp64 tile offset
+                for cc in range(8):
+                    tiles[brick, line + corner[cc]] += w[rs + i, cc] * dp
+    assert (seen >= 1).all(), "every brick needs a row"
+    grad = np.zeros(shape)
+    for brick in range(nb):
+        bx, by, bz = brick // (nby * nbz), (brick // nbz) % nby, brick % nbz
+        tl = tiles[brick].reshape(TX, TY, TZ)
+        for lx in range(BX):
+            for ly in range(BY):
+                for lz in range(BZ):
+                    x, y, z = bx * BX + lx, by * BY + ly, bz * BZ + lz
+                    if x >= X or y >= Y or z >= Z:
+                        continue
+                    val = tl[lx, ly, lz]
+                    for d in range(1, 8):
+                        dx, dy, dz = d & 1, (d >> 1) & 1, d >> 2
+                        if (dx and lx) or (dy and ly) or (dz and lz) or (dx and bx == 0) or (dy and by == 0) or (dz and bz == 0):
+                            continue
+                        nbrick = ((bx - dx) * nby + (by - dy)) * nbz + (bz - dz)
+                        tx, ty, tz = (BX if dx else lx), (BY if dy else ly), (BZ if dz else lz)
+                        h = halo_index(mod, tx, ty, tz)
+                        # the scratch line h of the neighbour is its tile line (tx, ty, tz)
+                        lines = [(a, b, c2) for a in range(TX) for b in range(TY) for c2 in range(TZ)
+                                 if (a == BX or b == BY or c2 == BZ) and halo_index(mod, a, b, c2) == h]
+                        assert lines == [(tx, ty, tz)]
+                        val += tiles[nbrick].reshape(TX, TY, TZ)[tx, ty, tz]
+                    if pre_scale != 0.0:
+                        val = val * pre_scale if mask[x, y, z] else 0.0
+                    grad[x, y, z] = val
+    return grad

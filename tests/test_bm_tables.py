@@ -54,6 +54,8 @@ def test_tables_reproduce_the_reference_chain(res, sph, zr, pre_scale, split, pu
     g = np.random.default_rng(1).standard_normal(sph * sph).astype(np.float32)
     ref.backward(torch.from_numpy(g).reshape(ref.shape))
     grad = E.backward(m, t, vox.shape, PS, stash, mask, g, dw, pre_scale)
+    grad_h = E.backward_halo(m, t, vox.shape, PS, stash, mask, g, dw, pre_scale)      # the halo form: same sums, other order
+    assert np.abs(grad_h - grad).max() <= 1e-12 * max(1.0, np.abs(grad).max())
     gr = vt.grad[0, 0].numpy()
     assert (np.abs(grad - gr) / np.maximum(1, np.abs(gr))).max() <= 2e-5
     if tuple(pull) == m.GATHER_BRICK:                                       # the gather form of the backward: same sums
