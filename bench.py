@@ -300,7 +300,7 @@ def kernel_table(G, dev, B):
                 bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
                 kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+" + ("bm_gather_kernel" if gather else "bm_scatter_kernel"),
                 pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel<4, 8, 8>",
-                     "bm_gather_kernel<true>" if gather else "bm_scatter_kernel<true, 4, 8, 8, 768>"],
+                     "bm_gather_kernel<true>" if gather else "bm_scatter_kernel<true, 4, 8, 8, 768, false>"],
                 src=("common.hpp", "sph_render_bm.hip"))
             bm_fwd(True)                                            # (the saved state of the GenRe volume again)
             rows["render_bwd_bm"]["us"] = event_time_us(bm_bwd_gather if gather else bm_bwd_scatter, iters, 5)

@@ -143,6 +143,10 @@ def main(argv=None):
     device = torch.device("cuda", local) if cuda else torch.device("cpu")
     if cuda:
         torch.cuda.set_device(device)
+    # util/util_loadlib.py:11 of the reference: MIOpen times its solvers per convolution shape instead of trusting its
+    # heuristics (measured on MI355X, round 4: ShapeHD step 49.7 -> 35.8 ms, GenRe joint 75.5 -> 64.5 ms; the results land in
+    # the user find-db, which tools/warm_miopen.py ships in the tree)
+    torch.backends.cudnn.benchmark = True
     dist = dist_utils.init_from_env(args.backend or ("nccl" if cuda else "gloo"), device if cuda else None)
     torch.manual_seed(1234)                                             # identical initial weights on every rank
     start = 0

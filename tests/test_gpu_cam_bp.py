@@ -357,4 +357,6 @@ def test_by_value_camera_entry_equals_the_tensor_entry(genre, oracle, dev):
     for res in (30, 126):
         ya = ShiftedCameraBackProjection.apply(d1, flt, cdt, res, False, (418.3, 2.2))
         yb = ShiftedCameraBackProjection.apply(d1, flt, cdt, res, False, None)
-        assert ya.shape == (1, 1, res, res, res) and torch.equal(ya, yb)
+        # (both are the three-launch path: global float atomics, so multi-hit voxels -- most of them at 30^3 -- agree to
+        # rounding, not bit for bit)
+        assert ya.shape == (1, 1, res, res, res) and (ya - yb).abs().max().item() <= res * TOL

@@ -20,6 +20,7 @@ from genre_shapehd_amd.models import shapehd as MS  # noqa: E402
 from genre_shapehd_amd.models.genre import GenReNet, GenReOptions, GenReInference  # noqa: E402
 
 dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = True           # MIOpen's measured find per shape: what the find-db should hold (train.py sets it too)
 t0 = time.time()
 to = lambda ns: type(ns)(**{k: v.to(dev) for k, v in vars(ns).items()})       # noqa: E731
 torch.manual_seed(0)
