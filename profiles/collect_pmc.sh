@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python "$ROOT/bench.
 python "$ROOT/profiles/summarize_rocpd.py" "$OUT"/prof/bench_results.db > "$OUT/kernel_stats.txt" 2>&1 || python "$ROOT/profiles/summarize_rocpd.py" $(ls "$OUT"/prof/*/*_results.db | head -1) > "$OUT/kernel_stats.txt" 2>&1
 # kernel trace of pmc_targets.py alone: the batch-minor renderer there runs on the SOFT volume only (what roofline is quoted on;
 # in the bench trace above the same kernel names mix it with the GenRe volume, whose backward only writes zeros)
-rocprofv3 --kernel-trace --stats -d "$OUT/prof_t" -o targets -- python "$ROOT/profiles/pmc_targets.py" "$B" > /dev/null 2> "$OUT/prof_t.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_t" -o targets -- python "$ROOT/profiles/pmc_targets.py" "$B" 16 > /dev/null 2> "$OUT/prof_t.err"
 python "$ROOT/profiles/summarize_rocpd.py" $(ls "$OUT"/prof_t/targets_results.db "$OUT"/prof_t/*/targets_results.db 2>/dev/null | head -1) > "$OUT/kernel_stats_soft.txt" 2>&1
 rm -rf "$OUT/prof_t"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_f" -o fetch -- python "$ROOT/profiles/pmc_targets.py" "$B" > /dev/null 2> "$OUT/pmc_f.err"
