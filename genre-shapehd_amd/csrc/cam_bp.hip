@@ -749,6 +749,137 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
     }
 }
 
+// ---- camera forward for IMAGE-MINOR volumes (round 4): one launch, LDS bricks, deterministic ---------------------------
+// Volumes whose image index is fastest in memory (element (n,x,y,z) at x*sx + y*sy + z*sz + n: what the batch-minor
+// renderer wants, csrc/sph_render_bm.hip) have no contiguous z rows, so cam_brick_kernel cannot write them and the
+// three-launch path (fill, tile scatter with GLOBAL float atomics in undefined order, per-pixel normalise) served them:
+// 149 us at batch 32, not run-to-run deterministic.  Here a workgroup owns a 4 x 4 x 8 voxel brick FOR A GROUP OF 32 IMAGES:
+//   * sums [128 voxels][32 images] fp64 + counts u32 in LDS (48 KB; ds_add_f64 as in cam_brick_kernel);
+//   * wave w takes images w, w + 4, ... of the group; for each image the brick's pixel footprint (~10 x 18 px at 128^3 /
+//     256^2 / the GenRe camera) is loaded -- all of a wave's images up front, three 64-pixel rounds each in registers -- and
+//     every pixel goes through the plane-depth test and, if it survives, the reference's arithmetic (pixel_voxel); a point that
+//     lands in the brick is added to [voxel][image];
+//   * flush: a voxel's 32 images are one 128-byte line of the output, eight z-neighbours 1 KB contiguous: float4 stores of
+//     the normalised value (K2, :291-305, exactly cam_brick_kernel's expression) and of the count.
+// Same values as cam_brick_kernel writes into an NCXYZ volume, bit for bit (sums of exact fp32 distances in fp64 are
+// order-independent here: 37 significant bits + the count fit the 53 of a double), so the two layouts agree exactly and the
+// result does not depend on the batch an image travels in.
+constexpr int kMX = 4, kMY = 4, kMZ = 8, kMVox = kMX * kMY * kMZ, kMImgs = 32, kMRounds = 3;
+
+template <bool BYVAL>
+__global__ __launch_bounds__(kBlock) void cam_bm_brick_kernel(Dims D, View4 depth, View2 camdist, View2 fl, View5 vox, View5 cnt,
+                                                              float prefill, float bias, float post_scale, float post_bias,
+                                                              float fill_val, float fl_val, float cd_val)
+{
+    __shared__ double s_sum[kMVox * kMImgs];
+    __shared__ unsigned s_cnt[kMVox * kMImgs];
+    const int nbz = (D.Z + kMZ - 1) / kMZ, nby = (D.Y + kMY - 1) / kMY;
+    const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
+    const int n0 = blockIdx.y * kMImgs;
+    const int x0 = bx * kMX, y0 = by * kMY, z0 = bz * kMZ;
+    const int x1 = min(x0 + kMX, D.X), y1 = min(y0 + kMY, D.Y), z1 = min(z0 + kMZ, D.Z);
+    const float rX = 1.0f / (float)D.X, rY = 1.0f / (float)D.Y, rZ = 1.0f / (float)D.Z;
+    const float bxlo = (float)x0 * rX - 0.5f, bxhi = (float)x1 * rX - 0.5f;
+    for (int e = threadIdx.x; e < kMVox * kMImgs; e += kBlock) { s_sum[e] = 0.0; s_cnt[e] = 0u; }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    constexpr int kPer = kMImgs / (kBlock / 64);                       // images per wave
+    float dv[kPer][kMRounds];
+    Win bw[kPer];
+    float fs[kPer], cds[kPer];
+    // ---- all loads of this wave's images first
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+        const int n = n0 + wave + i * (kBlock / 64);
+        const bool on = n < D.N;
+        fs[i] = BYVAL ? fl_val : (on ? fl.p[n * fl.s0] : 1.0f);
+        cds[i] = BYVAL ? cd_val : (on ? camdist.p[n * camdist.s0] : 1.0f);
+        bw[i] = project_box(D, bxlo, bxhi, (float)y0 * rY - 0.5f, (float)y1 * rY - 0.5f, (float)z0 * rZ - 0.5f,
+                            (float)z1 * rZ - 0.5f, cds[i], fs[i], 1.0f);
+        const int bww = bw[i].w1 - bw[i].w0 + 1, bwh = bw[i].h1 - bw[i].h0 + 1;
+        const int area = (on && bww > 0 && bwh > 0) ? bww * bwh : 0;
+        const float inv_bww = 1.0f / (float)(bww > 0 ? bww : 1);
+        const float *dimg = depth.p + (on ? n : 0) * depth.s0;
+#pragma unroll
+        for (int r = 0; r < kMRounds; r++) {
+            const int t = lane + 64 * r;
+            dv[i][r] = -1.0f;
+            if (t < area) {
+                int rr, q;
+                divmod_px(t, bww, inv_bww, rr, q);
+                dv[i][r] = dimg[(bw[i].h0 + rr) * depth.s2 + (bw[i].w0 + q) * depth.s3];
+            }
+        }
+    }
+    // ---- every footprint pixel once: plane-depth test, then the reference's arithmetic for the survivors
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+        const int img = wave + i * (kBlock / 64), n = n0 + img;
+        if (n >= D.N) continue;
+        const float f = fs[i], cam_dist = cds[i];
+        const int bww = bw[i].w1 - bw[i].w0 + 1, bwh = bw[i].h1 - bw[i].h0 + 1;
+        const int area = (bww > 0 && bwh > 0) ? bww * bwh : 0;
+        const float inv_bww = 1.0f / (float)(bww > 0 ? bww : 1);
+        const float eps = 1e-4f;
+        const bool special = !(f > 0.0f) || !(bxlo + cam_dist > 1e-3f) ||
+                             (bxlo + cam_dist - eps <= 0.0f && bxhi + cam_dist + eps >= 0.0f);
+        const float xlo_t = bxlo - 1e-5f, xhi_t = bxhi + 1e-5f;
+        const float *dimg = depth.p + n * depth.s0;
+        auto pixel = [&](int t, float d_raw) {
+            if (d_raw < 0.0f) return;                                       // :225
+            int rr, q;
+            divmod_px(t, bww, inv_bww, rr, q);
+            const int h = bw[i].h0 + rr, w = bw[i].w0 + q;
+            if (!special) {
+                const float u_h = (float)h - ((float)D.H - 1.0f) / 2.0f, u_w = (float)w - ((float)D.W - 1.0f) / 2.0f;
+                const float xp = d_raw * f * __frsqrt_rn(u_h * u_h + u_w * u_w + f * f) - cam_dist;
+                if (xp < xlo_t || xp > xhi_t) return;
+            }
+            int ix, iy, iz;
+            float dist;
+            if (pixel_voxel<false>(D, true, d_raw, 0.f, 0.f, 0.f, f, cam_dist, h, w, ix, iy, iz, dist) < 0) return;
+            if (ix < x0 || ix >= x1 || iy < y0 || iy >= y1 || iz < z0 || iz >= z1) return;
+            const int l = (((ix - x0) * kMY + (iy - y0)) * kMZ + (iz - z0)) * kMImgs + img;
+            unsafeAtomicAdd(&s_sum[l], (double)dist);                       // :273
+            atomicAdd(&s_cnt[l], 1u);                                       // :274
+        };
+#pragma unroll
+        for (int r = 0; r < kMRounds; r++)
+            if (lane + 64 * r < area) pixel(lane + 64 * r, dv[i][r]);
+        for (int t = lane + 64 * kMRounds; t < area; t += 64) {             // footprints beyond 192 pixels (other cameras)
+            int rr, q;
+            divmod_px(t, bww, inv_bww, rr, q);
+            pixel(t, dimg[(bw[i].h0 + rr) * depth.s2 + (bw[i].w0 + q) * depth.s3]);
+        }
+    }
+    __syncthreads();
+    // ---- normalise (:291-305) and write: four images per thread, a voxel's 32 images = one 128-byte line
+    const bool v4 = (D.N & 3) == 0 && ((vox.s2 | vox.s3 | vox.s4 | cnt.s2 | cnt.s3 | cnt.s4) & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(vox.p) | reinterpret_cast<uintptr_t>(cnt.p)) & 15) == 0;
+    for (int qd = threadIdx.x; qd < kMVox * (kMImgs / 4); qd += kBlock) {
+        const int line = qd >> 3, piece = (qd & 7) * 4, n = n0 + piece;
+        const int ix = x0 + line / (kMY * kMZ), iy = y0 + (line / kMZ) % kMY, iz = z0 + line % kMZ;
+        if (ix >= D.X || iy >= D.Y || iz >= D.Z || n >= D.N) continue;
+        float tv[4], kv[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float k = (float)s_cnt[line * kMImgs + piece + c];
+            kv[c] = k;
+            // (sum - bias) / k  (:304): a correctly rounded division, as the reference's -- once per voxel, not on the hot path
+            tv[c] = k > 0.0f ? post_bias + post_scale * (((prefill + (float)s_sum[line * kMImgs + piece + c]) - bias) / k) : fill_val;
+        }
+        float *pv = vox.p + ix * vox.s2 + iy * vox.s3 + iz * vox.s4 + n;
+        float *pc = cnt.p + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4 + n;
+        if (v4 && n + 3 < D.N) {
+            camq_store4(pv, make_float4(tv[0], tv[1], tv[2], tv[3]));
+            camq_store4(pc, make_float4(kv[0], kv[1], kv[2], kv[3]));
+        } else {
+            for (int c = 0; c < 4; c++)
+                if (n + c < D.N) { pv[c] = tv[c]; pc[c] = kv[c]; }
+        }
+    }
+}
+
 // ---- K3: surface mask (:324-357), one lane per voxel, z fastest -----------------
 __device__ __forceinline__ int floor_i_d(double a) { return (a < 0) ? (int)a - 1 : (int)a; }
 __device__ __forceinline__ int round_i_d(double a)
@@ -1081,6 +1212,19 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
     };
     const int vec_ok = rows_aligned(voxel) && rows_aligned(cnt);
     CamMode mode = SPH ? kScatter : cam_mode();
+    // image-minor outputs (the batch-minor renderer's layout): one launch, LDS bricks over groups of 32 images
+    const bool image_minor = !SPH && D.NC == 1 && D.N > 1 && voxel->stride[0] == 1 && cnt->stride[0] == 1 &&
+                             (int64_t)D.X * D.Y * D.Z > 0 && (D.N + kMImgs - 1) / kMImgs <= 65535;
+    if (image_minor && (mode == kAuto || mode == kBrick) && !byval) {
+        const float prefill = (float)(1.0 / (double)D.X);               // cam_back_projection.py:23-24 (res = X)
+        const float bias = 1.0f / (float)mx;                             // K2: dist_bias / max(res)  (:304,:829)
+        const int64_t bricks = (int64_t)((D.X + kMX - 1) / kMX) * ((D.Y + kMY - 1) / kMY) * ((D.Z + kMZ - 1) / kMZ);
+        GENRE_REQUIRE(bricks < ((int64_t)1 << 31), "%s: volume too large", op);
+        cam_bm_brick_kernel<false><<<dim3((unsigned)bricks, (unsigned)((D.N + kMImgs - 1) / kMImgs)), kBlock, 0, st>>>(
+            D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias, post_scale, post_bias, fill_val, 0.0f, 0.0f);
+        GENRE_LAUNCH_CHECK("projection forward (image-minor bricks)");
+        return 1;
+    }
     if (mode == kAuto) mode = (vec_ok && D.N * D.NC <= 65535) ? kBrick : kScatter;
     if (byval) {
         GENRE_REQUIRE(!SPH && vec_ok && D.N * D.NC <= 65535 && (mode == kBrick || cam_mode() == kAuto),

@@ -360,3 +360,47 @@ def test_by_value_camera_entry_equals_the_tensor_entry(genre, oracle, dev):
         # (both are the three-launch path: global float atomics, so multi-hit voxels -- most of them at 30^3 -- agree to
         # rounding, not bit for bit)
         assert ya.shape == (1, 1, res, res, res) and (ya - yb).abs().max().item() <= res * TOL
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+def test_image_minor_camera_forward_is_the_brick_kernel_bit_for_bit(shifted, genre, oracle, dev):
+    """cam_bm_brick_kernel (round 4): volumes whose image index is fastest in memory get the same values as
+    cam_brick_kernel writes into an NCXYZ volume -- bit for bit, on every voxel (sums of exact distances in fp64 are
+    order-independent), so the result is deterministic (two runs agree bit for bit) and independent of the layout and of the
+    batch an image travels in.  Batches of 32, 19 (a partly filled group), 40 (two groups, the second partly filled), 3;
+    per-image cameras; odd geometries (partial bricks, res % 4 != 0, a camera inside the grid, negative and zero depths)."""
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    from genre_shapehd_amd.toolbox import _fused_render
+    rng = np.random.default_rng(41)
+    cases = []
+    for n in (32, 19, 40, 3):
+        d = inputs.batch_depth(n, seed=70 + n)
+        fl = (418.3 * (1 + 0.05 * rng.standard_normal((n, 1)))).astype(np.float32)
+        cd = (2.2 * (1 + 0.03 * rng.standard_normal((n, 1)))).astype(np.float32)
+        cases.append((d, fl, cd, 128))
+    for d, fl, cd, res in _odd_cases():
+        n = 5
+        dd = np.concatenate([d] * n)[:n]
+        cases.append((dd, np.concatenate([fl] * n)[:n], np.concatenate([cd] * n)[:n], res))
+    fwd = cam_bp_lib.back_projection_forward_shifted if shifted else cam_bp_lib.back_projection_forward
+    for d, fl, cd, res in cases:
+        n = d.shape[0]
+        a, ca = torch.empty((n, 1, res, res, res), device=dev), torch.empty((n, 1, res, res, res), device=dev)
+        fwd(t(d, dev), t(cd, dev), t(fl, dev), a, ca)
+        runs = []
+        for _ in range(2):
+            b = _fused_render.empty_batch_minor((n, 1, res, res, res), torch.float32, dev)
+            cb = _fused_render.empty_batch_minor((n, 1, res, res, res), torch.float32, dev)
+            b.fill_(float("nan")), cb.fill_(float("nan"))                  # every element must be written
+            fwd(t(d, dev), t(cd, dev), t(fl, dev), b, cb)
+            assert b.stride(0) == 1
+            runs.append((b.clone(), cb.clone()))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), (d.shape, res)
+        if res % 4 == 0:                                                    # (the NCXYZ side is the brick kernel: the same arithmetic)
+            assert torch.equal(ca, runs[0][1]) and torch.equal(a, runs[0][0]), (d.shape, res, shifted)
+        else:                                                               # (the NCXYZ side is the three-launch path there)
+            assert torch.equal(ca, runs[0][1]) and (a - runs[0][0]).abs().max().item() <= res * TOL
+        tdf_o, cnt_o = oracle.back_projection_forward(d[:2], cd[:2], fl[:2], res)
+        want = (1 - res * tdf_o) if shifted else tdf_o
+        assert np.array_equal(runs[0][1][:2].cpu().numpy(), cnt_o)
+        assert np.abs(runs[0][0][:2].cpu().numpy() - want).max() <= (res if shifted else 1) * TOL
