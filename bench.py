@@ -246,13 +246,14 @@ def kernel_table(G, dev, B):
             layer = G.Camera_back_projection_layer(batch_minor=True).to(dev)
             with torch.no_grad():
                 proj_bm = layer(d)
-            # the camera forward the batch-minor STEP runs: cam_bm_brick_kernel (round 4: one launch, LDS bricks over groups of
-            # 32 images, deterministic) -- image-minor volumes have no contiguous z rows for cam_brick_kernel
+            # the camera forward the batch-minor STEP runs: image-minor volumes have no contiguous z rows, so it is the
+            # three-launch path (fill, tile scatter with global float atomics, per-pixel normalise), not cam_brick_kernel
+            # (the deterministic single-launch alternative, GENRE_CAMBP_MODE=imageminor, measured 2.2x slower: DESIGN 3.1)
             cnt_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
             t = event_time_us(lambda: cam_bp_lib.back_projection_forward_shifted(d, cd, fl, proj_bm, cnt_bm), iters, 5)
             rows["cam_bp_fwd_bm"] = dict(us=t, bytes=B * BYTES_CAM_FWD,
-                                         kernels="cam_bm_brick_kernel (image-minor outputs: one launch)",
-                                         pmc=["cam_bm_brick_kernel<false>"],
+                                         kernels="fill2_vec4_kernel+scatter_tile_kernel<false>+normalise_tile_kernel<false>",
+                                         pmc=["fill2_vec4_kernel", "scatter_tile_kernel<false>", "normalise_tile_kernel<false>"],
                                          src=("common.hpp", "cam_bp.hip"))
             TB = _fused_render.bm_tables_for(proj_bm.shape, dev, mod._dirs64, mod.depth_weight)
             groups = -(-B // 32)

@@ -752,8 +752,9 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
 // ---- camera forward for IMAGE-MINOR volumes (round 4): one launch, LDS bricks, deterministic ---------------------------
 // Volumes whose image index is fastest in memory (element (n,x,y,z) at x*sx + y*sy + z*sz + n: what the batch-minor
 // renderer wants, csrc/sph_render_bm.hip) have no contiguous z rows, so cam_brick_kernel cannot write them and the
-// three-launch path (fill, tile scatter with GLOBAL float atomics in undefined order, per-pixel normalise) served them:
-// 149 us at batch 32, not run-to-run deterministic.  Here a workgroup owns a 4 x 4 x 8 voxel brick FOR A GROUP OF 32 IMAGES:
+// three-launch path (fill, tile scatter with GLOBAL float atomics in undefined order, per-pixel normalise) serves them:
+// 149 us at batch 32, not run-to-run deterministic.  This kernel is the deterministic alternative (opt-in,
+// GENRE_CAMBP_MODE=imageminor: measured 335 us, forward_impl).  A workgroup owns a 4 x 4 x 8 voxel brick FOR A GROUP OF 32 IMAGES:
 //   * sums [128 voxels][32 images] fp64 + counts u32 in LDS (48 KB; ds_add_f64 as in cam_brick_kernel);
 //   * wave w takes images w, w + 4, ... of the group; for each image the brick's pixel footprint (~10 x 18 px at 128^3 /
 //     256^2 / the GenRe camera) is loaded -- all of a wave's images up front, three 64-pixel rounds each in registers -- and
@@ -1150,7 +1151,7 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
 // arrivals at ~10 ns each + the polling), +1.9 us for the L2 write-back and +1.7 us for the invalidate each side
 // needs so that the XCDs' L2s agree; a kernel boundary inside a HIP graph costs ~1 us.)
 // The spherical path always scatters.
-enum CamMode { kAuto, kScatter, kGather, kBrick };
+enum CamMode { kAuto, kScatter, kGather, kBrick, kImageMinor };
 // The only process-level setting the library reads: the environment variable GENRE_CAMBP_MODE, looked up ONCE at the first
 // camera forward and constant afterwards -- a read-only configuration value, not mutable state: calls stay re-entrant
 // and independent of one another (include/genre_hip.h: "keeps no global state").
@@ -1159,7 +1160,7 @@ inline CamMode cam_mode()
     static const CamMode m = [] {
         const char *e = getenv("GENRE_CAMBP_MODE");
         if (!e) return kAuto;
-        return e[0] == 'g' ? kGather : e[0] == 'b' ? kBrick : e[0] == 's' ? kScatter : kAuto;
+        return e[0] == 'g' ? kGather : e[0] == 'b' ? kBrick : e[0] == 's' ? kScatter : e[0] == 'i' ? kImageMinor : kAuto;
     }();
     return m;
 }
@@ -1212,10 +1213,14 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
     };
     const int vec_ok = rows_aligned(voxel) && rows_aligned(cnt);
     CamMode mode = SPH ? kScatter : cam_mode();
-    // image-minor outputs (the batch-minor renderer's layout): one launch, LDS bricks over groups of 32 images
+    // image-minor outputs (the batch-minor renderer's layout), GENRE_CAMBP_MODE=imageminor: one launch, LDS bricks over groups of
+    // 32 images -- deterministic and bit-identical to cam_brick_kernel, but MEASURED SLOWER than the three launches it would
+    // replace (batch 32: 335 us against 149 us, profiles/r04j_*: 16 384 workgroups x 32 images x three footprint rounds are
+    // latency- and issue-bound at three workgroups per CU), so it is opt-in
     const bool image_minor = !SPH && D.NC == 1 && D.N > 1 && voxel->stride[0] == 1 && cnt->stride[0] == 1 &&
                              (int64_t)D.X * D.Y * D.Z > 0 && (D.N + kMImgs - 1) / kMImgs <= 65535;
-    if (image_minor && (mode == kAuto || mode == kBrick) && !byval) {
+    if (mode == kImageMinor && !(image_minor && !byval)) mode = kAuto;   // other layouts: as if the variable were not set
+    if (mode == kImageMinor) {
         const float prefill = (float)(1.0 / (double)D.X);               // cam_back_projection.py:23-24 (res = X)
         const float bias = 1.0f / (float)mx;                             // K2: dist_bias / max(res)  (:304,:829)
         const int64_t bricks = (int64_t)((D.X + kMX - 1) / kMX) * ((D.Y + kMY - 1) / kMY) * ((D.Z + kMZ - 1) / kMZ);

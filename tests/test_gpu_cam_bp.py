@@ -362,13 +362,9 @@ def test_by_value_camera_entry_equals_the_tensor_entry(genre, oracle, dev):
         assert ya.shape == (1, 1, res, res, res) and (ya - yb).abs().max().item() <= res * TOL
 
 
-@pytest.mark.parametrize("shifted", [False, True])
-def test_image_minor_camera_forward_is_the_brick_kernel_bit_for_bit(shifted, genre, oracle, dev):
-    """cam_bm_brick_kernel (round 4): volumes whose image index is fastest in memory get the same values as
-    cam_brick_kernel writes into an NCXYZ volume -- bit for bit, on every voxel (sums of exact distances in fp64 are
-    order-independent), so the result is deterministic (two runs agree bit for bit) and independent of the layout and of the
-    batch an image travels in.  Batches of 32, 19 (a partly filled group), 40 (two groups, the second partly filled), 3;
-    per-image cameras; odd geometries (partial bricks, res % 4 != 0, a camera inside the grid, negative and zero depths)."""
+def check_image_minor_cases(oracle, dev, shifted):
+    """body of the image-minor test below (runs in a subprocess under GENRE_CAMBP_MODE=imageminor: the library reads the
+    variable once per process)"""
     from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
     from genre_shapehd_amd.toolbox import _fused_render
     rng = np.random.default_rng(41)
@@ -404,3 +400,28 @@ def test_image_minor_camera_forward_is_the_brick_kernel_bit_for_bit(shifted, gen
         want = (1 - res * tdf_o) if shifted else tdf_o
         assert np.array_equal(runs[0][1][:2].cpu().numpy(), cnt_o)
         assert np.abs(runs[0][0][:2].cpu().numpy() - want).max() <= (res if shifted else 1) * TOL
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+def test_image_minor_camera_forward_is_the_brick_kernel_bit_for_bit_subprocess(shifted, dev):
+    """cam_bm_brick_kernel (round 4, opt-in: GENRE_CAMBP_MODE=imageminor): volumes whose image index is fastest in memory get
+    the same values as cam_brick_kernel writes into an NCXYZ volume -- bit for bit, on every voxel (sums of exact distances in
+    fp64 are order-independent), so the result is deterministic (two runs agree bit for bit) and independent of the layout
+    and of the batch an image travels in.  Batches of 32, 19 (a partly filled group), 40 (two groups), 3; per-image cameras;
+    odd geometries (partial bricks, res % 4 != 0, a camera inside the grid, negative and zero depths).  Measured 2.2x slower
+    than the three-launch path, hence opt-in (csrc/cam_bp.hip: forward_impl)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import torch\n"
+        "from oracle.oracle import Oracle\n"
+        "import genre_shapehd_amd\n"
+        "import test_gpu_cam_bp as T\n"
+        "T.check_image_minor_cases(Oracle(), torch.device('cuda:0'), %r)\n"
+        "print('ok')\n" % (root, os.path.join(root, "tests"), shifted))
+    env = dict(os.environ, GENRE_CAMBP_MODE="imageminor")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
