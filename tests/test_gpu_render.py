@@ -35,7 +35,10 @@ GRAD_CASES = ("random", "blob")
 
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("name", ["genre_binary", "soft", "random", "blob"])
-def test_render_spherical_forward_backward(name, fused, genre, oracle, dev):
+def test_render_spherical_map_within_1e_5_and_gradient_within_2e_5_of_the_fp32_chain(name, fused, genre, oracle, dev):
+    """(the bar is in the name, VERDICT r3: the map holds north_star's 1e-5; the gradient is compared with the reference's OWN
+    fp32 op sequence on the CPU, which is itself 8e-5 ... 2.7e-4 off the exact value of its operator -- DESIGN.md 5 -- so the
+    bar against it is 2e-5; against the float64 exact-operator yardstick the gradient holds 1e-5: test_gpu_render_genre.py)"""
     from genre_shapehd_amd.toolbox import _fused_render
     if fused and not _fused_render.available():
         pytest.skip("fused render kernel not in this build")
@@ -98,7 +101,7 @@ def test_pre_scale_fusion(genre, oracle, dev):
 
 
 @pytest.mark.parametrize("res,sph_res,z_res", [(24, 16, 32), (40, 24, 64), (16, 8, 12), (33, 20, 100)])
-def test_render_odd_geometries(res, sph_res, z_res, genre, oracle, dev):
+def test_render_odd_geometries_map_within_1e_5_gradient_within_2e_5_of_the_fp32_chain(res, sph_res, z_res, genre, oracle, dev):
     """partial bricks (res not a multiple of 16), small ray fans, short rays: the brick tables are built for
     any geometry; forward and backward against the CPU restatement, fused vs unfused on the GPU"""
     from genre_shapehd_amd.toolbox import _fused_render
