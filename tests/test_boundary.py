@@ -88,6 +88,30 @@ def test_validation_errors_do_not_launch(genre):
     rc = lib.genre_render_spherical_forward(C.byref(vox), C.byref(dirs), C.byref(dw), C.byref(desc((1, 1, 12, 12))),
                                             None, None, None, None, 0.0, None)          # padded map without the tables
     assert rc == 0 and b"brick path" in lib.genre_last_error()
+    # batch-minor renderer backward: ABI 3 wants one word per image group behind the clamp masks; the halo form checks its
+    # own tables and scratch (nothing is launched: every call fails validation)
+    def bm_vol(n, x, y, z):
+        d = T()
+        d.data, d.ndim, d.dtype = 0x1000, 5, 0
+        for i, (sz, st) in enumerate(zip((n, 1, x, y, z), (1, n * x * y * z, y * z * n, z * n, n))):
+            d.size[i], d.stride[i] = sz, st
+        return d
+    n, R, nseg, S = 32, 4, 40, 300
+    gvox, gout = bm_vol(n, 8, 8, 8), desc((n, 1, R, R))
+    segs, rptr, rseg, rpre = desc((nseg, 4), 1), desc((R * R + 1,), 1), desc((nseg,), 1), desc((R * R, 4))
+    ent, rec, rows = desc((nseg, 4), 1), desc((S, 12), 1), desc((4, 4), 1)
+    dwt, ps, tr, stash = desc((16,)), desc((nseg * 64,)), desc((nseg * 64,)), desc((S * 32,))
+    lib.genre_render_bm_backward.argtypes = [C.c_void_p] * 14 + [C.c_float, C.c_int, C.c_void_p]
+    args = [C.byref(a) for a in (gout, gvox, segs, rptr, rseg, rpre, ent, rec, rows, dwt, ps, tr, stash)]
+    rc = lib.genre_render_bm_backward(*args, C.byref(desc((8 * 8 * 8,), 1)), 50.0, 488, None)      # masks without the group word
+    assert rc == 0 and b"+ groups" in lib.genre_last_error()
+    lib.genre_render_bm_backward_halo.argtypes = [C.c_void_p] * 15 + [C.c_float, C.c_void_p]
+    mask = desc((8 * 8 * 8 + 1,), 1)
+    rc = lib.genre_render_bm_backward_halo(*args[:6], C.byref(desc((nseg - 1, 4), 1)), *args[7:], C.byref(mask),
+                                           C.byref(desc((2 * 149 * 32,))), 50.0, None)               # h_ent: one row per segment
+    assert rc == 0 and b"h_ent" in lib.genre_last_error()
+    rc = lib.genre_render_bm_backward_halo(*args, C.byref(mask), C.byref(desc((2 * 149 * 32 - 1,))), 50.0, None)   # 2 bricks x 149 lines
+    assert rc == 0 and b"halo_scratch" in lib.genre_last_error()
     # empty problems succeed without launching anything
     e = desc((0, 1, 8, 8))
     ev = desc((0, 1, 4, 4, 4))
