@@ -6,16 +6,118 @@
 // Same arithmetic as my_lib.c -- float differences and float left-to-right x*x + y*y + z*z (this file is compiled
 // with -ffp-contract=off), strict `<` so that the first of equal minima wins, serial accumulation of the gradients
 // inside one batch item -- spread over host threads by (batch item, block of queries) instead of one core.
+//
+// Round 4: the search runs 16 (AVX-512) or 8 (AVX2) QUERIES per vector -- lane = query, the target broadcast -- with separate
+// multiplies and adds (no FMA: an fma would round x*x + y*y once instead of twice) and a strict `<` per lane: every lane
+// executes the scalar loop's operations in the scalar loop's order, so dist and idx are bit-identical to my_lib.c whatever
+// the width; the path is picked at run time from the CPU's features (the library itself is built for plain x86-64).
 #include "common.hpp"
 #include <algorithm>
+#include <immintrin.h>
 #include <thread>
 #include <vector>
 
 namespace genre {
 namespace {
 
-void nearest(int n, int m, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ dist,
-             int *__restrict__ idx, int j0, int j1)
+void nearest_scalar(int n, int m, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ dist,
+                    int *__restrict__ idx, int j0, int j1);
+
+#ifndef __HIP_DEVICE_COMPILE__          // (hipcc parses this file for gfx950 too: x86 intrinsics and CPU probes are host-pass only)
+// 8 queries j .. j + 7 (the last group of a block is padded with copies of the block's last query)
+__attribute__((target("avx2"))) void nearest_avx2(int n, int m, const float *__restrict__ a, const float *__restrict__ b,
+                                                  float *__restrict__ dist, int *__restrict__ idx, int j0, int j1)
+{
+    if (m <= 0) { nearest_scalar(n, m, a, b, dist, idx, j0, j1); return; }
+    for (int j = j0; j < j1; j += 8) {
+        alignas(32) float qx[8], qy[8], qz[8];
+        for (int l = 0; l < 8; l++) {
+            const int q = std::min(j + l, j1 - 1);
+            qx[l] = a[q * 3 + 0]; qy[l] = a[q * 3 + 1]; qz[l] = a[q * 3 + 2];
+        }
+        const __m256 x1 = _mm256_load_ps(qx), y1 = _mm256_load_ps(qy), z1 = _mm256_load_ps(qz);
+        __m256 best;
+        __m256i besti = _mm256_setzero_si256();
+        {   // k == 0 initialises (my_lib.c:16: `k == 0 || d < best`)
+            const __m256 x2 = _mm256_sub_ps(_mm256_set1_ps(b[0]), x1), y2 = _mm256_sub_ps(_mm256_set1_ps(b[1]), y1),
+                         z2 = _mm256_sub_ps(_mm256_set1_ps(b[2]), z1);
+            best = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(x2, x2), _mm256_mul_ps(y2, y2)), _mm256_mul_ps(z2, z2));
+        }
+        for (int k = 1; k < m; k++) {
+            const __m256 x2 = _mm256_sub_ps(_mm256_set1_ps(b[k * 3 + 0]), x1), y2 = _mm256_sub_ps(_mm256_set1_ps(b[k * 3 + 1]), y1),
+                         z2 = _mm256_sub_ps(_mm256_set1_ps(b[k * 3 + 2]), z1);
+            const __m256 d = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(x2, x2), _mm256_mul_ps(y2, y2)), _mm256_mul_ps(z2, z2));
+            const __m256 lt = _mm256_cmp_ps(d, best, _CMP_LT_OQ);           // strict, false on NaN: as the scalar `d < best`
+            best = _mm256_blendv_ps(best, d, lt);
+            besti = _mm256_castps_si256(_mm256_blendv_ps(_mm256_castsi256_ps(besti), _mm256_castsi256_ps(_mm256_set1_epi32(k)), lt));
+        }
+        alignas(32) float bd[8];
+        alignas(32) int bi[8];
+        _mm256_store_ps(bd, best);
+        _mm256_store_si256(reinterpret_cast<__m256i *>(bi), besti);
+        for (int l = 0; l < 8 && j + l < j1; l++) { dist[j + l] = bd[l]; idx[j + l] = bi[l]; }
+    }
+}
+
+__attribute__((target("avx512f"))) void nearest_avx512(int n, int m, const float *__restrict__ a, const float *__restrict__ b,
+                                                       float *__restrict__ dist, int *__restrict__ idx, int j0, int j1)
+{
+    if (m <= 0) { nearest_scalar(n, m, a, b, dist, idx, j0, j1); return; }
+    for (int j = j0; j < j1; j += 16) {
+        alignas(64) float qx[16], qy[16], qz[16];
+        for (int l = 0; l < 16; l++) {
+            const int q = std::min(j + l, j1 - 1);
+            qx[l] = a[q * 3 + 0]; qy[l] = a[q * 3 + 1]; qz[l] = a[q * 3 + 2];
+        }
+        const __m512 x1 = _mm512_load_ps(qx), y1 = _mm512_load_ps(qy), z1 = _mm512_load_ps(qz);
+        __m512 best;
+        __m512i besti = _mm512_setzero_si512();
+        {
+            const __m512 x2 = _mm512_sub_ps(_mm512_set1_ps(b[0]), x1), y2 = _mm512_sub_ps(_mm512_set1_ps(b[1]), y1),
+                         z2 = _mm512_sub_ps(_mm512_set1_ps(b[2]), z1);
+            best = _mm512_add_ps(_mm512_add_ps(_mm512_mul_ps(x2, x2), _mm512_mul_ps(y2, y2)), _mm512_mul_ps(z2, z2));
+        }
+        for (int k = 1; k < m; k++) {
+            const __m512 x2 = _mm512_sub_ps(_mm512_set1_ps(b[k * 3 + 0]), x1), y2 = _mm512_sub_ps(_mm512_set1_ps(b[k * 3 + 1]), y1),
+                         z2 = _mm512_sub_ps(_mm512_set1_ps(b[k * 3 + 2]), z1);
+            const __m512 d = _mm512_add_ps(_mm512_add_ps(_mm512_mul_ps(x2, x2), _mm512_mul_ps(y2, y2)), _mm512_mul_ps(z2, z2));
+            const __mmask16 lt = _mm512_cmp_ps_mask(d, best, _CMP_LT_OQ);
+            best = _mm512_mask_mov_ps(best, lt, d);
+            besti = _mm512_mask_mov_epi32(besti, lt, _mm512_set1_epi32(k));
+        }
+        alignas(64) float bd[16];
+        alignas(64) int bi[16];
+        _mm512_store_ps(bd, best);
+        _mm512_store_si512(reinterpret_cast<void *>(bi), besti);
+        for (int l = 0; l < 16 && j + l < j1; l++) { dist[j + l] = bd[l]; idx[j + l] = bi[l]; }
+    }
+}
+
+#endif
+
+using nearest_fn = void (*)(int, int, const float *, const float *, float *, int *, int, int);
+
+nearest_fn pick_nearest()
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    return (nearest_fn)nearest_scalar;
+#else
+    static const nearest_fn f = [] {
+        const char *e = getenv("GENRE_NND_HOST_ISA");                  // scalar | avx2 | avx512: pins a path (tests)
+        __builtin_cpu_init();
+        const bool a512 = __builtin_cpu_supports("avx512f"), a2 = __builtin_cpu_supports("avx2");
+        if (e && e[0] == 's') return (nearest_fn)nearest_scalar;
+        if (e && e[3] == '2' && a2) return (nearest_fn)nearest_avx2;
+        if (a512) return (nearest_fn)nearest_avx512;
+        if (a2) return (nearest_fn)nearest_avx2;
+        return (nearest_fn)nearest_scalar;
+    }();
+    return f;
+#endif
+}
+
+void nearest_scalar(int n, int m, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ dist,
+                    int *__restrict__ idx, int j0, int j1)
 {
     for (int j = j0; j < j1; j++) {
         const float x1 = a[j * 3 + 0], y1 = a[j * 3 + 1], z1 = a[j * 3 + 2];
@@ -67,6 +169,7 @@ extern "C" int genre_nnd_forward_host(const genre_tensor *xyz1, const genre_tens
                       dist1->size[1] == n && dist2->size[1] == m && idx1->size[1] == n && idx2->size[1] == m,
                   "%s: outputs must be contiguous dist [B,n] / [B,m] fp32 and idx int32", op);
     if (b == 0) return 1;
+    const nearest_fn nearest = pick_nearest();
     const float *a = (const float *)xyz1->data, *c = (const float *)xyz2->data;
     constexpr int kBlock = 256;                                    // queries per work item
     const int nb1 = (n + kBlock - 1) / kBlock, nb2 = (m + kBlock - 1) / kBlock;

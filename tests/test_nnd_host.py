@@ -35,3 +35,38 @@ def test_host_entry_matches_the_reference_build(genre, reference):
     assert np.array_equal(d1.numpy(), rd1) and np.array_equal(d2.numpy(), rd2)
     score = genre.nndistance_score(torch.from_numpy(x1), torch.from_numpy(x2))
     assert score.shape == (2,) and torch.isfinite(score).all()
+
+
+@pytest.mark.parametrize("isa", ["scalar", "avx2", "avx512"])
+def test_every_vector_width_of_the_host_search_is_bit_identical(isa):
+    """csrc/nnd_host.hip runs 16 / 8 / 1 queries per vector (picked from the CPU's features at run time, pinned here through
+    GENRE_NND_HOST_ISA -- read once per process, hence the subprocess): dist and idx bit-identical to the C oracle on ragged
+    sizes (query counts that are not a multiple of the width, one query, one target), exact ties (the first of equal minima
+    wins in every lane) and a NaN coordinate (never `<` anything: it stays where the scalar loop leaves it)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys
+sys.path[:0] = [%r, %r]
+import numpy as np, torch
+import inputs
+import genre_shapehd_amd as G
+from oracle.oracle import Oracle
+O = Oracle()
+for b, n, m in ((1, 2048, 2048), (2, 37, 100), (3, 1, 5), (1, 64, 1), (2, 17, 16), (1, 255, 33)):
+    x1, x2 = inputs.clouds(b, n, m, seed1=30 + n, seed2=40 + m)
+    if m >= 5:
+        x2[:, 3] = x2[:, 1]
+    if n >= 17:
+        x1[0, 5, 1] = np.nan
+    d1, d2, i1, i2 = G.nndistance_w_idx(torch.from_numpy(x1), torch.from_numpy(x2))
+    rd1, rd2, ri1, ri2 = O.nnd_forward(x1, x2)
+    assert np.array_equal(i1.numpy(), ri1) and np.array_equal(i2.numpy(), ri2), (b, n, m)
+    assert np.array_equal(d1.numpy(), rd1, equal_nan=True) and np.array_equal(d2.numpy(), rd2, equal_nan=True), (b, n, m)
+print('ok')
+""" % (root, os.path.join(root, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, GENRE_NND_HOST_ISA=isa))
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-300:], out.stderr[-1500:])
