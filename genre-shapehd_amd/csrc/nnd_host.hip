@@ -24,38 +24,101 @@ void nearest_scalar(int n, int m, const float *__restrict__ a, const float *__re
                     int *__restrict__ idx, int j0, int j1);
 
 #ifndef __HIP_DEVICE_COMPILE__          // (hipcc parses this file for gfx950 too: x86 intrinsics and CPU probes are host-pass only)
-// 8 queries j .. j + 7 (the last group of a block is padded with copies of the block's last query)
+// U independent groups of queries per target: the chain best -> compare -> blend -> best is ~6 cycles long, and one group per
+// target runs at that latency; with U groups in flight the loop is bound by issue instead (measured on a 2.1 GHz Xeon, one
+// thread, 2048 x 2048 both directions: 1.57 ms with U = 1).  The last groups of a block are padded with copies of its last query.
+template <int U>
+__attribute__((target("avx2"))) void nearest_avx2_u(int m, const float *__restrict__ a, const float *__restrict__ b,
+                                                    float *__restrict__ dist, int *__restrict__ idx, int j0, int j1)
+{
+    for (int j = j0; j < j1; j += 8 * U) {
+        __m256 x1[U], y1[U], z1[U], best[U];
+        __m256i besti[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            alignas(32) float qx[8], qy[8], qz[8];
+            for (int l = 0; l < 8; l++) {
+                const int q = std::min(j + u * 8 + l, j1 - 1);
+                qx[l] = a[q * 3 + 0]; qy[l] = a[q * 3 + 1]; qz[l] = a[q * 3 + 2];
+            }
+            x1[u] = _mm256_load_ps(qx); y1[u] = _mm256_load_ps(qy); z1[u] = _mm256_load_ps(qz);
+            // k == 0 initialises (my_lib.c:16: `k == 0 || d < best`)
+            const __m256 x2 = _mm256_sub_ps(_mm256_set1_ps(b[0]), x1[u]), y2 = _mm256_sub_ps(_mm256_set1_ps(b[1]), y1[u]),
+                         z2 = _mm256_sub_ps(_mm256_set1_ps(b[2]), z1[u]);
+            best[u] = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(x2, x2), _mm256_mul_ps(y2, y2)), _mm256_mul_ps(z2, z2));
+            besti[u] = _mm256_setzero_si256();
+        }
+        for (int k = 1; k < m; k++) {
+            const __m256 bx = _mm256_set1_ps(b[k * 3 + 0]), by = _mm256_set1_ps(b[k * 3 + 1]), bz = _mm256_set1_ps(b[k * 3 + 2]);
+            const __m256i kk = _mm256_set1_epi32(k);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const __m256 x2 = _mm256_sub_ps(bx, x1[u]), y2 = _mm256_sub_ps(by, y1[u]), z2 = _mm256_sub_ps(bz, z1[u]);
+                const __m256 d = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(x2, x2), _mm256_mul_ps(y2, y2)), _mm256_mul_ps(z2, z2));
+                const __m256 lt = _mm256_cmp_ps(d, best[u], _CMP_LT_OQ);   // strict, false on NaN: as the scalar `d < best`
+                best[u] = _mm256_blendv_ps(best[u], d, lt);
+                besti[u] = _mm256_castps_si256(_mm256_blendv_ps(_mm256_castsi256_ps(besti[u]), _mm256_castsi256_ps(kk), lt));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            alignas(32) float bd[8];
+            alignas(32) int bi[8];
+            _mm256_store_ps(bd, best[u]);
+            _mm256_store_si256(reinterpret_cast<__m256i *>(bi), besti[u]);
+            for (int l = 0; l < 8 && j + u * 8 + l < j1; l++) { dist[j + u * 8 + l] = bd[l]; idx[j + u * 8 + l] = bi[l]; }
+        }
+    }
+}
+
 __attribute__((target("avx2"))) void nearest_avx2(int n, int m, const float *__restrict__ a, const float *__restrict__ b,
                                                   float *__restrict__ dist, int *__restrict__ idx, int j0, int j1)
 {
     if (m <= 0) { nearest_scalar(n, m, a, b, dist, idx, j0, j1); return; }
-    for (int j = j0; j < j1; j += 8) {
-        alignas(32) float qx[8], qy[8], qz[8];
-        for (int l = 0; l < 8; l++) {
-            const int q = std::min(j + l, j1 - 1);
-            qx[l] = a[q * 3 + 0]; qy[l] = a[q * 3 + 1]; qz[l] = a[q * 3 + 2];
-        }
-        const __m256 x1 = _mm256_load_ps(qx), y1 = _mm256_load_ps(qy), z1 = _mm256_load_ps(qz);
-        __m256 best;
-        __m256i besti = _mm256_setzero_si256();
-        {   // k == 0 initialises (my_lib.c:16: `k == 0 || d < best`)
-            const __m256 x2 = _mm256_sub_ps(_mm256_set1_ps(b[0]), x1), y2 = _mm256_sub_ps(_mm256_set1_ps(b[1]), y1),
-                         z2 = _mm256_sub_ps(_mm256_set1_ps(b[2]), z1);
-            best = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(x2, x2), _mm256_mul_ps(y2, y2)), _mm256_mul_ps(z2, z2));
+    if (j1 - j0 > 8) nearest_avx2_u<2>(m, a, b, dist, idx, j0, j1);       // 16 ymm registers: two groups
+    else nearest_avx2_u<1>(m, a, b, dist, idx, j0, j1);
+}
+
+template <int U>
+__attribute__((target("avx512f"))) void nearest_avx512_u(int m, const float *__restrict__ a, const float *__restrict__ b,
+                                                         float *__restrict__ dist, int *__restrict__ idx, int j0, int j1)
+{
+    for (int j = j0; j < j1; j += 16 * U) {
+        __m512 x1[U], y1[U], z1[U], best[U];
+        __m512i besti[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            alignas(64) float qx[16], qy[16], qz[16];
+            for (int l = 0; l < 16; l++) {
+                const int q = std::min(j + u * 16 + l, j1 - 1);
+                qx[l] = a[q * 3 + 0]; qy[l] = a[q * 3 + 1]; qz[l] = a[q * 3 + 2];
+            }
+            x1[u] = _mm512_load_ps(qx); y1[u] = _mm512_load_ps(qy); z1[u] = _mm512_load_ps(qz);
+            const __m512 x2 = _mm512_sub_ps(_mm512_set1_ps(b[0]), x1[u]), y2 = _mm512_sub_ps(_mm512_set1_ps(b[1]), y1[u]),
+                         z2 = _mm512_sub_ps(_mm512_set1_ps(b[2]), z1[u]);
+            best[u] = _mm512_add_ps(_mm512_add_ps(_mm512_mul_ps(x2, x2), _mm512_mul_ps(y2, y2)), _mm512_mul_ps(z2, z2));
+            besti[u] = _mm512_setzero_si512();
         }
         for (int k = 1; k < m; k++) {
-            const __m256 x2 = _mm256_sub_ps(_mm256_set1_ps(b[k * 3 + 0]), x1), y2 = _mm256_sub_ps(_mm256_set1_ps(b[k * 3 + 1]), y1),
-                         z2 = _mm256_sub_ps(_mm256_set1_ps(b[k * 3 + 2]), z1);
-            const __m256 d = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(x2, x2), _mm256_mul_ps(y2, y2)), _mm256_mul_ps(z2, z2));
-            const __m256 lt = _mm256_cmp_ps(d, best, _CMP_LT_OQ);           // strict, false on NaN: as the scalar `d < best`
-            best = _mm256_blendv_ps(best, d, lt);
-            besti = _mm256_castps_si256(_mm256_blendv_ps(_mm256_castsi256_ps(besti), _mm256_castsi256_ps(_mm256_set1_epi32(k)), lt));
+            const __m512 bx = _mm512_set1_ps(b[k * 3 + 0]), by = _mm512_set1_ps(b[k * 3 + 1]), bz = _mm512_set1_ps(b[k * 3 + 2]);
+            const __m512i kk = _mm512_set1_epi32(k);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const __m512 x2 = _mm512_sub_ps(bx, x1[u]), y2 = _mm512_sub_ps(by, y1[u]), z2 = _mm512_sub_ps(bz, z1[u]);
+                const __m512 d = _mm512_add_ps(_mm512_add_ps(_mm512_mul_ps(x2, x2), _mm512_mul_ps(y2, y2)), _mm512_mul_ps(z2, z2));
+                const __mmask16 lt = _mm512_cmp_ps_mask(d, best[u], _CMP_LT_OQ);
+                best[u] = _mm512_mask_mov_ps(best[u], lt, d);
+                besti[u] = _mm512_mask_mov_epi32(besti[u], lt, kk);
+            }
         }
-        alignas(32) float bd[8];
-        alignas(32) int bi[8];
-        _mm256_store_ps(bd, best);
-        _mm256_store_si256(reinterpret_cast<__m256i *>(bi), besti);
-        for (int l = 0; l < 8 && j + l < j1; l++) { dist[j + l] = bd[l]; idx[j + l] = bi[l]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            alignas(64) float bd[16];
+            alignas(64) int bi[16];
+            _mm512_store_ps(bd, best[u]);
+            _mm512_store_si512(reinterpret_cast<void *>(bi), besti[u]);
+            for (int l = 0; l < 16 && j + u * 16 + l < j1; l++) { dist[j + u * 16 + l] = bd[l]; idx[j + u * 16 + l] = bi[l]; }
+        }
     }
 }
 
@@ -63,34 +126,9 @@ __attribute__((target("avx512f"))) void nearest_avx512(int n, int m, const float
                                                        float *__restrict__ dist, int *__restrict__ idx, int j0, int j1)
 {
     if (m <= 0) { nearest_scalar(n, m, a, b, dist, idx, j0, j1); return; }
-    for (int j = j0; j < j1; j += 16) {
-        alignas(64) float qx[16], qy[16], qz[16];
-        for (int l = 0; l < 16; l++) {
-            const int q = std::min(j + l, j1 - 1);
-            qx[l] = a[q * 3 + 0]; qy[l] = a[q * 3 + 1]; qz[l] = a[q * 3 + 2];
-        }
-        const __m512 x1 = _mm512_load_ps(qx), y1 = _mm512_load_ps(qy), z1 = _mm512_load_ps(qz);
-        __m512 best;
-        __m512i besti = _mm512_setzero_si512();
-        {
-            const __m512 x2 = _mm512_sub_ps(_mm512_set1_ps(b[0]), x1), y2 = _mm512_sub_ps(_mm512_set1_ps(b[1]), y1),
-                         z2 = _mm512_sub_ps(_mm512_set1_ps(b[2]), z1);
-            best = _mm512_add_ps(_mm512_add_ps(_mm512_mul_ps(x2, x2), _mm512_mul_ps(y2, y2)), _mm512_mul_ps(z2, z2));
-        }
-        for (int k = 1; k < m; k++) {
-            const __m512 x2 = _mm512_sub_ps(_mm512_set1_ps(b[k * 3 + 0]), x1), y2 = _mm512_sub_ps(_mm512_set1_ps(b[k * 3 + 1]), y1),
-                         z2 = _mm512_sub_ps(_mm512_set1_ps(b[k * 3 + 2]), z1);
-            const __m512 d = _mm512_add_ps(_mm512_add_ps(_mm512_mul_ps(x2, x2), _mm512_mul_ps(y2, y2)), _mm512_mul_ps(z2, z2));
-            const __mmask16 lt = _mm512_cmp_ps_mask(d, best, _CMP_LT_OQ);
-            best = _mm512_mask_mov_ps(best, lt, d);
-            besti = _mm512_mask_mov_epi32(besti, lt, _mm512_set1_epi32(k));
-        }
-        alignas(64) float bd[16];
-        alignas(64) int bi[16];
-        _mm512_store_ps(bd, best);
-        _mm512_store_si512(reinterpret_cast<void *>(bi), besti);
-        for (int l = 0; l < 16 && j + l < j1; l++) { dist[j + l] = bd[l]; idx[j + l] = bi[l]; }
-    }
+    if (j1 - j0 > 32) nearest_avx512_u<4>(m, a, b, dist, idx, j0, j1);    // 32 zmm registers: four groups
+    else if (j1 - j0 > 16) nearest_avx512_u<2>(m, a, b, dist, idx, j0, j1);
+    else nearest_avx512_u<1>(m, a, b, dist, idx, j0, j1);
 }
 
 #endif
@@ -136,7 +174,8 @@ void nearest_scalar(int n, int m, const float *__restrict__ a, const float *__re
 template <typename F>
 void parallel_for(int64_t items, F &&fn)
 {
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("GENRE_HOST_THREADS")) hw = std::max(1, atoi(e));      // (experiments / reproducible timings)
     const int nt = (int)std::min<int64_t>(hw, items);
     if (nt <= 1) { for (int64_t i = 0; i < items; i++) fn(i); return; }
     std::vector<std::thread> pool;
