@@ -1184,8 +1184,8 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
         GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] >= (int64_t)D.groups * D.nslot * kImgs,
                       "%s: p_stash must hold groups*S*32 floats", op);
         GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) &&
-                                            mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z),
-                      "%s: pre_scale with a saved state needs mask int32 [groups*X*Y*Z]", op);
+                                            mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z + D.groups),
+                      "%s: pre_scale with a saved state needs mask int32 [groups*X*Y*Z + groups] (one word per image group behind the voxel masks)", op);
     }
     hipStream_t st = (hipStream_t)stream;
     if (save && pre_scale != 0.0f) {          // the groups' "some voxel passes the clamp" words behind the masks (set by the sampler)
