@@ -38,6 +38,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak (the networks of `m1` run fp32 on MIOpen)
 BYTES_CAM_FWD = 256 * 256 * 4 + 2 * 128 ** 3 * 4          # depth + tdf + cnt          = 17 039 360
 BYTES_CP_FWD = 2 * 128 * 128 * 256 * 4                    # prob in + stop out         = 33 554 432
 BYTES_CP_BWD_FUSED = 4 * 128 * 128 * 256 * 4              # p, s, grad in + grad out   = 67 108 864
@@ -87,6 +88,18 @@ def pmc_traffic(kernel_names, batch, sources=("common.hpp",)):
             return None, "%s has no row for %s" % (name, k)
         total += row["hbm_bytes"]
     return total, "profiles/" + name
+
+
+def miopen_find_db_state():
+    """`shipped` when MIOpen reads its find-db from the tree (genre-shapehd_amd/.miopen/db/*.txt, tracked since round 5: the measured
+    solver choices of tools/warm_miopen.py -- worth 154 -> 180 forward passes/s in round 4), `absent` when a clone has none and
+    MIOpen ranks solvers by its built-in estimates"""
+    import glob
+    db = os.environ.get("MIOPEN_USER_DB_PATH")
+    n = len(glob.glob(os.path.join(db, "*.ufdb.txt"))) if db else 0
+    return {"state": "shipped" if n else "absent", "path": os.path.relpath(db, ROOT) if db else None,
+            "kernel_cache": "present" if glob.glob(os.path.join(os.environ.get("MIOPEN_CUSTOM_CACHE_DIR", "/nonexistent"), "*.ukdb")) else
+                            "absent (MIOpen compiles its kernels on first use: minutes, outside every timed region)"}
 
 
 def parse():
@@ -305,6 +318,10 @@ def kernel_table(G, dev, B):
                 src=("common.hpp", "sph_render_bm.hip"))
             bm_fwd(True)                                            # (the saved state of the GenRe volume again)
             rows["render_bwd_bm"]["us"] = event_time_us(bm_bwd_gather if gather else bm_bwd_scatter, iters, 5)
+            # on GenRe's own volume the clamp blocks every voxel: the group reads B group words and writes grad_vox = 0 --
+            # it is billed with the bytes it MOVES there, not with the algorithmic bytes of a backward it does not compute
+            rows["render_bwd_bm"]["bytes"] = B * 128 ** 3 * 4
+            rows["render_bwd_bm"]["kernels"] += " on GenRe's volume (clamp blocks every voxel: writes zeros)"
             rows["render_fwd_bm_soft"] = dict(us=event_time_us(bm_fwd_soft, iters, 5), bytes=B * BYTES_RENDER_FUSED,
                                               kernels="bm_sample_kernel+bm_combine_fwd_kernel (soft volume)")
             bm_fwd_soft()
@@ -487,6 +504,52 @@ def batch1_graph(G, dev):
     return res
 
 
+def hot_path_batch1(G, dev, reps=20):
+    """configs[1] AS BASELINE.json STATES IT: one 256x256 depth map, forward AND backward (the reference tests at batch 1,
+    scripts/test_genre.sh:30; chain models/depth_pred_with_sph_inpaint.py:120-126), the reference's NCXYZ layout, replayed from
+    a HIP graph of `reps` forward+backward passes.  Two volumes: GenRe's own (clamp(proj * 50): every voxel saturated or
+    empty, the gradient through render_spherical identically zero, as in the reference) and the same chain with the
+    pre-scale at 0.9 instead of 50 (occupied voxels 0.12 ... 0.9: the clamp passes them -- a live gradient through the
+    renderer's backward down to the depth map)."""
+    import inputs
+    res = {"what": "configs[1] at its stated size: ONE 256x256 depth map -> cam_bp -> 128^3 -> clamp(x s) -> render_spherical -> "
+                   "sph_pad -> 160x160, forward + backward to grad_depth, NCXYZ layout, HIP-graph replay of %d passes" % reps}
+    d = torch.from_numpy(inputs.sphere_depth(noise_seed=2)).to(dev).requires_grad_(True)
+    gout = torch.randn((1, 1, 160, 160), device=dev)
+    net = HotPath(G, True).to(dev)
+    nbytes_f = BYTES_CAM_FWD + BYTES_RENDER_FUSED
+    nbytes_b = BYTES_RENDER_FUSED + 128 ** 3 * 4 + BYTES_CAM_FWD
+    for name, scale in (("genre_volume", 50.0), ("live_gradient", 0.9)):
+        def one():
+            d.grad = None
+            out = net.render(net.cam(d), pre_scale=scale, pad=16)
+            out.backward(gout)
+        try:
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                one()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            d.grad = None
+            with torch.cuda.graph(g):
+                for _ in range(reps):
+                    one()
+            us = event_time_us(g.replay, 20, 3) / reps
+            res[name] = {"us_per_image_fwd_bwd": us, "shapes_per_s": 1e6 / us, "pre_scale": scale,
+                         "grad_depth_absmax": float(d.grad.abs().max()),
+                         "GBs_algorithmic": (nbytes_f + nbytes_b) / us / 1e3,
+                         "frac_of_8TBs": (nbytes_f + nbytes_b) / us / 1e3 / HBM_PEAK_GBS}
+            del g
+        except Exception as e:      # pragma: no cover -- never fatal for the bench line
+            res[name] = {"error": repr(e)[:300]}
+    return res
+
+
 def m1_capture(G, dev, batches=(1, 8)):
     """BASELINE.json metric, first half: GenRe forward passes per second, 256x256 RGB -> 128^3 voxels, on one GPU.
     The reference's full model (models/genre_full_model.py:116-132: MarrNet-1, the geometric ops, the inpainting
@@ -511,10 +574,24 @@ def m1_capture(G, dev, batches=(1, 8)):
 def m1_table(cap):
     res = {"what": "GenRe full-model forward (3 networks + geometric ops), random weights, fp32, HIP-graph replay",
            "target_fwd_per_s_batch1": 50.0}
-    for n, (replay, eager, _) in cap.items():
+    # FLOPs of one forward, counted with torch.utils.flop_counter over the same call (convolutions + linears of the three
+    # networks; profiles/r05a_m1_flops.json: 102.28 GFLOP per image, 78 of them in Unet_3D, 53.7 in its 8^3-kernel
+    # ConvTranspose3d) against the dense fp32 MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s)
+    res["fp32_mfma_peak_TFLOPs"] = FP32_MFMA_PEAK_TFLOPS
+    for n, (replay, eager, inf) in cap.items():
         us = event_time_us(replay, 10, 2)
         us_eager = event_time_us(eager, 10, 2)
-        res["batch%d" % n] = {"ms_per_forward": us / 1e3, "shapes_per_s": n / us * 1e6, "eager_ms": us_eager / 1e3}
+        row = {"ms_per_forward": us / 1e3, "shapes_per_s": n / us * 1e6, "eager_ms": us_eager / 1e3}
+        try:
+            from torch.utils.flop_counter import FlopCounterMode
+            with FlopCounterMode(display=False) as fc:
+                eager()
+            row["flops_per_forward"] = int(fc.get_total_flops())
+            row["TFLOPs"] = row["flops_per_forward"] / us / 1e6
+            row["frac_fp32_mfma"] = row["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS
+        except Exception as e:      # pragma: no cover
+            row["flops_error"] = repr(e)[:200]
+        res["batch%d" % n] = row
     return res
 
 
@@ -566,9 +643,11 @@ def train_bench(dev, dist, du, world, rank, steps, which=("shapehd", "genre")):
             torch.cuda.empty_cache()
             return
         fence()
-        el = du.max_over_ranks(dist, time.perf_counter() - t0, dev)
+        mine = time.perf_counter() - t0
+        el = du.max_over_ranks(dist, mine, dev)
         res[name] = {"batch_per_gpu": batch, "ms_per_step": el * 1e3 / steps,
-                     "samples_per_s": world * batch * steps / el, "what": note}
+                     "samples_per_s": world * batch * steps / el,
+                     "per_rank_samples_per_s": [batch * steps / t for t in du.per_rank(dist, mine, dev)], "what": note}
         torch.cuda.empty_cache()
 
     to = lambda ns: type(ns)(**{k: v.to(dev) for k, v in vars(ns).items()})       # noqa: E731
@@ -666,6 +745,9 @@ def cpu_baseline(budget_s):
         if el >= budget_s or n >= 64:
             break
     res = dict(value=n / el, unit="shapes/s", cores=1, kind=backend.kind,
+               what="the configs[1] forward+backward chain on the host: pairs with `hot_path` / `hot_path_batch1` (shapes/s of the "
+                    "same chain on the GPU), NOT with the top-level `value` (the GenRe full-model forward, whose networks have "
+                    "no host leg here)",
                sample="%d depth maps fwd+bwd through the same chain in %.1f s, 1 thread" % (n, el))
     # the same chain on several host cores at once (one image per thread, intra-op threads stay at 1), so that the
     # host figure is not artificially weak; bounded to 16 threads / ~8 s
@@ -780,13 +862,16 @@ def main():
         for _ in range(args.steps):
             fn()
         fence()
-        return dist_utils.max_over_ranks(dist, time.perf_counter() - t0, dev)
+        timed_steps.last_local = time.perf_counter() - t0             # this rank's own clock (per-rank figures of the line)
+        return dist_utils.max_over_ranks(dist, timed_steps.last_local, dev)
 
     hot_elapsed = timed_steps(run)
+    hot_per_rank = dist_utils.per_rank(dist, timed_steps.last_local, dev)
     hot = {"what": "configs[1]: 256x256 depth -> cam_bp -> 128^3 voxel -> clamp(x50) -> render_spherical (calc_prob) -> 160x160 "
                    "spherical map, forward + backward, inputs resident in HBM",
            "shapes_per_s": world * B * args.steps / hot_elapsed, "ms_per_step": hot_elapsed * 1e3 / args.steps,
            "batch_per_gpu": B, "steps": args.steps, "step_launch": launch,
+           "per_rank_shapes_per_s": [B * args.steps / t for t in hot_per_rank],
            "render_spherical": "fused" if fused else "reference op sequence (grid_sample + CalcStopProb)",
            "volume_layout": "batch-minor (image index fastest)" if bm else "NCXYZ",
            "note": "on GenRe's own volume the x50 clamp blocks every voxel: the gradient through render_spherical is "
@@ -795,7 +880,7 @@ def main():
     # ---- the headline: BASELINE.json's metric -- GenRe full-model forward passes per second, batch 1 per GPU -------
     del graph_holder[:]
     torch.cuda.empty_cache()
-    cap, value, ms_per_step, m1_err = None, None, None, None
+    cap, value, ms_per_step, m1_err, m1_per_rank = None, None, None, None, None
     if not args.no_m1:
         try:
             cap = m1_capture(G, dev)
@@ -805,6 +890,7 @@ def main():
         if ok:
             el = timed_steps(cap[1][0])
             value, ms_per_step = world * 1 * args.steps / el, el * 1e3 / args.steps
+            m1_per_rank = [args.steps / t for t in dist_utils.per_rank(dist, timed_steps.last_local, dev)]
         elif m1_err is None:
             m1_err = "another rank failed to build the GenRe forward"
     if value is None:                      # --no-m1 (or the networks could not be built): the hot-path step is what was timed
@@ -824,11 +910,27 @@ def main():
             in_step = ["cam_bp_fwd_bm", "render_fwd_bm", "render_bwd_bm"]
         else:
             in_step = ["cam_bp_fwd", "render_fwd_fused", "render_bwd_fused"]
-        # the dominant hand-written kernel group: the renderer's backward where it does work (the soft volume); on GenRe's own
-        # volume its gradient is identically zero and the group only writes zeros -- then the slowest group of the step
-        dom_name = "render_bwd_bm_soft" if (bm and "render_bwd_bm_soft" in rows) else max(in_step, key=lambda k: rows[k]["us"])
+        # `roofline` = the slowest hand-written kernel group OF THE TIMED hot-path step, on the volume the step renders (round 5;
+        # the block must describe a timed region).  The renderer's backward where it does work -- the soft volume,
+        # which no timed step renders -- keeps its own block, `roofline_soft`.
+        dom_name = max(in_step, key=lambda k: rows[k]["us"])
         dom = rows[dom_name]
-        traffic, traffic_src = pmc_traffic(dom.get("pmc", []), B, dom.get("src", ("common.hpp",)))
+        traffic, traffic_src = pmc_traffic(dom.get("pmc_in_step", dom.get("pmc", [])), B, dom.get("src", ("common.hpp",)))
+
+        def roof(name, row, tr, tr_src):
+            return {"bound": "hbm", "kernel": name + " (" + row["kernels"] + ")", "achieved": row["GBs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": row["GBs"] / HBM_PEAK_GBS, "traffic": tr, "traffic_unit": "bytes/launch",
+                    "traffic_source": tr_src, "algorithmic_bytes_per_launch": row["bytes"], "avg_launch_us": row["us"]}
+        roofline = roof(dom_name, dom, traffic, traffic_src)
+        roofline["in_timed_step"] = "hot_path (batch %d per GPU, %s)" % (B, "batch-minor volume" if bm else "NCXYZ volume")
+        roofline_soft = None
+        if bm and "render_bwd_bm_soft" in rows:
+            sr = rows["render_bwd_bm_soft"]
+            st, st_src = pmc_traffic(sr.get("pmc", []), B, sr.get("src", ("common.hpp",)))
+            roofline_soft = roof("render_bwd_bm_soft", sr, st, st_src)
+            roofline_soft["in_timed_step"] = None
+            roofline_soft["note"] = ("the renderer's backward on a volume whose every sample passes the clamps; no timed step renders "
+                                     "such a volume (on GenRe's own the group writes zeros: kernels.render_bwd_bm)")
         m2_us = rows["cam_bp_fwd"]["us"] + rows["calc_prob_fwd"]["us"]
         m2_bytes = rows["cam_bp_fwd"]["bytes"] + rows["calc_prob_fwd"]["bytes"]
         b1 = batch1_graph(G, dev)
@@ -846,11 +948,8 @@ def main():
                        "batch_per_gpu": 1 if headline_is_m1 else B, "target_fwd_per_s": 50.0,
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "hot_path": hot,
-            "roofline": {"bound": "hbm", "kernel": dom_name + " (" + dom["kernels"] + ")",
-                         "achieved": dom["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["us"]},
+            "roofline": roofline,
+            "roofline_soft": roofline_soft,
             "roofline_m2": {"what": "BASELINE.json's second quantity: cam_bp fwd + calc_prob fwd, algorithmic bytes (50 593 792 "
                                     "per image) / time against 8 TB/s; target >= 0.40 at batch 1",
                             "batch1": {"frac": b1["frac"], "GBs": b1["GBs"], "us_per_image": b1["us_per_image"],
@@ -876,13 +975,19 @@ def main():
                              "batch_minor_layout_us": rows.get("chain_fwd_batch_minor", {}).get("us"),
                              "shapes_per_s": (B / rows["chain_fwd_batch_minor"]["us"] * 1e6) if "chain_fwd_batch_minor" in rows else None},
             "batch1": b1,
+            "hot_path_batch1": hot_path_batch1(G, dev),
+            "rccl_ranks": world,
+            "miopen_find_db": miopen_find_db_state(),
         }
         if not args.no_m1:
             if cap is not None:
                 try:
                     m1 = m1_table(cap)
                     m1["timed_region"] = {"steps": args.steps, "warmup": args.warmup, "ms_per_forward": ms_per_step,
-                                          "shapes_per_s": value, "note": "the bench line's `value`: barrier-bracketed, max over ranks"}
+                                          "shapes_per_s": value, "per_rank_fwd_per_s": m1_per_rank,
+                                          "note": "the bench line's `value`: barrier-bracketed, max over ranks"}
+                    m1["kernel_trace"] = ("profiles/r05a_m1_b1_kernel_stats.txt, r05a_m1_b8_kernel_stats.txt (rocprofv3 "
+                                          "--kernel-trace --stats of profiles/m1_target.py: no naive_conv_* kernel in the forward)")
                     geo = b1.get("genre_geometry_fwd_us_per_image")
                     if geo:
                         m1["geometry_us_batch1"] = geo

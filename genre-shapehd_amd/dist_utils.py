@@ -74,19 +74,36 @@ def all_agree(dist, ok, device="cpu"):
     return t.item() > 0.5
 
 
+def per_rank(dist, value, device="cpu"):
+    """[value on rank 0, value on rank 1, ...] on every rank (one all-gather of a float64 scalar): the per-rank figures that
+    bench.py prints beside the max-over-ranks one, so that a scaling record can be checked for N ranks at a glance"""
+    if dist is None:
+        return [float(value)]
+    world = dist.get_world_size()
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return [p.item() for p in parts]
+
+
 def average_float_buffers(dist, nets):
     """BatchNorm running statistics stay PER RANK during training (train.py: broadcast_buffers=False, no SyncBN -- the reference
     has neither).  A checkpoint is written by rank 0 only, so without this it would carry rank 0's statistics alone and every
-    rank would resume from them: the launcher calls this once before saving / evaluating -- floating-point buffers are
-    replaced by their mean over the ranks (integer buffers such as num_batches_tracked are identical already)."""
+    rank would resume from them: the launcher calls this once before saving / evaluating -- `running_mean` / `running_var` of
+    every batch-norm module are replaced by their mean over the ranks.  Nothing else is touched: constant buffers
+    that are identical on every rank (the renderer's `grid` / `depth_weight`, camera constants) would come back as
+    (x * world) / world, which is not exact for world sizes that are not a power of two, and integer buffers
+    (num_batches_tracked) are identical already."""
     if dist is None:
         return
     world = dist.get_world_size()
     for net in nets:
-        for b in net.buffers():
-            if b.is_floating_point():
-                dist.all_reduce(b, op=dist.ReduceOp.SUM)
-                b.div_(world)
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                for b in (m.running_mean, m.running_var):
+                    if b is not None:
+                        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+                        b.div_(world)
 
 
 def gather_batch(dist, local, total):
