@@ -94,8 +94,12 @@ def depth_to_points(abs_depth, silhou_t, k=2048, fl=418.3, cam_dist=2.2, generat
 
 def genre_train_step(net, optimizer, inputs, gt, opt, chamfer_weight=0.0, chamfer_idx=None):
     """joint fine-tuning of all three GenRe modules (--joint_train, depth_pred_with_sph_inpaint.py:114-118,
-    genre_full_model.py:117-121): the gradient of the voxel / spherical losses flows back through the spherical
-    back-projection, the inpainting net, render_spherical, cam_bp and get_abs_depth into MarrNet-1.  chamfer_weight > 0
+    genre_full_model.py:117-121).  What reaches MarrNet-1 through the geometry: the voxel loss through Unet_3D's second input
+    channel clamp(proj_depth / 50) <- cam_bp <- get_abs_depth (genre_full_model.py:126).  The other branch -- spherical
+    back-projection <- net2 <- render_spherical <- clamp(proj * 50) <- cam_bp -- trains net2 and the refiner but carries an
+    IDENTICALLY ZERO gradient into MarrNet-1, in the reference as here: the x50 clamp saturates every occupied voxel and
+    blocks every empty one (depth_pred_with_sph_inpaint.py:124; DESIGN 3.4d,
+    tests/test_gpu_models.py::test_projection_gradients_of_the_joint_step_against_the_cpu_chain).  chamfer_weight > 0
     adds a Chamfer term (toolbox/nndistance; the reference ships the op but no loss uses it) between the
     back-projected predicted depth and a ground-truth surface cloud."""
     from genre_shapehd_amd.models.genre import genre_loss, SCALE_25D

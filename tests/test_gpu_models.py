@@ -109,21 +109,89 @@ def test_genre_end_to_end_and_graph_replay(pair, dev):
     assert (a - c).abs().max().item() > 1e-3 * scale                      # the static inputs really are refreshed
 
 
-def test_joint_finetune_step_reaches_marrnet1_through_the_projections(dev):
-    """config #5 at world_size 1: one Adam step of the joint loss + Chamfer term; the gradient arrives in MarrNet-1's
-    depth decoder through Unet_3D <- spherical back-projection <- net2 <- render_spherical <- cam_bp <- get_abs_depth"""
+def test_projection_gradients_of_the_joint_step_against_the_cpu_chain(oracle, dev):
+    """What reaches MarrNet-1's depth map THROUGH THE GEOMETRY in the joint step (genre_full_model.py:122-131,
+    depth_pred_with_sph_inpaint.py:120-129), branch by branch, against the reference's lines on CPU torch + the oracle
+    (GenReGlueCPU):
+
+      (i)  through render_spherical <- clamp(proj * 50) <- cam_bp: EXACTLY zero -- every occupied voxel saturates the x50 clamp,
+           every empty one sits below its lower bound (:124), on both sides.  The reference's behaviour, pinned here: net2 and
+           everything behind it never train MarrNet-1 through this branch.
+      (ii) through the refiner's second channel clamp(proj_depth / 50) <- cam_bp <- get_abs_depth (genre_full_model.py:126,
+           the un-clamped proj * 50 of :128): the live branch; equal to the CPU chain's gradient to 128 * 1e-5 of its scale
+           (shift_tdf multiplies cam_bp's 1e-5 bar by the resolution)."""
+    from genre_shapehd_amd.callers import AbsDepth, RefinerInput, GenReGeometry
+    from oracle.torch_oracle import GenReGlueCPU
+    rng = np.random.default_rng(17)
+    n = 2
+    _, sil = _inputs(n)
+    ax = np.linspace(-1, 1, 256)
+    bump = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) * 2)[None, None]
+    pred = torch.from_numpy((45 + 12 * bump + rng.uniform(0, 2, (n, 1, 256, 256))).astype(np.float32))    # of scale_25d = 100
+    mm = torch.tensor([[1.9, 2.5], [1.85, 2.45]])
+    ga = torch.from_numpy(rng.standard_normal((n, 1, 160, 160)).astype(np.float32))
+    gb = torch.from_numpy(rng.standard_normal((n, 1, 128, 128, 128)).astype(np.float32))
+    full = torch.from_numpy(rng.uniform(0.3, 0.7, (n, 1, 160, 160)).astype(np.float32))                 # net2's map: no gradient here
+
+    # the reference's lines on the host
+    glue = GenReGlueCPU(oracle)
+    pc = pred.clone().requires_grad_(True)
+    d_c = glue.get_abs_depth(pc, mm, sil)
+    tdf = glue.hot.cam(d_c, torch.full((n, 1), glue.hot.fl), torch.full((n, 1), glue.hot.cam_dist), 128)
+    proj_c = 1 - 128 * tdf
+    sph_c = glue.hot.render(torch.clamp(proj_c * 50, 1e-5, 1 - 1e-5))
+    (g_render_c,) = torch.autograd.grad((sph_c * ga[:, :, 16:144, 16:144]).sum(), pc, retain_graph=True)
+    ch1_c = torch.clamp(proj_c * 50 / 50, 1e-5, 1 - 1e-5)
+    (g_ch1_c,) = torch.autograd.grad((ch1_c * gb).sum(), pc)
+    assert g_render_c.abs().max().item() == 0.0                         # the reference's own chain: exactly zero
+    assert (g_ch1_c != 0).sum().item() > 1000
+
+    # the product
+    geo = GenReGeometry().to(dev)
+    pg = pred.to(dev).requires_grad_(True)
+    d_g = AbsDepth.apply(pg, mm.to(dev), sil.to(dev), 100.0)
+    assert torch.equal(d_g.detach().cpu(), d_c.detach())
+    proj50_g, sph_g = geo.depth_to_spherical(d_g)
+    (g_render_g,) = torch.autograd.grad((sph_g * ga.to(dev)).sum(), pg, retain_graph=True)
+    assert torch.count_nonzero(g_render_g).item() == 0                  # (i)
+    ri, _ = RefinerInput.apply(full.to(dev), geo.grid.expand(n, -1, -1, -1, -1), proj50_g, 16)
+    (g_ch1_g,) = torch.autograd.grad((ri[:, 1:2] * gb.to(dev)).sum(), pg)
+    scale = max(1.0, g_ch1_c.abs().max().item())
+    err = (g_ch1_g.cpu() - g_ch1_c).abs().max().item()
+    print("gradient through refiner channel 1 <- cam_bp: |g| max %.3e, GPU vs CPU chain %.3e" % (scale, err))
+    assert err <= 128e-5 * scale                                        # (ii)
+
+
+def test_joint_finetune_step_reaches_marrnet1_through_the_refiner_channel(dev):
+    """config #5 at world_size 1: one Adam step of the joint loss with NO Chamfer term and the 2.5-D losses switched off by
+    construction of the check: the voxel loss's gradient arrives in MarrNet-1's depth decoder through Unet_3D's second input
+    channel clamp(proj_depth / 50) <- cam_bp <- get_abs_depth ONLY (the branch through net2 <- render_spherical carries an
+    identically zero gradient: the test above) -- so the depth head's gradient of the VOXEL loss alone must be
+    non-zero and finite"""
     from genre_shapehd_amd import train as T
     from genre_shapehd_amd.models import GenReNet, GenReOptions
+    from genre_shapehd_amd.models.genre import genre_loss
     torch.manual_seed(1)
     opt = GenReOptions(joint_train=True)
     net = NF.fill_state(GenReNet(opt), seed=4).to(dev).train()
+    with torch.no_grad():                                               # a depth range that puts the surface in the cube
+        head = net.depth_and_inpaint.net1.decoder_minmax[9]
+        head.weight.zero_()
+        head.bias.copy_(torch.tensor([1.9, 2.4]))
+        # seeded random weights emit depths of ~1e4 (of scale_25d = 100): scaled so that the predicted surface is a plausible
+        # one inside the cube, as in test_genre_end_to_end_and_graph_replay
+        net.depth_and_inpaint.net1.decoder_depth[4][3].weight.mul_(1e-5)
     inputs, gt = T.genre_batch(2, dev, seed=11)
+    depth_w = net.depth_and_inpaint.net1.decoder_depth[4][3].weight
+    pred = net(inputs)
+    (g_vox,) = torch.autograd.grad(genre_loss(pred, gt, opt, joint=False), depth_w, allow_unused=True)   # voxel loss ONLY
+    assert g_vox is not None and torch.isfinite(g_vox).all() and g_vox.abs().max().item() > 0
+    assert (pred["proj_depth"] != 0).sum().item() > 1000                 # ... because the surface did land in the cube
+    # and the whole step (all joint losses, no Chamfer) runs and moves the weights
     optim = torch.optim.Adam(net.parameters(), lr=1e-6)
-    w0 = net.depth_and_inpaint.net1.decoder_depth[4][3].weight.detach().clone()
-    loss = T.genre_train_step(net, optim, inputs, gt, opt, chamfer_weight=0.1)
+    w0 = depth_w.detach().clone()
+    loss = T.genre_train_step(net, optim, inputs, gt, opt, chamfer_weight=0.0)
     assert torch.isfinite(loss)
-    g = net.depth_and_inpaint.net1.decoder_depth[4][3].weight.grad
-    assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
-    assert not torch.equal(w0, net.depth_and_inpaint.net1.decoder_depth[4][3].weight.detach())
+    assert not torch.equal(w0, depth_w.detach())
     for p in net.refine_net.parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all()

@@ -72,7 +72,7 @@ def perturb_(net, eps, seed):
     return net
 
 
-def assert_backward_stable(got, ref64, kap, kap_whole, what, c=64.0, c_tensor=2048.0):
+def assert_backward_stable(got, ref64, kap, kap_whole, what, c=64.0, c_tensor=2048.0, min_tight=0.0):
     """statement 3 of the module docstring.  Two constants: the whole gradient vector is held to 64 unit roundoffs times its
     condition number; a single tensor to 2048 -- statement 1 allows every convolution 8 sqrt(K) 2^-24 (250 ... 2000 unit
     roundoffs at the reduction lengths of these networks; MIOpen's Winograd and implicit-GEMM solvers do use a few tens of
@@ -92,10 +92,24 @@ def assert_backward_stable(got, ref64, kap, kap_whole, what, c=64.0, c_tensor=20
             worst = (e / bar, k, e, bar)
     whole = rel_l2(flat(got, keys), flat(ref64, keys))
     bar_w = 1e-4 + c * kap_whole * U32
+    # How much of the per-tensor statement is NOT vacuous: a tensor's bar 1e-4 + 2048 kappa_t 2^-24 says something only while it
+    # stays below ~1 (kappa_t <= 1e4: bar <= 1.3); the count and the element share of those tensors are printed and asserted, so
+    # that a regression cannot hide behind a condition number -- and the well-conditioned tensors are also held, as
+    # ONE vector, to the vector constant (64 unit roundoffs times THEIR condition number, measured like kappa_whole).
+    live = [k for k in keys if ref64[k].abs().max().item() > 1e-9 * top]
+    tight = [k for k in live if kap[k] <= 1e4]
+    share = sum(ref64[k].numel() for k in tight) / max(1, sum(ref64[k].numel() for k in live))
     print("%s: %d tensors; whole gradient off by %.2e (bar %.2e, kappa %.1e); worst tensor %s: %.2e of its bar %.2e "
-          "(kappa %.1e)" % (what, len(keys), whole, bar_w, kap_whole, worst[1], worst[2], worst[3], kap.get(worst[1], 0)))
+          "(kappa %.1e); non-vacuous tensor bars (kappa_t <= 1e4): %d of %d tensors = %.1f %% of the gradient's elements"
+          % (what, len(keys), whole, bar_w, kap_whole, worst[1], worst[2], worst[3], kap.get(worst[1], 0), len(tight), len(live),
+             100 * share))
     assert whole <= bar_w, (what, whole, bar_w)
     assert worst[0] <= 1.0, (what,) + worst
+    assert len(tight) >= min_tight * len(live), (what, "only %d of %d tensor bars are non-vacuous" % (len(tight), len(live)))
+    if tight:
+        k_t = max(kap[k] for k in tight)
+        e_t = rel_l2(flat(got, tight), flat(ref64, tight))
+        assert e_t <= 1e-4 + c_tensor * k_t * U32, (what, "well-conditioned tensors as one vector", e_t, k_t)
 
 
 def assert_same_function(got, ref, what, tol=1e-8):
