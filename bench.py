@@ -242,19 +242,36 @@ def kernel_table(G, dev, B):
         vbuf = torch.empty((B * 128 * 128 * mod.z_res,), device=dev)
         scratch = torch.empty((vbuf.numel() + max(4, B),), device=dev)
         proj = 1 - 128 * tdf
+        live = torch.empty((B * (1 + 512),), dtype=torch.int32, device=dev)      # the clamp's pass words (ABI 4): what autograd passes
         t = event_time_us(lambda: render_lib.render_spherical_forward(
-            proj, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0), iters, 5)
+            proj, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0, live), iters, 5)
         rows["render_fwd_fused"] = dict(us=t, bytes=B * BYTES_RENDER_FUSED,
                                         kernels="render_sample_brick_group_kernel+render_scan_fwd_kernel",
-                                        pmc=["render_sample_brick_group_kernel<2, 512>", "render_scan_fwd_kernel"],
+                                        pmc=["render_sample_brick_group_kernel<2, 512>@genre", "render_scan_fwd_kernel@genre"],
                                         src=("common.hpp", "wave_scan.hpp", "sph_render.hip"))
-        t = event_time_us(lambda: render_lib.render_spherical_backward(
-            proj, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"], vbuf, T["kin"], 50.0),
-            iters, 5)
-        rows["render_bwd_fused"] = dict(us=t, bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                                        kernels="render_scan_bwd_kernel+zero_shared_bricks_kernel+render_bwd_brick_kernel",
-                                        pmc=["render_scan_bwd_kernel", "zero_shared_bricks_kernel", "render_bwd_brick_kernel"],
-                                        src=("common.hpp", "wave_scan.hpp", "sph_render.hip"))
+        bwd_pmc = ["render_scan_bwd_kernel", "zero_shared_bricks_kernel", "render_bwd_brick_kernel"]       # + the phase of profiles/pmc_targets.py
+
+        def std_bwd(vol, lv):
+            render_lib.render_spherical_backward(vol, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"],
+                                                 T["bwd_chunks"], vbuf, T["kin"], 50.0, lv)
+        # GenRe's own volume: the clamp blocks every voxel, the group writes grad_vox = 0 (billed with the bytes it moves) ...
+        rows["render_bwd_fused"] = dict(us=event_time_us(lambda: std_bwd(proj, live), iters, 5), bytes=B * 128 ** 3 * 4,
+                                        kernels="render_scan_bwd_kernel+zero_shared_bricks_kernel+render_bwd_brick_kernel on GenRe's "
+                                                "volume (clamp blocks every voxel: writes zeros)",
+                                        pmc=[k + "@genre" for k in bwd_pmc], src=("common.hpp", "wave_scan.hpp", "sph_render.hip"))
+        # ... and the same kernels where they do work: the soft volume (every sample passes the clamps)
+        gs = torch.Generator(device="cpu").manual_seed(1)
+        soft = ((torch.rand(proj.shape, generator=gs) * 0.9 + 0.05) * 0.02).to(dev)
+        render_lib.render_spherical_forward(soft, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"],
+                                            50.0, live)
+        rows["render_bwd_fused_soft"] = dict(us=event_time_us(lambda: std_bwd(soft, live), iters, 5),
+                                             bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
+                                             kernels="render_scan_bwd_kernel+zero_shared_bricks_kernel+render_bwd_brick_kernel on "
+                                                     "the soft volume (gradient everywhere)",
+                                             pmc=[k + "@soft" for k in bwd_pmc], src=("common.hpp", "wave_scan.hpp", "sph_render.hip"))
+        del soft
+        render_lib.render_spherical_forward(proj, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"],
+                                            50.0, live)
         if B >= 16:     # batch-minor tile renderer (csrc/sph_render_bm.hip): the volume with the image index fastest
             layer = G.Camera_back_projection_layer(batch_minor=True).to(dev)
             with torch.no_grad():
@@ -271,7 +288,7 @@ def kernel_table(G, dev, B):
             TB = _fused_render.bm_tables_for(proj_bm.shape, dev, mod._dirs64, mod.depth_weight)
             groups = -(-B // 32)
             ps = torch.empty((groups * TB["segs"].shape[0] * 64,), device=dev)
-            tr = torch.empty((ps.numel() + 64,), device=dev)          # + the gather kernel's row counters (one per group)
+            tr = torch.empty((ps.numel(),), device=dev)
             stash = torch.empty((groups * TB["rec_f"].shape[0] * 32,), device=dev)
             mask = torch.empty((groups * 128 ** 3 + groups,), dtype=torch.int32, device=dev)
             out_p = torch.empty((B, 1, 160, 160), device=dev)
@@ -284,7 +301,7 @@ def kernel_table(G, dev, B):
                                              mask if save else None, 50.0)
             rows["render_fwd_bm"] = dict(us=event_time_us(lambda: bm_fwd(True), iters, 5), bytes=B * BYTES_RENDER_FUSED,
                                          kernels="bm_sample_kernel+bm_combine_fwd_kernel",
-                                         pmc=["bm_sample_kernel<true, true, 1024>", "bm_combine_fwd_kernel"],
+                                         pmc=["bm_sample_kernel<true, true, 1024>@genre", "bm_combine_fwd_kernel@genre"],
                                          src=("common.hpp", "sph_render_bm.hip"))
             rows["render_fwd_bm_nosave"] = dict(us=event_time_us(lambda: bm_fwd(False), iters, 5),
                                                 bytes=B * BYTES_RENDER_FUSED, kernels="bm_sample_kernel (no saved state)")
@@ -293,10 +310,6 @@ def kernel_table(G, dev, B):
                                               TB["ent"], TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, tr, stash,
                                               mask, 50.0, TB["pull_code"])
 
-            def bm_bwd_gather():
-                render_lib.render_bm_backward_gather(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"],
-                                                     TB["ray_pre"], TB["g_ent"], TB["g_chunks"], TB["g_blob"],
-                                                     TB["g_rows"], mod.depth_weight, ps, tr, stash, mask, 50.0)
             # The same kernels on a volume whose every sample passes the clamps (`soft`: uniform(0.05, 0.95) / 50 under
             # pre_scale 50 -- the instantiation the step runs, with a gradient everywhere).  On GenRe's own volume the clamp
             # blocks every voxel (saturated or empty, depth_pred_with_sph_inpaint.py:124), the backward is identically zero
@@ -308,33 +321,30 @@ def kernel_table(G, dev, B):
             def bm_fwd_soft():
                 render_lib.render_bm_forward(soft_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"],
                                              TB["ray_seg"], TB["ray_pre"], ps, stash, mask, 50.0)
-            gather = "g_ent" in TB and _fused_render.bm_backward_mode() == "gather"     # what the step's autograd runs
+            bm_bwd_pmc = ["bm_combine_bwd_kernel", "bm_zero_shared_kernel<4, 8, 8>", "bm_scatter_kernel<true, 4, 8, 8, 768>"]
             rows["render_bwd_bm"] = dict(
-                us=event_time_us(bm_bwd_gather if gather else bm_bwd_scatter, iters, 5),
+                us=event_time_us(bm_bwd_scatter, iters, 5),
                 bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+" + ("bm_gather_kernel" if gather else "bm_scatter_kernel"),
-                pmc=["bm_combine_bwd_kernel", "bm_zero_shared_kernel<4, 8, 8>",
-                     "bm_gather_kernel<true>" if gather else "bm_scatter_kernel<true, 4, 8, 8, 768, false>"],
+                kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+bm_scatter_kernel",
+                pmc=[k + "@genre" for k in bm_bwd_pmc],
                 src=("common.hpp", "sph_render_bm.hip"))
             bm_fwd(True)                                            # (the saved state of the GenRe volume again)
-            rows["render_bwd_bm"]["us"] = event_time_us(bm_bwd_gather if gather else bm_bwd_scatter, iters, 5)
+            rows["render_bwd_bm"]["us"] = event_time_us(bm_bwd_scatter, iters, 5)
             # on GenRe's own volume the clamp blocks every voxel: the group reads B group words and writes grad_vox = 0 --
             # it is billed with the bytes it MOVES there, not with the algorithmic bytes of a backward it does not compute
             rows["render_bwd_bm"]["bytes"] = B * 128 ** 3 * 4
             rows["render_bwd_bm"]["kernels"] += " on GenRe's volume (clamp blocks every voxel: writes zeros)"
             rows["render_fwd_bm_soft"] = dict(us=event_time_us(bm_fwd_soft, iters, 5), bytes=B * BYTES_RENDER_FUSED,
-                                              kernels="bm_sample_kernel+bm_combine_fwd_kernel (soft volume)")
+                                              kernels="bm_sample_kernel+bm_combine_fwd_kernel (soft volume)",
+                                              pmc=["bm_sample_kernel<true, true, 1024>@soft", "bm_combine_fwd_kernel@soft"],
+                                              src=("common.hpp", "sph_render_bm.hip"))
             bm_fwd_soft()
             rows["render_bwd_bm_soft"] = dict(
-                us=event_time_us(bm_bwd_gather if gather else bm_bwd_scatter, iters, 5),
+                us=event_time_us(bm_bwd_scatter, iters, 5),
                 bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                kernels=rows["render_bwd_bm"]["kernels"] + " on the soft volume (gradient everywhere)",
-                pmc=rows["render_bwd_bm"]["pmc"], src=("common.hpp", "sph_render_bm.hip"))
+                kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+bm_scatter_kernel on the soft volume (gradient everywhere)",
+                pmc=[k + "@soft" for k in bm_bwd_pmc], src=("common.hpp", "sph_render_bm.hip"))
             bm_fwd(True)
-            if gather:      # the scatter form (LDS atomics), for comparison
-                rows["render_bwd_bm_scatter"] = dict(us=event_time_us(bm_bwd_scatter, iters, 5),
-                                                     bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                                                     kernels="bm_combine_bwd_kernel+bm_zero_shared_kernel+bm_scatter_kernel")
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3
     # forward-only chain (inference) at this batch size, standard layout and batch-minor layout

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgenre_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 _MAX_DIMS = 5
 _F32, _I32 = 0, 1
 
@@ -40,7 +40,6 @@ def _load():
     T, V = C.POINTER(GenreTensor), C.c_void_p
     scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float],
                "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float, C.c_int],
-               "genre_render_bm_backward_gather": [C.c_float], "genre_render_bm_backward_halo": [C.c_float],
                "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float],
                "genre_back_projection_forward_const": [C.c_float, C.c_float, C.c_int]}
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
@@ -51,9 +50,8 @@ def _load():
                         ("genre_spherical_back_proj_backward_shifted", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
-                        ("genre_render_spherical_forward", 8), ("genre_render_spherical_backward", 10),
+                        ("genre_render_spherical_forward", 9), ("genre_render_spherical_backward", 11),
                         ("genre_render_bm_forward", 11), ("genre_render_bm_backward", 14),
-                        ("genre_render_bm_backward_gather", 15), ("genre_render_bm_backward_halo", 15),
                         ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4),
                         ("genre_nnd_forward_host", 6), ("genre_nnd_backward_host", 8)):
         fn = getattr(lib, name, None)
@@ -198,20 +196,22 @@ class _RenderLib:
 
     @staticmethod
     def render_spherical_forward(vox, dirs64_as_f32, depth_weight, out,
-                                 v_scratch=None, fwd_table=None, fwd_chunks=None, kin=None, pre_scale=0.0):
+                                 v_scratch=None, fwd_table=None, fwd_chunks=None, kin=None, pre_scale=0.0, live=None):
         """with the four optional tensors: LDS-staged brick sampling + scan (v_scratch receives the raw
-        sample values); without: one wave-per-ray gather kernel"""
+        sample values); without: one wave-per-ray gather kernel.  live (int32 [N*NC*(1 + bricks)], with pre_scale): receives
+        the clamp's pass words per image and per 16^3 brick for the backward"""
         return _call("genre_render_spherical_forward", vox, dirs64_as_f32, depth_weight, out,
-                     v_scratch, fwd_table, fwd_chunks, kin, scalars=(C.c_float(pre_scale),))
+                     v_scratch, fwd_table, fwd_chunks, kin, live, scalars=(C.c_float(pre_scale),))
 
     @staticmethod
     def render_spherical_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
                                   dp_scratch=None, brick_table=None, chunk_list=None, v_scratch=None, kin=None,
-                                  pre_scale=0.0):
+                                  pre_scale=0.0, live=None):
         """dp_scratch/brick_table/chunk_list given: brick-owned backward (no global atomics), re-using the
-        forward's v_scratch when it is passed too; without: global-atomic scatter fallback"""
+        forward's v_scratch when it is passed too; without: global-atomic scatter fallback.  live: the forward's pass words --
+        what the pre_scale clamp blocks is written as zeros without being computed"""
         return _call("genre_render_spherical_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                     dp_scratch, brick_table, chunk_list, v_scratch, kin, scalars=(C.c_float(pre_scale),))
+                     dp_scratch, brick_table, chunk_list, v_scratch, kin, live, scalars=(C.c_float(pre_scale),))
 
 
     @staticmethod
@@ -229,24 +229,6 @@ class _RenderLib:
                      rec_b, bwd_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask,
                      scalars=(C.c_float(pre_scale), C.c_int(pull_brick)))
 
-
-    @staticmethod
-    def render_bm_backward_gather(grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, g_ent, g_chunks, g_blob,
-                                  g_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask=None, pre_scale=0.0):
-        """the backward in gather form (voxel sums in registers, per-voxel contribution lists; no LDS atomics)"""
-        return _call("genre_render_bm_backward_gather", grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32,
-                     g_ent, g_chunks, g_blob, g_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask,
-                     scalars=(C.c_float(pre_scale),))
-
-
-    @staticmethod
-    def render_bm_backward_halo(grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, h_ent, rec_f, h_rows,
-                                depth_weight, ps_scratch, tr_scratch, p_stash, mask, halo_scratch, pre_scale=0.0):
-        """the backward in halo form (every brick scatters its own segments into a tile with halo; a second kernel adds the
-        neighbours' halo lines): halo_scratch fp32 [groups * bricks * 149 * 32]"""
-        return _call("genre_render_bm_backward_halo", grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32,
-                     h_ent, rec_f, h_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask, halo_scratch,
-                     scalars=(C.c_float(pre_scale),))
 
 
 class _GlueLib:

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
                                                                         const double *__restrict__ dirs,
                                                                         const int *__restrict__ fwd_table,
                                                                         const int *__restrict__ fwd_list,
-                                                                        float *__restrict__ vbuf, int imgs)
+                                                                        float *__restrict__ vbuf, int imgs,
+                                                                        int *__restrict__ live)
 {
     extern __shared__ float gtile[];                                     // [G][kTile3]
     // (placing all rows of an image group on one XCD, as render_bwd_brick_kernel does, made THIS kernel 6 % slower)
@@ -448,13 +449,16 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
     const int lz0 = (int)threadIdx.x % kTile, ly0 = ((int)threadIdx.x / kTile) % kTile,
               lx0 = (int)threadIdx.x / (kTile * kTile);
     const int step = kSX * D.sx + kSY * D.sy + kSZ * D.sz, wrap_z = D.sy - kTile * D.sz, wrap_y = D.sx - kTile * D.sy;
+    int pass_g[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) pass_g[g] = 0;
 #pragma unroll
     for (int g = 0; g < G; g++) {
         if (g >= ng) break;
         const int img = img0 + g;
         const float *__restrict__ base = vox.p + (img / D.NC) * vox.s0 + (img % D.NC) * vox.s1;
         float vals[kPer];
-        unsigned inside = 0;
+        unsigned inside = 0, own = 0;                                    // own: a voxel of the brick itself (not its halo)
         int lz = lz0, ly = ly0, x = ox + lx0, y = oy + ly0, z = oz + lz0;
         int off = x * D.sx + y * D.sy + z * D.sz;
 #pragma unroll
@@ -467,19 +471,44 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
             if ((int)threadIdx.x + i * NT < kTile3 && x > ox && y > oy && z > oz && x < D.X && y < D.Y && z < D.Z) {
                 vals[i] = base[off];
                 inside |= 1u << i;
+                if (x <= ox + kBrick && y <= oy + kBrick && z <= oz + kBrick) own |= 1u << i;
             }
             lz += kSZ; z += kSZ; ly += kSY; y += kSY; x += kSX; off += step;
             if (lz >= kTile) { lz -= kTile; z -= kTile; ly += 1; y += 1; off += wrap_z; }
             if (ly >= kTile) { ly -= kTile; y -= kTile; x += 1; off += wrap_y; }
         }
+        int passes = 0;                                                  // some voxel of the BRICK passes the pre_scale clamp
 #pragma unroll
         for (int i = 0; i < kPer; i++) {
-            if (D.pre_scale != 0.0f && (inside & (1u << i)))             // depth_pred_with_sph_inpaint.py:124
-                vals[i] = fminf(fmaxf(vals[i] * D.pre_scale, D.lo), D.hi);
+            if (D.pre_scale != 0.0f && (inside & (1u << i))) {           // depth_pred_with_sph_inpaint.py:124
+                const float raw = vals[i] * D.pre_scale;
+                vals[i] = fminf(fmaxf(raw, D.lo), D.hi);
+                passes |= (vals[i] == raw && (own & (1u << i))) ? 1 : 0;  // lo <= raw <= hi: the clamp passes the gradient
+            }
             if ((int)threadIdx.x + i * NT < kTile3) gtile[g * kTile3 + threadIdx.x + i * NT] = vals[i];
         }
+        pass_g[g] = passes;
     }
-    __syncthreads();
+    // WHAT THE CLAMP BLOCKS IS NOT COMPUTED (round 5; the batch-minor renderer's 3.4d for this layout).  With pre_scale the
+    // backward multiplies every voxel's sum by its clamp mask.  live[img][0] = "some voxel of this image passes",
+    // live[img][1 + brick] = "some voxel of this brick passes" (cleared by the host entry in front of this launch; every writer
+    // stores the same 1): render_scan_bwd_kernel returns at once for a dead image, render_bwd_brick_kernel writes zeros for a
+    // dead brick.  On GenRe's own chain -- clamp(proj * 50) of proj = 1 - 128 tdf, depth_pred_with_sph_inpaint.py:124: occupied
+    // voxels saturate, empty ones sit below the lower bound -- that is every brick of every image.
+    if (live != nullptr) {
+        const int nbricks = ((D.X + kBrick - 1) / kBrick) * nby * nbz;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int any = __syncthreads_or(g < ng ? pass_g[g] : 0);
+            if (threadIdx.x == 0 && g < ng && any) {
+                int *lv = live + (int64_t)(img0 + g) * (nbricks + 1);
+                lv[0] = 1;
+                lv[1 + brick] = 1;
+            }
+        }
+    } else {
+        __syncthreads();
+    }
     const int64_t img_stride = (int64_t)D.R * D.R * D.ZR;
     float *__restrict__ v0 = vbuf + (int64_t)img0 * img_stride;
     constexpr int kFwdInFlight = 2;
@@ -525,14 +554,14 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
 template <int G, int NT>
 int launch_sample_group(const char *op, const RenderDims &D, const genre_tensor *vox, const genre_tensor *dirs,
                         const genre_tensor *fwd_table, const genre_tensor *fwd_chunks, const genre_tensor *v_scratch,
-                        int rows, int imgs, hipStream_t st)
+                        int rows, int imgs, int *live, hipStream_t st)
 {
     constexpr size_t lds = (size_t)G * kTile3 * sizeof(float);
     static std::atomic<uint64_t> done{0};
     if (!reserve_lds(op, reinterpret_cast<const void *>(&render_sample_brick_group_kernel<G, NT>), lds, done)) return 0;
     render_sample_brick_group_kernel<G, NT><<<dim3(rows, (imgs + G - 1) / G), NT, lds, st>>>(
         D, view5(vox), (const double *)dirs->data, (const int *)fwd_table->data, (const int *)fwd_chunks->data,
-        (float *)v_scratch->data, imgs);
+        (float *)v_scratch->data, imgs, live);
     return 1;
 }
 
@@ -596,10 +625,14 @@ __global__ __launch_bounds__(kBlock) void render_scan_bwd_kernel(RenderDims D, c
                                                                   const int *__restrict__ kin,
                                                                   const float *__restrict__ dw, View4 gout,
                                                                   float *__restrict__ dpbuf,
-                                                                  unsigned *__restrict__ dpmax_bits)
+                                                                  unsigned *__restrict__ dpmax_bits,
+                                                                  const int *__restrict__ live, int live_stride)
 {
     const int lane = threadIdx.x & 63, kb = lane * 4;
     const int rr = D.R * D.R, img = blockIdx.y;
+    // no voxel of this image passes the pre_scale clamp (forward's live word): its grad_vox is identically zero, nothing reads
+    // its dL/dp (render_bwd_brick_kernel writes the zeros without looking at the list)
+    if (live != nullptr && live[(int64_t)img * live_stride] == 0) return;
     const int w0 = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = gridDim.x * kWavesPerBlock;
     const float *__restrict__ vimg = vbuf + (int64_t)img * rr * D.ZR;
@@ -653,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                                                                    const int *__restrict__ brick_table,
                                                                    const int *__restrict__ chunk_list,
                                                                    const unsigned *__restrict__ dpmax_bits, View5 vox,
-                                                                   View5 gvox)
+                                                                   View5 gvox, const int *__restrict__ live)
 {
     __shared__ unsigned long long tile[kBrick * kBrick * kBrick];
     // XCD-aware order: workgroups go to the 8 XCDs round-robin by linear id; when the image count allows it, all rows
@@ -666,6 +699,29 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
         const int xcd = lin & 7, idx = lin >> 3;
         img = xcd + 8 * (idx / n_row);
         trow = idx % n_row;
+    }
+    if (live != nullptr) {
+        // the clamp blocks every voxel of this brick (or of the whole image): its gradient is zero whatever arrives from above
+        // (the clamp adjoint is a select -- not even a NaN survives it, as in the batch-minor renderer): stream the zeros, or
+        // nothing at all where zero_shared_bricks_kernel already wrote them, before any list word is read
+        const int brick_e = brick_table[trow * 4 + 0];
+        const int nby_e = (D.Y + kBrick - 1) / kBrick, nbz_e = (D.Z + kBrick - 1) / kBrick;
+        const int nbricks = ((D.X + kBrick - 1) / kBrick) * nby_e * nbz_e;
+        const int *lv = live + (int64_t)img * (nbricks + 1);
+        if (lv[0] == 0 || lv[1 + brick_e] == 0) {
+            if (brick_table[trow * 4 + 3] == 0) {
+                const int oxe = (brick_e / (nby_e * nbz_e)) * kBrick, oye = ((brick_e / nbz_e) % nby_e) * kBrick,
+                          oze = (brick_e % nbz_e) * kBrick;
+                float *gb = gvox.p + (img / D.NC) * gvox.s0 + (img % D.NC) * gvox.s1;
+                const int y = oye + (int)threadIdx.x / kBrick, z = oze + (int)threadIdx.x % kBrick;
+                if (y < D.Y && z < D.Z) {
+#pragma unroll
+                    for (int i = 0; i < kBrick * kBrick * kBrick / kBlock; i++)
+                        if (oxe + i < D.X) gb[(oxe + i) * gvox.s2 + y * gvox.s3 + z * gvox.s4] = 0.f;
+                }
+            }
+            return;
+        }
     }
     // fixed-point scale 2^(44-e), 2^e >= THIS image's max|dL/dp| (see file header); max == 0 -> everything is 0.  Per
     // image, so that an image whose upstream gradient is many orders of magnitude below its neighbours' keeps all 44 bits.
@@ -904,7 +960,7 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
                                               const genre_tensor *depth_weight, const genre_tensor *out,
                                               const genre_tensor *v_scratch, const genre_tensor *fwd_table,
                                               const genre_tensor *fwd_chunks, const genre_tensor *kin,
-                                              float pre_scale, void *stream)
+                                              const genre_tensor *live, float pre_scale, void *stream)
 {
     const char *op = "render_spherical_forward";
     RenderDims D{};
@@ -925,11 +981,20 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
         GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R,
                       "%s: kin must be int32 [R*R]", op);
         const int imgs = D.N * D.NC;
+        int *live_p = nullptr;
+        if (live != nullptr && pre_scale != 0.0f) {      // the clamp's pass words of the backward (file header; ABI 4)
+            const int64_t nb = (int64_t)((D.X + kBrick - 1) / kBrick) * ((D.Y + kBrick - 1) / kBrick) * ((D.Z + kBrick - 1) / kBrick);
+            GENRE_REQUIRE(is_i32(live, 1) && is_contiguous(live) && live->size[0] >= (int64_t)imgs * (nb + 1),
+                          "%s: live must be int32 [N*NC*(1 + bricks)] = [%lld]", op, (long long)(imgs * (nb + 1)));
+            live_p = (int *)live->data;
+            GENRE_REQUIRE(hipMemsetAsync(live_p, 0, (size_t)imgs * (nb + 1) * 4, st) == hipSuccess,
+                          "%s: hipMemsetAsync of the live words failed", op);
+        }
         // batches: kGroup images share one walk over the sample list; a lone image gets the same kernel with G = 1
         // (512 threads per workgroup: 38.9 us for the batch-1 forward chain against 42.1 with 256, 42.2 with 1024)
         const int ok = imgs >= 2
-            ? launch_sample_group<kGroup, kGroupBlock>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, st)
-            : launch_sample_group<1, 512>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, st);
+            ? launch_sample_group<kGroup, kGroupBlock>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, live_p, st)
+            : launch_sample_group<1, 512>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, live_p, st);
         if (!ok) return 0;
         GENRE_LAUNCH_CHECK("render_spherical forward (bricks)");
         // (LDS-transposed per-lane serial scans for this layout -- 64 rays per wave, 16-sample tiles -- measured 136 us
@@ -952,7 +1017,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                                                const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
                                                const genre_tensor *brick_table, const genre_tensor *chunk_list,
                                                const genre_tensor *v_scratch, const genre_tensor *kin,
-                                               float pre_scale, void *stream)
+                                               const genre_tensor *live, float pre_scale, void *stream)
 {
     const char *op = "render_spherical_backward";
     RenderDims D{};
@@ -975,6 +1040,12 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                           aligned16(dp_scratch->data),
                       "%s: dp_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR + N*NC elements", op);
         unsigned *dpmax = (unsigned *)dp_scratch->data + rays * D.ZR;       // per-image max|dL/dp| behind the samples
+        const int *live_p = nullptr;                                        // the forward's clamp pass words (pre_scale only)
+        if (live != nullptr && pre_scale != 0.0f && v_scratch && kin) {
+            GENRE_REQUIRE(is_i32(live, 1) && is_contiguous(live) && live->size[0] >= (int64_t)imgs * (nb + 1),
+                          "%s: live must be the forward's int32 [N*NC*(1 + bricks)] buffer", op);
+            live_p = (const int *)live->data;
+        }
         if (hipMemsetAsync(dpmax, 0, (size_t)imgs * 4, st) != hipSuccess) return fail("%s: hipMemsetAsync failed", op);
         if (rays > 0 && v_scratch && kin) {          // the forward left the raw sample values: scan only
             GENRE_REQUIRE((D.ZR & 3) == 0, "%s: brick path needs ZR %% 4 == 0", op);
@@ -985,7 +1056,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                           "%s: kin must be int32 [R*R]", op);
             render_scan_bwd_kernel<<<scan_grid(D), kBlock, 0, st>>>(
                 D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data,
-                view4(grad_out), (float *)dp_scratch->data, dpmax);
+                view4(grad_out), (float *)dp_scratch->data, dpmax, live_p, nb + 1);
             GENRE_LAUNCH_CHECK("render_spherical backward (scan)");
         } else if (rays > 0) {                       // recompute the samples from vox
             GENRE_REQUIRE(D.pad == 0, "%s: the padded map layout needs the forward's v_scratch", op);
@@ -1004,7 +1075,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
         // the dL/dp gathers and the LDS atomics, not by the shared geometry arithmetic)
         render_bwd_brick_kernel<<<dim3(rows, D.N * D.NC), kBlock, 0, st>>>(
             D, (const double *)dirs->data, (const float *)dp_scratch->data, (const int *)brick_table->data,
-            (const int *)chunk_list->data, dpmax, view5(vox), view5(grad_vox));
+            (const int *)chunk_list->data, dpmax, view5(vox), view5(grad_vox), live_p);
         GENRE_LAUNCH_CHECK("render_spherical backward (bricks)");
         return 1;
     }

@@ -336,10 +336,8 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
                                                              const int *__restrict__ ray_ptr,
                                                              const int *__restrict__ ray_seg,
                                                              const double2 *__restrict__ ray_pre, View4 gout,
-                                                             float *__restrict__ tr, int *__restrict__ row_counter,
-                                                             const unsigned *__restrict__ group_any)
+                                                             float *__restrict__ tr, const unsigned *__restrict__ group_any)
 {
-    if (row_counter && blockIdx.x == 0 && threadIdx.x == 0) row_counter[blockIdx.y] = 0;   // for the gather kernel behind this one
     if (group_any && group_any[blockIdx.y] == 0u) return;              // no voxel of this group passes the clamp: nothing reads tr
     const int q = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     if (q >= D.R * D.R) return;
@@ -441,19 +439,8 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
 // ---- backward: brick-owned pull scatter ----------------------------------------------------------------
 // The backward's bricks ("pull bricks", PX x PY x PZ voxels) need not be the forward's: a bigger one lowers the number of
 // bricks a segment touches (every touching brick re-reads the segment's saved samples) at the price of LDS.
-constexpr int kHaloLines = kTX * kTY * kTZ - kBX * kBY * kBZ;         // 149 lines of a 5 x 9 x 9 tile outside its 4 x 8 x 8 brick
-
-// line (tx, ty, tz) of a halo tile that lies outside the brick -> 0 .. 148: the x = BX slab first, then the y = BY face, then z = BZ
-__device__ __forceinline__ int halo_index(int tx, int ty, int tz)
-{
-    if (tx == kBX) return ty * kTZ + tz;
-    if (ty == kBY) return kTY * kTZ + tx * kTZ + tz;
-    return kTY * kTZ + kBX * kTZ + tx * kBY + ty;
-}
-
 template <int PX, int PY, int PZ>
-__global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, float *__restrict__ gvox,
-                                                                  float *__restrict__ halo = nullptr, int nb = 0)
+__global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, float *__restrict__ gvox)
 {
     const int4 row = rows[blockIdx.x];
     if (row.w != 1) return;
@@ -464,10 +451,6 @@ __global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, cons
         const int line = e >> 5, n = n0 + (e & 31);
         const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
         if (x < D.X && y < D.Y && z < D.Z && n < D.N) gvox[x * D.gx + y * D.gy + z * D.gz + n] = 0.f;
-    }
-    if (halo) {                                                         // the halo lines of a brick several rows add onto
-        float *h = halo + ((size_t)blockIdx.y * nb + row.x) * kHaloLines * kImgs;
-        for (int e = threadIdx.x; e < kHaloLines * kImgs; e += kThreads) h[e] = 0.f;
     }
 }
 
@@ -507,20 +490,13 @@ struct BmEntryRegs {
 };
 
 // 768 threads: two workgroups per CU = 6 waves per SIMD, which the register allocation must respect (<= 80 VGPRs)
-// HALO (round 4, "owner computes"): the tile is the brick PLUS its high halo (5 x 9 x 9 lines, as the forward sampler's), a
-// workgroup scatters the segments of ITS OWN brick only -- every sample exactly once (2.52 M per image group instead of the
-// 4.34 M the pull form lists), all eight corners, no ownership masks -- writes the brick's lines to grad_vox and the 149 halo
-// lines to a scratch buffer, and bm_halo_combine_kernel adds each brick's <= 7 neighbours' halo lines onto its low faces.
-// Entries = the forward's segments (h_ent: i0 = 0, i1 = L), records = the forward's rec_f (tile offsets in the fp32 tile:
-// doubled when they are staged), rows = h_rows.
-template <bool PS, int PX, int PY, int PZ, int kThreadsB, bool HALO = false>
-__global__ __launch_bounds__(kThreadsB, (HALO ? 4 : (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE_BM_SCATTER_WAVES) : 4))) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
+template <bool PS, int PX, int PY, int PZ, int kThreadsB>
+__global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE_BM_SCATTER_WAVES) : 4)) void bm_scatter_kernel(BmDims D, const int4 *__restrict__ ents, const int *__restrict__ rec_b,
                                                                const int4 *__restrict__ rows, const float *__restrict__ dw,
                                                                const float *__restrict__ tr, const float *__restrict__ stash,
-                                                               const unsigned *__restrict__ mask, float *__restrict__ gvox,
-                                                               float *__restrict__ halo = nullptr, int nb = 0)
+                                                               const unsigned *__restrict__ mask, float *__restrict__ gvox)
 {
-    constexpr int QX = PX + (HALO ? 1 : 0), QY = PY + (HALO ? 1 : 0), QZ = PZ + (HALO ? 1 : 0);     // tile dimensions in lines
+    constexpr int QX = PX, QY = PY, QZ = PZ;                            // tile dimensions in lines: the brick, no halo
     constexpr int kLinesB = QX * QY * QZ, kWavesB = kThreadsB / 64;
     constexpr int kMaskThreads = (kLinesB + 255) / 256 * 256;           // threads that carry a mask word (whole waves)
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
@@ -570,10 +546,6 @@ __global__ __launch_bounds__(kThreadsB, (HALO ? 4 : (PX == 4 ? (kThreadsB <= 768
                 if (v4 && n + 3 < D.N) *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
                 else
                     for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] = 0.f;
-            }
-            if (HALO && group_live) {                                   // (a dead GROUP: the combine kernel does not run either)
-                float4 *h = reinterpret_cast<float4 *>(halo + ((size_t)g * nb + row.x) * kHaloLines * kImgs);
-                for (int q = threadIdx.x; q < kHaloLines * (kImgs / 4); q += kThreadsB) h[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             return;
         }
@@ -633,8 +605,7 @@ __global__ __launch_bounds__(kThreadsB, (HALO ? 4 : (PX == 4 ? (kThreadsB <= 768
         const int i0 = pk & 63, i1 = (pk >> 6) & 63, L = (pk >> 12) & 63;
         if (lane < (i1 - i0) * 3) {
             int4 *to = reinterpret_cast<int4 *>(stage_to + i0 * kRecL);
-            int4 rv = cur.rq;
-            if (HALO && stage_part == 0) rv.x *= 2;                     // rec_f: byte offset in the fp32 tile -> in the fp64 tile
+            const int4 rv = cur.rq;
             *to = rv;
             if (stage_part == 0) to[2] = rv;                            // the header, again, for the upper half-wave
         }
@@ -676,18 +647,11 @@ __global__ __launch_bounds__(kThreadsB, (HALO ? 4 : (PX == 4 ? (kThreadsB <= 768
             if (i < i1) {
                 const float dp = ps > 0.f ? c * d : 0.f;                // the clamp passes the gradient where the saved sample is > 0
                 double *a = reinterpret_cast<double *>(tl + hc.x);
-                if (HALO) {                                             // every corner line is in the tile: no masks
-                    unsafeAtomicAdd(a, (double)(wc.x * dp));
-                    unsafeAtomicAdd(a + kXS, (double)(wc.y * dp));
-                    unsafeAtomicAdd(a + kYS, (double)(wc.z * dp));
-                    unsafeAtomicAdd(a + kXS + kYS, (double)(wc.w * dp));
-                } else {
-                    const unsigned own = (unsigned)__builtin_amdgcn_readfirstlane(hc.y);
-                    if (owned(own, 0)) unsafeAtomicAdd(a, (double)(wc.x * dp));                // ds_add_f64
-                    if (owned(own, 1)) unsafeAtomicAdd(a + kXS, (double)(wc.y * dp));
-                    if (owned(own, 2)) unsafeAtomicAdd(a + kYS, (double)(wc.z * dp));
-                    if (owned(own, 3)) unsafeAtomicAdd(a + kXS + kYS, (double)(wc.w * dp));
-                }
+                const unsigned own = (unsigned)__builtin_amdgcn_readfirstlane(hc.y);
+                if (owned(own, 0)) unsafeAtomicAdd(a, (double)(wc.x * dp));                    // ds_add_f64
+                if (owned(own, 1)) unsafeAtomicAdd(a + kXS, (double)(wc.y * dp));
+                if (owned(own, 2)) unsafeAtomicAdd(a + kYS, (double)(wc.z * dp));
+                if (owned(own, 3)) unsafeAtomicAdd(a + kXS + kYS, (double)(wc.w * dp));
             }
         };
 #pragma unroll
@@ -731,48 +695,6 @@ __global__ __launch_bounds__(kThreadsB, (HALO ? 4 : (PX == 4 ? (kThreadsB <= 768
     __syncthreads();
     // Flush: every voxel of the brick exactly once.  Four images per thread (two 16-byte LDS reads, one 16-byte store) when
     // the layout allows; rows that share their brick with other rows add atomically onto pre-zeroed voxels.
-    if (HALO) {
-        // the brick's lines to grad_vox (clamp adjoint applied), the 149 halo lines UNMASKED to this brick's slice of the
-        // scratch buffer (bm_halo_combine_kernel applies the receiving voxel's mask); shared rows add atomically to both
-        const bool v4 = (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
-                        (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
-        float *hb = halo + ((size_t)g * nb + row.x) * kHaloLines * kImgs;
-        for (int q = threadIdx.x; q < kLinesB * (kImgs / 4); q += kThreadsB) {
-            const int line = q >> 3, piece = (q & 7) * 4, n = n0 + piece;
-            const int tx = line / (QY * QZ), ty = (line / QZ) % QY, tz = line % QZ;
-            const double2 t01 = *reinterpret_cast<const double2 *>(tile + line * kImgs + piece);
-            const double2 t23 = *reinterpret_cast<const double2 *>(tile + line * kImgs + piece + 2);
-            float4 v = make_float4((float)t01.x, (float)t01.y, (float)t23.x, (float)t23.y);
-            if (tx < PX && ty < PY && tz < PZ) {
-                const int x = ox + tx, y = oy + ty, z = oz + tz;
-                if (x >= D.X || y >= D.Y || z >= D.Z || n >= D.N) continue;
-                if (PS) {
-                    const unsigned m = mlds[line] >> piece;
-                    v.x = (m & 1u) ? v.x * D.pre_scale : 0.f;
-                    v.y = (m & 2u) ? v.y * D.pre_scale : 0.f;
-                    v.z = (m & 4u) ? v.z * D.pre_scale : 0.f;
-                    v.w = (m & 8u) ? v.w * D.pre_scale : 0.f;
-                }
-                float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-                if (row.w == 0) {
-                    if (v4 && n + 3 < D.N) *reinterpret_cast<float4 *>(dst) = v;
-                    else
-                        for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] = vv[c];
-                } else {
-                    for (int c = 0; c < 4; c++) if (n + c < D.N && vv[c] != 0.f) unsafeAtomicAdd(dst + c, vv[c]);
-                }
-            } else {
-                float *dst = hb + halo_index(tx, ty, tz) * kImgs + piece;
-                if (row.w == 0) *reinterpret_cast<float4 *>(dst) = v;
-                else {
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
-                    for (int c = 0; c < 4; c++) if (vv[c] != 0.f) unsafeAtomicAdd(dst + c, vv[c]);
-                }
-            }
-        }
-        return;
-    }
     const bool vec4 = row.w == 0 && (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
                       (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
     if (vec4) {
@@ -806,310 +728,6 @@ __global__ __launch_bounds__(kThreadsB, (HALO ? 4 : (PX == 4 ? (kThreadsB <= 768
             if (row.w == 0) *dst = val;
             else if (val != 0.f) unsafeAtomicAdd(dst, val);
         }
-    }
-}
-
-// ---- backward, halo form: every brick collects what its neighbours scattered onto its low faces -----------------------
-// grid = (bricks, groups).  A voxel with local coordinate 0 along x / y / z receives from the brick below it along that axis
-// (and along two / three axes at once for edge / corner voxels): <= 7 neighbours, whose halo lines lie in the scratch buffer
-// as bm_scatter_kernel<HALO> left them.  The receiving voxel's clamp mask is applied here.
-template <bool PS>
-__global__ __launch_bounds__(256) void bm_halo_combine_kernel(BmDims D, const float *__restrict__ halo, const unsigned *__restrict__ mask,
-                                                            float *__restrict__ gvox, int nb)
-{
-    const int g = blockIdx.y, n0 = g * kImgs, brick = blockIdx.x;
-    if (PS && mask[(size_t)D.groups * D.X * D.Y * D.Z + g] == 0u) return;      // nothing of this group passes the clamp
-    const int nby = (D.Y + kBY - 1) / kBY, nbz = (D.Z + kBZ - 1) / kBZ;
-    const int bx = brick / (nby * nbz), by = (brick / nbz) % nby, bz = brick % nbz;
-    const int ox = bx * kBX, oy = by * kBY, oz = bz * kBZ;
-    const bool v4 = (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
-                    (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
-    for (int q = threadIdx.x; q < kBX * kBY * kBZ * (kImgs / 4); q += 256) {
-        const int line = q >> 3, piece = (q & 7) * 4, n = n0 + piece;
-        const int lx = line / (kBY * kBZ), ly = (line / kBZ) % kBY, lz = line % kBZ;
-        if (lx && ly && lz) continue;                                   // an inner voxel: only its own brick touches it
-        const int x = ox + lx, y = oy + ly, z = oz + lz;
-        if (x >= D.X || y >= D.Y || z >= D.Z || n >= D.N) continue;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int d = 1; d < 8; d++) {
-            const int dx = d & 1, dy = (d >> 1) & 1, dz = d >> 2;
-            if ((dx && lx) || (dy && ly) || (dz && lz)) continue;
-            if ((dx && bx == 0) || (dy && by == 0) || (dz && bz == 0)) continue;
-            const int nbrick = ((bx - dx) * nby + (by - dy)) * nbz + (bz - dz);
-            const int hidx = halo_index(dx ? kBX : lx, dy ? kBY : ly, dz ? kBZ : lz);
-            const float4 h = *reinterpret_cast<const float4 *>(halo + (((size_t)g * nb + nbrick) * kHaloLines + hidx) * kImgs + piece);
-            acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
-        }
-        if (PS) {
-            const unsigned m = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] >> piece;
-            acc.x = (m & 1u) ? acc.x * D.pre_scale : 0.f;
-            acc.y = (m & 2u) ? acc.y * D.pre_scale : 0.f;
-            acc.z = (m & 4u) ? acc.z * D.pre_scale : 0.f;
-            acc.w = (m & 8u) ? acc.w * D.pre_scale : 0.f;
-        }
-        float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
-        if (v4 && n + 3 < D.N) {
-            float4 o = *reinterpret_cast<float4 *>(dst);
-            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-            *reinterpret_cast<float4 *>(dst) = o;
-        } else {
-            const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
-            for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] += a4[c];
-        }
-    }
-}
-
-// ---- backward, gather form -----------------------------------------------------------------------------------------
-// The adjoint of the trilinear interpolation is a sparse matrix product  grad_vox[v, :] = sum_s W[v, s] dLdp[s, :]  whose
-// dense dimension is the image index = the 32 lanes of a half-wave.  bm_scatter_kernel keeps dLdp in a register and the
-// voxel sums in LDS: one ds_add_f64 (8.7 LDS cycles per wave instruction on gfx950) per corner line plus the scalar-unit
-// ownership masks.  Here the voxel sums live in REGISTERS -- a half-wave owns 16 voxels of its 4 x 8 x 8 brick for the whole
-// row -- the dL/dp of the samples that touch the brick are parked in an LDS sample buffer (one plain ds_write per sample),
-// and every contribution costs one ds_read_b32 (2 LDS cycles) and one fused multiply-add; which sample adds to which voxel
-// with which weight is a LIST built on the host (toolbox/_bm_tables.py: _gather_tables), read with one 16-byte LDS read per
-// two contributions.  No atomics, no ownership logic, no tile to clear or flush.
-//   row    = a pull brick's chunks (or a share of them: such rows add onto pre-zeroed voxels)
-//   chunk  = <= kGCH listed samples (whole entries) + the voxel lists over them ("blob"), staged in LDS
-//   phase A  a HALF-wave per entry (32 lanes = images): the segment's saved samples p and its (g T, R) are loaded -- the
-//            next round's loads are in flight during this round's scans --, forward scan g T_k, reverse scan R_k,
-//            dL/dp_k = g T_k (w_k - R_{k+1}) of the listed samples written to their lines of the sample buffer.  The two
-//            entries of a wave are neighbours in a longest-first order, so the scans run to the longer one's length.
-//   phase B  half-wave hw, voxel v: the list (start, n) from the blob's header; both half-waves of a wave hold z-neighbours,
-//            whose lists are padded to one even length -- the loop count is wave-uniform.
-#ifndef GENRE_G_ABL
-#define GENRE_G_ABL 0          // tools/ab_gather.py: 1 no phase B, 2 no scans, 4 no entry loads, 8 no list staging, 16 no flush mask
-#endif
-constexpr int kGThreads = 512, kGHW = kGThreads / 32, kGVox = 16;
-constexpr int kGCH = 384, kGLCAP = 2816;                   // toolbox/_bm_tables.py: GATHER_CH, GATHER_LCAP
-constexpr int kGBlobWords = 256 + 2 * kGLCAP, kGDwWords = 256 + kMaxSeg;
-constexpr size_t kGLds = (size_t)(kGBlobWords + kGDwWords) * 4 + (size_t)kGCH * kImgs * 4;
-
-struct GEntry { float p[kMaxSeg]; float T, R; };
-// what the gather kernel needs of BmDims (scalar registers are scarce in it)
-struct GDims { int N, X, Y, Z, nseg, ZR; int64_t nslot, gx, gy, gz; float pre_scale; };
-
-__device__ __forceinline__ void g_brick_origin(const GDims &D, int brick, int &ox, int &oy, int &oz)
-{
-    const int nby = (D.Y + 7) / 8, nbz = (D.Z + 7) / 8;
-    ox = (brick / (nby * nbz)) * 4; oy = ((brick / nbz) % nby) * 8; oz = (brick % nbz) * 8;
-}
-
-template <bool PS>
-__global__ __launch_bounds__(kGThreads, 4) void bm_gather_kernel(GDims D, const int4 *__restrict__ ents, const int4 *__restrict__ chunks,
-                                                                 const int *__restrict__ blob, const int4 *__restrict__ rows, int nrows,
-                                                                 const float *__restrict__ dw, const float *__restrict__ tr,
-                                                                 const float *__restrict__ stash, const unsigned *__restrict__ mask,
-                                                                 float *__restrict__ gvox, int *__restrict__ row_counter)
-{
-    // PERSISTENT workgroups: the launch has two per CU; each takes rows from a counter (the table is sorted heaviest first)
-    // and walks the chunks of its rows as ONE stream -- while chunk i is gathered, the headers, the blob and the first
-    // entries of chunk i + 1 are in flight, whether it belongs to the same row or to the next one.  (A workgroup per row
-    // spends three dependent memory round trips -- row, chunk, entry headers -- before its first useful instruction:
-    // 110 us of the first version's 550.)
-    extern __shared__ __attribute__((aligned(16))) int lds_g[];
-    __shared__ int s_next;
-    int *bl = lds_g;                                                    // [256 headers][2 * kGLCAP]
-    float *dwl = reinterpret_cast<float *>(lds_g + kGBlobWords);       // depth weights (+ kMaxSeg: read past a short segment)
-    float *sbuf = dwl + kGDwWords;                                      // [kGCH][32]  (behind >= 16 lines of other data: the
-                                                                        //  per-entry base below, (ls0 - i0) lines, is never negative)
-    const int g = blockIdx.y, n0 = g * kImgs;
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), hw = wave * 2 + half;
-    // voxel v of this half-wave: lx = v >> 2, lz = 2 (v & 3) + half, ly = (wave - 2 (v & 3) - 4 lx) mod 8 -- the waves
-    // interleave the brick (a chunk's contributions concentrate on a part of it; toolbox/_bm_tables.py: hidx)
-    for (int i = tid; i < kGDwWords; i += kGThreads) dwl[i] = dw[min(i, D.ZR - 1)];
-    const float *stash_g = stash + (size_t)g * D.nslot * kImgs + l;
-    const float *tr_g = tr + (size_t)g * D.nseg * 2 * kImgs + l;
-    float acc[kGVox];
-#pragma unroll
-    for (int v = 0; v < kGVox; v++) acc[v] = 0.f;
-
-    auto header = [&](const int4 ck, int r) {                          // the entry of this half-wave in round r (pk = 0: none)
-        const int e = ck.x + r * kGHW + hw;
-        int4 h = ents[max(min(e, ck.y - 1), 0)];                        // (a chunk without entries: the table's first row, unused)
-        if (e >= ck.y) h.z = 0;
-        return h;
-    };
-    auto fetch = [&](const int4 h, GEntry &o) {                        // 18 loads, unconditionally (exact waits)
-        if (GENRE_G_ABL & 4) {
-#pragma unroll
-            for (int j = 0; j < kMaxSeg; j++) o.p[j] = __int_as_float(h.x + j);
-            o.T = 1.f; o.R = 0.5f;
-            return;
-        }
-        const float *st = stash_g + (size_t)h.y * kImgs;
-#pragma unroll
-        for (int j = 0; j < kMaxSeg; j++) o.p[j] = st[j * kImgs];
-        const float *tp = tr_g + (size_t)h.x * 2 * kImgs;
-        o.T = tp[0]; o.R = tp[kImgs];
-    };
-    auto process = [&](const int4 h, GEntry &e) {
-        if (GENRE_G_ABL & 2) { if (e.p[3] == 12345.f && e.T == e.R) sbuf[l] = e.p[5]; return; }
-        const int pk = h.z;
-        const int i0 = pk & 63, n_l = ((pk >> 6) & 63) - i0, L = (pk >> 12) & 63, k0 = (pk >> 18) & 255;
-        const int Lmax = __builtin_amdgcn_readfirstlane(L);            // the wave's lower entry is the longer one
-        const bool uneven = __builtin_amdgcn_readlane(L, 32) != Lmax;  // ... and usually they are equally long
-        float ce[kMaxSeg];
-        float Tg = e.T, Rr = e.R;
-        if (uneven) {                                                   // the shorter entry of the wave: no-ops beyond its end
-#pragma unroll
-            for (int j = 0; j < kMaxSeg; j++) e.p[j] = j < L ? e.p[j] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < kMaxSeg; j++) {                             // forward: g T_k  (four at a time up to the longer entry's end)
-            if ((j & 3) == 0 && j >= Lmax) break;
-            ce[j] = Tg;
-            Tg = __builtin_fmaf(-fabsf(e.p[j]), Tg, Tg);
-        }
-        float *sb = sbuf + (h.w - i0) * kImgs + l;
-        const float *wl = dwl + k0;
-        // reverse: R_k; dL/dp_k of the listed samples.  The depth weight of a sample is requested two samples ahead -- it
-        // is an LDS read in front of a serial chain (R), which would otherwise wait for it at every step
-        float wa = wl[kMaxSeg - 1], wb = wl[kMaxSeg - 2];
-#pragma unroll
-        for (int j = kMaxSeg - 1; j >= 0; j--) {
-            const float wj = wa;
-            wa = wb;
-            if (j >= 2) wb = wl[j - 2];
-            if (j < Lmax) {
-                const float d = wj - Rr;
-                Rr = __builtin_fmaf(fabsf(e.p[j]), d, Rr);
-                const float dp = e.p[j] > 0.f ? ce[j] * d : 0.f;        // the clamp passes the gradient where the saved sample is > 0
-                if ((unsigned)(j - i0) < (unsigned)n_l) sb[j * kImgs] = dp;
-            }
-        }
-    };
-    // a chunk's blob travels global -> registers -> LDS: three 16-byte pieces per thread (kGBlobWords <= 3 * 4 * kGThreads)
-    static_assert(kGBlobWords <= 3 * 4 * kGThreads, "blob staging: three sweeps");
-    int4 bq[3];
-    auto blob_load = [&](const int4 ck) {
-#pragma unroll
-        for (int u = 0; u < 3; u++) {
-            const int i = (tid + u * kGThreads) * 4;
-            bq[u] = make_int4(0, 0, 0, 0);
-            if (i < ((GENRE_G_ABL & 8) ? 256 : ck.w)) bq[u] = *reinterpret_cast<const int4 *>(blob + (size_t)ck.z + i);
-        }
-    };
-    auto blob_store = [&](const int4 ck) {
-#pragma unroll
-        for (int u = 0; u < 3; u++) {
-            const int i = (tid + u * kGThreads) * 4;
-            if (i < ck.w) *reinterpret_cast<int4 *>(bl + i) = bq[u];
-        }
-    };
-    int row_i = blockIdx.x;
-    if (row_i >= nrows) return;
-    int4 row = rows[row_i];                                            // (every row has at least one chunk: _gather_tables)
-    int c = row.y;
-    int4 ck = chunks[c];                                               // (entry begin, entry end, blob begin, blob words)
-    GEntry A, B;
-    int4 hA = header(ck, 0), hB = header(ck, 1);
-    blob_load(ck);
-    fetch(hA, A);
-    bool row_start = true;
-    int next_row = nrows;
-    for (;;) {
-        // here: the blob of chunk c is in bq (requested a phase ago), round 0 of its entries in hA / hB / A, LDS is free
-        if (row_start && tid == 0) s_next = (int)gridDim.x + atomicAdd(row_counter + g, 1);    // the row after this one
-        blob_store(ck);
-        const int rounds = (ck.y - ck.x + kGHW - 1) / kGHW;
-        for (int r = 0; r < rounds; r += 2) {                          // phase A: the next round's loads fly during this round's scans
-            const int4 hC = header(ck, r + 2);
-            fetch(hB, B);
-            process(hA, A);
-            if (r + 1 >= rounds) break;
-            const int4 hD = header(ck, r + 3);
-            fetch(hC, A);
-            process(hB, B);
-            hA = hC; hB = hD;
-        }
-        __syncthreads();
-        if (row_start) next_row = s_next;
-        // the next chunk of the stream: of this row, else the first of the next row
-        const bool row_ends = c + 1 >= row.z;
-        int4 rown = row;
-        int cn = c + 1;
-        bool more = true;
-        if (row_ends) {
-            more = next_row < nrows;
-            if (more) { rown = rows[next_row]; cn = rown.y; }
-        }
-        int4 ckn = ck;
-        if (more) {
-            ckn = chunks[cn];
-            hA = header(ckn, 0); hB = header(ckn, 1);
-            blob_load(ckn);
-        }
-        unsigned mword = 0u;                                            // (lives from here to the flush below, not across chunks)
-        if (PS && !(GENRE_G_ABL & 16) && row_ends) {                    // the clamp mask of voxel (l & 15): used behind phase B
-            // (requested HERE: a load behind a run-time condition makes the compiler's next wait inexact -- in front of
-            // phase A that serialises the entry pipeline, here the next wait is half a phase away)
-            int ox, oy, oz;
-            g_brick_origin(D, row.x, ox, oy, oz);
-            const int v = l & 15;
-            const int x = ox + (v >> 2), y = oy + ((wave - 2 * (v & 3) - 4 * (v >> 2)) & 7), z = oz + 2 * (v & 3) + half;
-            mword = 0u;
-            if (x < D.X && y < D.Y && z < D.Z) mword = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
-        }
-        // ---- phase B: this half-wave's sixteen lists are one contiguous stream in the blob (so are its partner's, of the
-        // same lengths): four contributions per step, the list words requested two steps ahead ACROSS the voxel boundaries
-        {
-            int hd[kGVox];
-#pragma unroll
-            for (int v4 = 0; v4 < kGVox / 4; v4++) {
-                const int4 t4 = reinterpret_cast<const int4 *>(bl + hw * kGVox)[v4];
-                hd[4 * v4] = t4.x; hd[4 * v4 + 1] = t4.y; hd[4 * v4 + 2] = t4.z; hd[4 * v4 + 3] = t4.w;
-            }
-            const char *q = reinterpret_cast<const char *>(bl + 256) + (hd[0] & 0xFFFF) * 8;
-            const char *sl = reinterpret_cast<const char *>(sbuf + l);
-            int4 c01 = *reinterpret_cast<const int4 *>(q), c23 = *reinterpret_cast<const int4 *>(q + 16);
-            int4 d01 = *reinterpret_cast<const int4 *>(q + 32), d23 = *reinterpret_cast<const int4 *>(q + 48);
-#pragma unroll
-            for (int v = 0; v < kGVox; v++) {
-                if (v == kGVox / 2 && more) fetch(hA, A);               // the next chunk's first entries (headers requested above)
-                const int n = (GENRE_G_ABL & 1) ? 0 : __builtin_amdgcn_readfirstlane(hd[v] >> 16);   // a multiple of 4, wave-uniform
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                for (int i = 0; i < n; i += 4) {
-                    const float x0 = *reinterpret_cast<const float *>(sl + c01.x), x1 = *reinterpret_cast<const float *>(sl + c01.z);
-                    const float x2 = *reinterpret_cast<const float *>(sl + c23.x), x3 = *reinterpret_cast<const float *>(sl + c23.z);
-                    const float w0 = __int_as_float(c01.y), w1 = __int_as_float(c01.w), w2 = __int_as_float(c23.y), w3 = __int_as_float(c23.w);
-                    c01 = d01; c23 = d23;
-                    q += 32;
-                    d01 = *reinterpret_cast<const int4 *>(q + 32);     // (behind the stream: other lists / the buffer's tail, unused)
-                    d23 = *reinterpret_cast<const int4 *>(q + 48);
-                    a0 = __builtin_fmaf(w0, x0, a0); a1 = __builtin_fmaf(w1, x1, a1);
-                    a2 = __builtin_fmaf(w2, x2, a2); a3 = __builtin_fmaf(w3, x3, a3);
-                }
-                acc[v] += (a0 + a1) + (a2 + a3);
-            }
-        }
-        if (row_ends) {
-            // ---- every voxel of the brick once: a 128-byte line per half-wave and voxel ----
-            int ox, oy, oz;
-            g_brick_origin(D, row.x, ox, oy, oz);
-#pragma unroll
-            for (int v = 0; v < kGVox; v++) {
-                const int lx = v >> 2, ly = (wave - 2 * (v & 3) - 4 * lx) & 7, lz = 2 * (v & 3) + half;
-                const int x = ox + lx, y = oy + ly, z = oz + lz, n = n0 + l;
-                // lane v / 32 + v of the wave hold the mask words of this voxel for the lower / upper half-wave
-                const unsigned m_lo = PS ? (unsigned)__builtin_amdgcn_readlane((int)mword, v) : 0u;
-                const unsigned m_hi = PS ? (unsigned)__builtin_amdgcn_readlane((int)mword, 32 + v) : 0u;
-                const unsigned m = half ? m_hi : m_lo;
-                if (x < D.X && y < D.Y && z < D.Z && n < D.N) {
-                    float val = acc[v];
-                    if (PS && !(GENRE_G_ABL & 16)) val = ((m >> l) & 1u) ? val * D.pre_scale : 0.f;   // adjoint of clamp(x * pre_scale, lo, hi)
-                    float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
-                    if (row.w == 0) *dst = val;
-                    else if (val != 0.f) unsafeAtomicAdd(dst, val);
-                }
-                acc[v] = 0.f;
-            }
-        }
-        if (!more) break;
-        __syncthreads();                                               // this chunk's lists and samples are done with
-        row_start = row_ends;
-        row = rown; c = cn; ck = ckn;
     }
 }
 
@@ -1253,7 +871,7 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
     hipStream_t st = (hipStream_t)stream;
     bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
         D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
-        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data, nullptr,
+        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data,
         pre_scale != 0.0f ? (const unsigned *)mask->data + (int64_t)D.groups * D.X * D.Y * D.Z : nullptr);
     GENRE_LAUNCH_CHECK("render_bm backward (rays)");
     const int nb = ((D.X + px - 1) / px) * ((D.Y + 7) / 8) * ((D.Z + 7) / 8);
@@ -1280,142 +898,5 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
     else { if (pre_scale != 0.0f) GENRE_BM_SCATTER(true, 8, 1024); else GENRE_BM_SCATTER(false, 8, 1024); }
 #undef GENRE_BM_SCATTER
     GENRE_LAUNCH_CHECK("render_bm backward (bricks)");
-    return 1;
-}
-
-extern "C" int genre_render_bm_backward_halo(const genre_tensor *grad_out, const genre_tensor *grad_vox,
-                                             const genre_tensor *segs, const genre_tensor *ray_ptr,
-                                             const genre_tensor *ray_seg, const genre_tensor *ray_pre,
-                                             const genre_tensor *h_ent, const genre_tensor *rec_f,
-                                             const genre_tensor *h_rows, const genre_tensor *depth_weight,
-                                             const genre_tensor *ps_scratch, const genre_tensor *tr_scratch,
-                                             const genre_tensor *p_stash, const genre_tensor *mask,
-                                             const genre_tensor *halo_scratch, float pre_scale, void *stream)
-{
-    const char *op = "render_bm_backward_halo";
-    BmDims D{};
-    if (!check_bm(op, grad_vox, grad_out, segs, ray_ptr, ray_seg, ray_pre, D, true)) return 0;
-    if (!check_rows(op, D, h_rows)) return 0;
-    D.gx = grad_vox->stride[2]; D.gy = grad_vox->stride[3]; D.gz = grad_vox->stride[4];
-    D.pre_scale = pre_scale;
-    GENRE_REQUIRE(is_i32(h_ent, 2) && h_ent->size[1] == 4 && is_contiguous(h_ent) && aligned16(h_ent->data) &&
-                      h_ent->size[0] == D.nseg, "%s: h_ent must be int32 [nseg,4]", op);
-    GENRE_REQUIRE(is_i32(rec_f, 2) && rec_f->size[1] == kRec && is_contiguous(rec_f) && aligned16(rec_f->data),
-                  "%s: rec_f must be a contiguous int32 [S,12] tensor", op);
-    GENRE_REQUIRE(is_f32(depth_weight, 1) && is_contiguous(depth_weight) && depth_weight->size[0] >= 1 &&
-                      depth_weight->size[0] <= 256, "%s: depth_weight must be fp32 [ZR], 1 <= ZR <= 256", op);
-    D.ZR = (int)depth_weight->size[0];
-    D.nslot = rec_f->size[0];
-    const int64_t per = (int64_t)D.groups * D.nseg * 2 * kImgs;
-    GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ps_scratch->size[0] >= per &&
-                      is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && tr_scratch->size[0] >= per,
-                  "%s: ps_scratch / tr_scratch must hold groups*nseg*64 floats", op);
-    GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] >= (int64_t)D.groups * D.nslot * kImgs,
-                  "%s: p_stash must be the forward's [groups*S*32] buffer", op);
-    GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) && mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z + D.groups),
-                  "%s: pre_scale needs the forward's mask int32 [groups*X*Y*Z + groups]", op);
-    const int nb = ((D.X + kBX - 1) / kBX) * ((D.Y + kBY - 1) / kBY) * ((D.Z + kBZ - 1) / kBZ);
-    GENRE_REQUIRE(is_f32(halo_scratch, 1) && is_contiguous(halo_scratch) && aligned16(halo_scratch->data) &&
-                      halo_scratch->size[0] >= (int64_t)D.groups * nb * kHaloLines * kImgs,
-                  "%s: halo_scratch must hold groups*bricks*149*32 floats", op);
-    hipStream_t st = (hipStream_t)stream;
-    const unsigned *group_any = pre_scale != 0.0f ? (const unsigned *)mask->data + (int64_t)D.groups * D.X * D.Y * D.Z : nullptr;
-    bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
-        D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
-        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data, nullptr, group_any);
-    GENRE_LAUNCH_CHECK("render_bm backward (rays)");
-    const dim3 grid((unsigned)h_rows->size[0], (unsigned)D.groups);
-    if (h_rows->size[0] > nb) {                   // some bricks are split over several rows: those add atomically
-        bm_zero_shared_kernel<kBX, kBY, kBZ><<<grid, kThreads, 0, st>>>(D, (const int4 *)h_rows->data, (float *)grad_vox->data,
-                                                                        (float *)halo_scratch->data, nb);
-        GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");
-    }
-    constexpr int NTH = 1024;
-    constexpr int kLinesH = kTX * kTY * kTZ, kMaskH = (kLinesH + 255) / 256 * 256;
-    constexpr size_t lds = (size_t)kLinesH * kImgs * 8 + (size_t)(NTH / 64) * kMaxSeg * kRecL * 4 + (size_t)(kMaskH + kMaskH / 64 + 4) * 4;
-#define GENRE_BM_HALO(PSV)                                                                                                \
-    do {                                                                                                                  \
-        static std::atomic<uint64_t> done_{0};                                                                            \
-        if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_scatter_kernel<PSV, kBX, kBY, kBZ, NTH, true>), lds, done_)) return 0; \
-        bm_scatter_kernel<PSV, kBX, kBY, kBZ, NTH, true><<<grid, NTH, lds, st>>>(                                         \
-            D, (const int4 *)h_ent->data, (const int *)rec_f->data, (const int4 *)h_rows->data,                           \
-            (const float *)depth_weight->data, (const float *)tr_scratch->data, (const float *)p_stash->data,             \
-            pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr, (float *)grad_vox->data,                          \
-            (float *)halo_scratch->data, nb);                                                                             \
-        GENRE_LAUNCH_CHECK("render_bm backward (bricks, halo form)");                                                     \
-        bm_halo_combine_kernel<PSV><<<dim3((unsigned)nb, (unsigned)D.groups), 256, 0, st>>>(                              \
-            D, (const float *)halo_scratch->data, pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr,             \
-            (float *)grad_vox->data, nb);                                                                                 \
-    } while (0)
-    if (pre_scale != 0.0f) GENRE_BM_HALO(true); else GENRE_BM_HALO(false);
-#undef GENRE_BM_HALO
-    GENRE_LAUNCH_CHECK("render_bm backward (halo combine)");
-    return 1;
-}
-
-extern "C" int genre_render_bm_backward_gather(const genre_tensor *grad_out, const genre_tensor *grad_vox,
-                                               const genre_tensor *segs, const genre_tensor *ray_ptr,
-                                               const genre_tensor *ray_seg, const genre_tensor *ray_pre,
-                                               const genre_tensor *g_ent, const genre_tensor *g_chunks,
-                                               const genre_tensor *g_blob, const genre_tensor *g_rows,
-                                               const genre_tensor *depth_weight, const genre_tensor *ps_scratch,
-                                               const genre_tensor *tr_scratch, const genre_tensor *p_stash,
-                                               const genre_tensor *mask, float pre_scale, void *stream)
-{
-    const char *op = "render_bm_backward_gather";
-    BmDims D{};
-    if (!check_bm(op, grad_vox, grad_out, segs, ray_ptr, ray_seg, ray_pre, D, true)) return 0;
-    if (!check_rows(op, D, g_rows, 4, 8, 8)) return 0;
-    D.gx = grad_vox->stride[2]; D.gy = grad_vox->stride[3]; D.gz = grad_vox->stride[4];
-    D.pre_scale = pre_scale;
-    GENRE_REQUIRE(is_i32(g_ent, 2) && g_ent->size[1] == 4 && is_contiguous(g_ent) && aligned16(g_ent->data) && g_ent->size[0] >= 1,
-                  "%s: g_ent must be int32 [E,4]", op);
-    GENRE_REQUIRE(is_i32(g_chunks, 2) && g_chunks->size[1] == 4 && is_contiguous(g_chunks) && aligned16(g_chunks->data),
-                  "%s: g_chunks must be int32 [C,4]", op);
-    GENRE_REQUIRE(is_i32(g_blob, 1) && is_contiguous(g_blob) && aligned16(g_blob->data) && g_blob->size[0] < ((int64_t)1 << 31),
-                  "%s: g_blob must be a contiguous int32 tensor", op);
-    GENRE_REQUIRE(is_f32(depth_weight, 1) && is_contiguous(depth_weight) && depth_weight->size[0] >= 1 &&
-                      depth_weight->size[0] <= 256, "%s: depth_weight must be fp32 [ZR], 1 <= ZR <= 256", op);
-    D.ZR = (int)depth_weight->size[0];
-    const int64_t per = (int64_t)D.groups * D.nseg * 2 * kImgs;
-    GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ps_scratch->size[0] >= per &&
-                      is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && tr_scratch->size[0] >= per + D.groups,
-                  "%s: ps_scratch must hold groups*nseg*64 floats, tr_scratch groups*nseg*64 + groups", op);
-    GENRE_REQUIRE(is_f32(p_stash, 1) && is_contiguous(p_stash) && p_stash->size[0] % kImgs == 0 && D.groups > 0 &&
-                      p_stash->size[0] / kImgs % D.groups == 0, "%s: p_stash must be the forward's [groups*S*32] buffer", op);
-    D.nslot = p_stash->size[0] / kImgs / D.groups;
-    GENRE_REQUIRE(pre_scale == 0.0f || (is_i32(mask, 1) && is_contiguous(mask) && mask->size[0] >= (int64_t)D.groups * D.X * D.Y * D.Z + D.groups),
-                  "%s: pre_scale needs the forward's mask int32 [groups*X*Y*Z + groups]", op);
-    hipStream_t st = (hipStream_t)stream;
-    bm_combine_bwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
-        D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
-        (const double2 *)ray_pre->data, view4(grad_out), (float *)tr_scratch->data,
-        reinterpret_cast<int *>((float *)tr_scratch->data + per), nullptr);
-    GENRE_LAUNCH_CHECK("render_bm backward (rays)");
-    const int nb = ((D.X + 3) / 4) * ((D.Y + 7) / 8) * ((D.Z + 7) / 8);
-    const dim3 grid((unsigned)g_rows->size[0], (unsigned)D.groups);
-    const int nrows = (int)g_rows->size[0];
-    // persistent workgroups: two per CU (LDS), fewer when there are fewer rows; they take rows from a counter per group
-    // that lives behind tr_scratch's payload and is reset by the per-ray kernel in front of this one
-    const dim3 pgrid((unsigned)(nrows < 2 * kCUs ? nrows : 2 * kCUs), (unsigned)D.groups);
-    int *counter = reinterpret_cast<int *>((float *)tr_scratch->data + per);
-    const GDims GD{D.N, D.X, D.Y, D.Z, D.nseg, D.ZR, D.nslot, D.gx, D.gy, D.gz, D.pre_scale};
-    if (g_rows->size[0] > nb) {                   // some bricks are split over several rows: those add atomically
-        bm_zero_shared_kernel<4, 8, 8><<<grid, kThreads, 0, st>>>(D, (const int4 *)g_rows->data, (float *)grad_vox->data);
-        GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");
-    }
-#define GENRE_BM_GATHER(PSV)                                                                                              \
-    do {                                                                                                                  \
-        static std::atomic<uint64_t> done_{0};                                                                            \
-        if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_gather_kernel<PSV>), kGLds, done_)) return 0;             \
-        bm_gather_kernel<PSV><<<pgrid, kGThreads, kGLds, st>>>(                                                           \
-            GD, (const int4 *)g_ent->data, (const int4 *)g_chunks->data, (const int *)g_blob->data,                        \
-            (const int4 *)g_rows->data, nrows, (const float *)depth_weight->data, (const float *)tr_scratch->data,        \
-            (const float *)p_stash->data, pre_scale != 0.0f ? (const unsigned *)mask->data : nullptr,                     \
-            (float *)grad_vox->data, counter);                                                                            \
-    } while (0)
-    if (pre_scale != 0.0f) GENRE_BM_GATHER(true); else GENRE_BM_GATHER(false);
-#undef GENRE_BM_GATHER
-    GENRE_LAUNCH_CHECK("render_bm backward (gather)");
     return 1;
 }

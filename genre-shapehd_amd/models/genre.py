@@ -68,7 +68,9 @@ class DepthInpaintNet(nn.Module):
         opt = opt or GenReOptions()
         self.net1 = MarrNet1Net([3, 1, 1], ["normal", "depth", "silhou"], pred_depth_minmax=True)
         self.net2 = Net_inpaint([1], ["spherical"], input_planes=1)
-        self.proj_depth = Camera_back_projection_layer()
+        # the volume's memory layout follows the batch size (round 5): batches of >= 16 images are laid out image-minor, where
+        # the renderer's tile kernels (csrc/sph_render_bm.hip) run; the reference's batch sizes (1, 4, 8 per GPU) keep NCXYZ
+        self.proj_depth = Camera_back_projection_layer(batch_minor=True)
         self.render_spherical = render_spherical()
         self.joint_train, self.load_offline, self.padding_margin = opt.joint_train, opt.load_offline, opt.padding_margin
         if opt.net1_path:

@@ -49,7 +49,6 @@ LINE_F = 128                    # bytes of one voxel line in the forward tile (3
 LINE_B = 256                    # ... in the backward tile (32 images x fp64)
 SPLIT_F = 4096                  # samples per forward row
 SPLIT_B = 2048                  # listed samples per backward row
-SPLIT_H = 2048                  # samples per row of the halo-form backward
 LO = np.float32(1e-5)           # spherical_proj.py:66
 
 
@@ -68,7 +67,7 @@ def _axis(d2a, a, size):
 PULL = (4, 8, 8)                # the backward's bricks (csrc/sph_render_bm.hip: pull_brick 488 or 888; 8x8x8 measured slower)
 
 
-def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split_b=SPLIT_B, pull=PULL, gather=True):
+def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split_b=SPLIT_B, pull=PULL):
     R = dirs64.shape[0]
     RR = R * R
     assert z_res <= 256 and RR < (1 << 22)
@@ -221,153 +220,9 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     cumb = np.concatenate(([0], np.cumsum((i_last + 1 - i_first).astype(np.int64))))
     bwd_rows = _split_rows(eb, ee, cumb, split_b, 1)
 
-    # ---- backward, halo form ("owner computes": csrc/sph_render_bm.hip, bm_scatter_kernel<HALO>): a brick scatters its OWN
-    # segments into a tile with halo -- the forward's segments and records serve as they are; an entry lists the whole segment
-    h_pack = (segs[:, 2] << 6) | (segs[:, 2] << 12) | (segs[:, 1] << 18)
-    h_ent = np.stack([segs[:, 0], segs[:, 3], h_pack, segs[:, 3]], 1).astype(np.int32)
-    h_rows = _split_rows(sb, se, cum, SPLIT_H, 1)
-
     out = dict(segs=segs, rec_f=rec_f, fwd_rows=fwd_rows, ray_ptr=ray_ptr, ray_seg=ray_seg, ray_pre=ray_pre,
-               ent=ent, rec_b=rec_b, bwd_rows=bwd_rows, kin=kin, pull=np.asarray(pull, np.int32), h_ent=h_ent, h_rows=h_rows)
-    if tuple(pull) == GATHER_BRICK and gather:
-        out.update(_gather_tables(pnb, ent, ent_brick, gstart, gcount, i_first, rel, own, wts[s_id], eb, ee, split_b))
+               ent=ent, rec_b=rec_b, bwd_rows=bwd_rows, kin=kin, pull=np.asarray(pull, np.int32))
     return out
-
-
-# ---- backward, gather form (csrc/sph_render_bm.hip: bm_gather_kernel) ------------------------------------------------
-# The adjoint of the trilinear interpolation is a sparse matrix product  grad_vox[v, :] = sum_s W[v, s] dLdp[s, :]  whose
-# dense dimension is the image index (the 32 lanes of a half-wave).  Scatter form (bm_scatter_kernel): dLdp in a register,
-# the voxel sums in LDS, one LDS atomic per corner line.  Gather form: the voxel sums in REGISTERS (a half-wave owns 16
-# voxels of its brick for the whole row), dLdp of the samples that touch the brick parked in LDS, one plain LDS read per
-# contribution -- ds_read_b32 costs 2 LDS cycles per wave instruction, ds_add_f64 8.7 -- and no ownership logic at all:
-# which sample adds to which voxel with which weight is a LIST, built here.
-#   g_ent     int32 [E + GATHER_EPAD, 4]  (segment, slot of its first sample, i0 | i1 << 6 | L << 12 | k0 << 18,
-#                                           local slot of sample i0 in the chunk's sample buffer); the entries of a chunk
-#                                           are sorted by L, longest first (two entries share a wave)
-#   g_chunks  int32 [C, 4]                (entry begin, entry end, first word of the chunk's blob, words in the blob)
-#   g_blob    int32 [...]                 per chunk: 256 header words -- one per voxel of the brick, at index
-#                                           half_wave * 16 + v (see hidx in _gather_tables): list start | list length << 16, in
-#                                           contributions -- then the lists, 8 bytes per contribution: (byte offset of the
-#                                           sample's line in the sample buffer, weight).  The lists of z-neighbours (the two
-#                                           half-waves of a wave) are padded with zero-weight contributions to the same
-#                                           length, a multiple of four.
-#   g_rows    int32 [rows, 4]             (pull brick, chunk begin, chunk end, shared)
-GATHER_BRICK = (4, 8, 8)
-GATHER_CH = 384                 # listed samples per chunk: 48 KB of LDS (32 images x fp32 per sample)
-GATHER_RAW = 1900               # contributions per chunk before padding
-GATHER_LCAP = 2816              # ... after padding: 22 KB of LDS
-DEBUG_STATS = False
-GATHER_EPAD = 64                # zero entries behind the last (prefetches of a chunk's tail read past it)
-
-
-def _gather_tables(pnb, ent, ent_brick, gstart, gcount, i_first, rel, own, wl, eb, ee, split_b):
-    nE, nl = ent.shape[0], own.shape[0]
-    L_e = (ent[:, 2] >> 12) & 63
-    pc8 = np.array([bin(v).count("1") for v in range(256)], np.int64)
-    raw_l = pc8[own & 255]
-    cumL = np.concatenate(([0], np.cumsum(gcount.astype(np.int64))))
-    cumC = np.concatenate(([0], np.cumsum(np.add.reduceat(raw_l, gstart)))) if nE else np.zeros(1, np.int64)
-    # header index of voxel vi = (lx*8 + ly)*8 + lz: wave = (ly + 2 (lz >> 1) + 4 lx) mod 8, half-wave = lz & 1,
-    # v = lx*4 + (lz >> 1).  The two half-waves of a wave hold z-neighbours (vi ^ 1), whose lists are alike: they are padded to
-    # one length.  The wave index is a skewed interleave of the brick: a chunk's samples are a bundle of neighbouring rays, so
-    # its contributions concentrate on a part of the brick, and the gather phase takes as long as its busiest wave --
-    # compact 4 x 4 x 8 blocks per wave: the busiest has 2.1 x the mean, this map 1.35 x (measured over the 128^3 tables)
-    vi_all = np.arange(256)
-    lx_, ly_, lz_ = vi_all >> 6, (vi_all >> 3) & 7, vi_all & 7
-    hidx = (((ly_ + 2 * (lz_ >> 1) + 4 * lx_) & 7) * 2 + (lz_ & 1)) * 16 + lx_ * 4 + (lz_ >> 1)
-    # contributions: (listed sample, owned corner) -> (entry, voxel, weight)
-    e_of_l = np.repeat(np.arange(nE), gcount)
-    i_l = np.arange(nl) - gstart[e_of_l]                                  # position inside the entry's listed run
-    PX, PY, PZ = GATHER_BRICK
-    c_l, c_vi, c_w = [], [], []
-    for c in range(8):
-        okc = np.nonzero((own >> ((c & 3) + 4 * (c >> 2))) & 1)[0]
-        vi = ((rel[0][okc] + (c & 1)) * PY + rel[1][okc] + ((c >> 1) & 1)) * PZ + rel[2][okc] + (c >> 2)
-        assert ((vi >= 0) & (vi < PX * PY * PZ)).all()
-        c_l.append(okc); c_vi.append(vi.astype(np.int64)); c_w.append(wl[okc, c].view(np.int32))
-    c_l, c_vi, c_w = np.concatenate(c_l), np.concatenate(c_vi), np.concatenate(c_w)
-    c_e = e_of_l[c_l]
-    # chunks: every brick's entries (segment order), as many as fit the sample buffer; a chunk whose padded lists would
-    # not fit the list buffer is halved
-    bounds = []
-    for b in range(pnb):
-        e, end = int(eb[b]), int(ee[b])
-        while e < end:
-            l1 = int(np.searchsorted(cumL, cumL[e] + GATHER_CH, side="right")) - 1
-            l2 = int(np.searchsorted(cumC, cumC[e] + GATHER_RAW, side="right")) - 1
-            e2 = max(min(end, l1, l2), e + 1)
-            assert cumL[e2] - cumL[e] <= GATHER_CH, "one entry exceeds the chunk capacity"
-            bounds.append((e, e2))
-            e = e2
-    while True:
-        cbeg = np.asarray([b0 for b0, _ in bounds], np.int64)
-        nC = cbeg.shape[0]
-        chunk_of = (np.searchsorted(cbeg, np.arange(nE), side="right") - 1) if nC else np.zeros(0, np.int64)
-        keys = chunk_of[c_e] * 256 + c_vi
-        counts = np.bincount(keys, minlength=nC * 256).reshape(nC, 256)
-        padded = np.maximum(counts, counts[:, vi_all ^ 1])
-        padded = (padded + 3) & ~3                                         # the kernel takes four contributions per step
-        tot = padded.sum(1)
-        big = np.nonzero(tot > GATHER_LCAP)[0]
-        if big.size == 0:
-            break
-        for c in big[::-1]:
-            b0, b1 = bounds[c]
-            assert b1 - b0 > 1, "one entry's lists exceed the list buffer"
-            mid = int(np.searchsorted(cumL, (cumL[b0] + cumL[b1]) // 2, side="left"))
-            mid = min(max(mid, b0 + 1), b1 - 1)
-            bounds[c:c + 1] = [(b0, mid), (mid, b1)]
-    if DEBUG_STATS:
-        print("gather: chunks", nC, "raw", counts.sum(), "padded", tot.sum(), "max padded", tot.max() if nC else 0,
-              "nonempty pair visits", (padded > 0).sum() // 2, "of", nC * 128)
-    chunk_brick = ent_brick[cbeg] if nC else np.zeros(0, np.int64)
-    padded_h = np.empty_like(padded)
-    padded_h[:, hidx] = padded                                             # in header order
-    starts_h = np.cumsum(padded_h, 1) - padded_h                          # lists are laid out in header order
-    starts = starts_h[:, hidx]                                             # ... looked up by vi
-    assert nC == 0 or padded.max() < (1 << 16)
-    # inside a chunk: longest segments first (two entries share a wave; its loops run to the longer one)
-    order = np.lexsort((-L_e, chunk_of))
-    cb = np.searchsorted(chunk_of, np.arange(nC), side="left")            # chunk_of is non-decreasing
-    ce = np.searchsorted(chunk_of, np.arange(nC), side="right")
-    n_sorted = gcount[order].astype(np.int64)
-    cs = np.concatenate(([0], np.cumsum(n_sorted)))
-    ls0_sorted = cs[:-1] - cs[cb[chunk_of[order]]]
-    g_ent = np.zeros((nE + GATHER_EPAD, 4), np.int32)
-    g_ent[:nE, :3] = ent[order, :3]
-    g_ent[:nE, 3] = ls0_sorted
-    ls0 = np.empty(nE, np.int64)
-    ls0[order] = ls0_sorted
-    offs = ((ls0[c_e] + i_l[c_l]) * 128).astype(np.int32)
-    words = 256 + 2 * tot
-    base = np.concatenate(([0], np.cumsum(words)))
-    assert base[-1] < (1 << 31)
-    g_blob = np.zeros(int(base[-1]) + 256 + 4, np.int32)                  # + one all-empty blob (below)
-    hdr_pos = (base[:-1, None] + np.arange(256)[None, :]).reshape(-1)
-    g_blob[hdr_pos] = (starts_h | (padded_h << 16)).reshape(-1).astype(np.int32)
-    o = np.argsort(keys, kind="stable")
-    ks = keys[o]
-    first = np.concatenate(([0], np.cumsum(counts.reshape(-1))))[:-1]
-    rank = np.arange(ks.shape[0]) - first[ks]
-    pos = base[ks >> 8] + 256 + 2 * (starts.reshape(-1)[ks] + rank)
-    g_blob[pos] = offs[o]
-    g_blob[pos + 1] = c_w[o]
-    g_chunks = np.stack([cb, ce, base[:-1], words], 1).astype(np.int32)
-    # rows: a brick's chunks, cut where they exceed split_b listed samples
-    lis_c = cs[ce] - cs[cb]
-    rb = np.searchsorted(chunk_brick, np.arange(pnb), side="left")
-    re_ = np.searchsorted(chunk_brick, np.arange(pnb), side="right")
-    g_rows = _split_rows(rb, re_, np.concatenate(([0], np.cumsum(lis_c))), split_b, 1)
-    # the XCD interleave (ROW_ORDER = 'xcd') pads the table with SKIP rows; bm_gather_kernel's persistent workgroups take rows
-    # from a counter and do not test for them (a SKIP row would be read as chunk `row.y` of another brick): none here
-    g_rows = np.ascontiguousarray(g_rows[g_rows[:, 3] != SKIP])
-    # a brick that no sample touches still has to be written (zeros): its row gets one chunk without entries, whose blob
-    # is 256 empty lists -- the kernel walks the chunks of its rows as one stream and never meets a row without one
-    g_chunks = np.concatenate((g_chunks, np.asarray([[0, 0, int(base[-1]), 256]], np.int32)))
-    empty = (g_rows[:, 1] == g_rows[:, 2]) & (g_rows[:, 3] != SKIP)
-    g_rows[empty, 1] = nC
-    g_rows[empty, 2] = nC + 1
-    return dict(g_ent=g_ent, g_chunks=g_chunks, g_blob=g_blob, g_rows=g_rows)
 
 
 def _split_rows(begin, end, cum, split, shared_mode):

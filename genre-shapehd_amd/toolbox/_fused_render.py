@@ -196,18 +196,16 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
     # keyed on the CONTENTS of the depth_weight buffer (hashed once per address + version, _content_of): no device ->
     # host copy -- and no stream synchronisation, which HIP-graph capture forbids -- while the buffer is untouched
     dw_hash, dw = _content_of(depth_weight)
-    gather = bm_backward_mode() == "gather"
-    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], dw_hash, str(device), pull, gather)
+    key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], dw_hash, str(device), pull)
     t = _TABLES.get(key)
     if t is None:
         d64 = dirs64.cpu().numpy()
 
         def build():
-            return _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, pull=pull,
-                                              gather=gather)
+            return _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, pull=pull)
         build.__module__ = _bm_tables.__name__
         np_t = _disk_cached("bm", (tuple(vox_shape[2:]), pull, _bm_tables.ROW_ORDER, _bm_tables.SPLIT_F,
-                                   _bm_tables.SPLIT_B, _bm_tables.SPLIT_H, _bm_tables.MAXSEG, gather, "r4"), [d64, dw], build)
+                                   _bm_tables.SPLIT_B, _bm_tables.MAXSEG, "r5"), [d64, dw], build)
         t = {"pull_code": int(np_t["pull"][0]) * 100 + int(np_t["pull"][1]) * 10 + int(np_t["pull"][2])}
         for k, v in np_t.items():
             if k == "pull":
@@ -218,17 +216,6 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
             t[k] = tv.to(device)
         _remember(key, t)
     return t
-
-
-def bm_backward_mode():
-    """which backward the batch-minor renderer runs: "scatter" (default; bm_scatter_kernel, LDS fp64 atomics) or
-    "gather" (bm_gather_kernel: voxel sums in registers over per-voxel contribution lists -- measured on MI355X at batch
-    32: no faster; its tables are only built when it is selected) -- the switch GENRE_BM_BWD, read
-    at every call"""
-    import os
-    mode = os.environ.get("GENRE_BM_BWD", "scatter")
-    assert mode in ("gather", "scatter", "halo"), "GENRE_BM_BWD must be scatter, gather or halo"
-    return mode
 
 
 def is_batch_minor(vox):
@@ -280,8 +267,14 @@ class RenderSphericalFused(Function):
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
         rays = vox.shape[0] * vox.shape[1] * res * res
         v = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
+        # with pre_scale and a backward to come: the clamp's pass words per image and per 16^3 brick (csrc/sph_render.hip) --
+        # what the clamp blocks is then written as zeros by the backward, not computed (GenRe's own volumes: everything)
+        ctx.live = None
+        if pre_scale and ctx.needs_input_grad[0]:
+            nb = -(-vox.shape[2] // BRICK) * -(-vox.shape[3] // BRICK) * -(-vox.shape[4] // BRICK)
+            ctx.live = torch.empty((vox.shape[0] * vox.shape[1] * (1 + nb),), dtype=torch.int32, device=vox.device)
         lib.render_spherical_forward(vox, dirs64.view(torch.float32), depth_weight, out,
-                                     v, t["fwd_table"], t["fwd_chunks"], t["kin"], float(pre_scale))
+                                     v, t["fwd_table"], t["fwd_chunks"], t["kin"], float(pre_scale), ctx.live)
         ctx.save_for_backward(vox, dirs64, depth_weight, v)
         return out
 
@@ -294,21 +287,9 @@ class RenderSphericalFused(Function):
             t = bm_tables_for(ctx.vox_shape, grad_out.device, dirs64, depth_weight)
             grad_vox = empty_batch_minor(ctx.vox_shape, grad_out.dtype, grad_out.device)
             groups = -(-ctx.vox_shape[0] // 32)
-            if bm_backward_mode() == "halo":
-                nb = -(-ctx.vox_shape[2] // 4) * -(-ctx.vox_shape[3] // 8) * -(-ctx.vox_shape[4] // 8)
-                lib.render_bm_backward_halo(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"],
-                                            t["h_ent"], t["rec_f"], t["h_rows"], depth_weight, ps, torch.empty_like(ps), stash,
-                                            ctx.mask, torch.empty((groups * nb * 149 * 32,), dtype=ps.dtype, device=ps.device),
-                                            ctx.pre_scale)
-            elif "g_ent" in t and bm_backward_mode() == "gather":
-                lib.render_bm_backward_gather(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"],
-                                              t["g_ent"], t["g_chunks"], t["g_blob"], t["g_rows"], depth_weight, ps,
-                                              torch.empty((ps.numel() + groups,), dtype=ps.dtype, device=ps.device),
-                                              stash, ctx.mask, ctx.pre_scale)      # (+ one row counter per image group)
-            else:
-                lib.render_bm_backward(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], t["ent"],
-                                       t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,
-                                       ctx.pre_scale, t["pull_code"])
+            lib.render_bm_backward(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], t["ent"],
+                                   t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,
+                                   ctx.pre_scale, t["pull_code"])
             return grad_vox, None, None, None, None
         vox, dirs64, depth_weight, v = ctx.saved_tensors
         z_res = depth_weight.shape[0]
@@ -317,5 +298,5 @@ class RenderSphericalFused(Function):
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
         scratch = torch.empty((rays * z_res + vox.shape[0] * vox.shape[1],), dtype=torch.float32, device=vox.device)
         lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,
-                                      scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"], ctx.pre_scale)
+                                      scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"], ctx.pre_scale, ctx.live)
         return grad_vox, None, None, None, None

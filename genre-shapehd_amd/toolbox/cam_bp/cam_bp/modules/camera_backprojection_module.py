@@ -13,7 +13,7 @@ class Camera_back_projection_layer(nn.Module):
     def __init__(self, res=128, batch_minor=False):
         """batch_minor (extension): batches of >= 16 single-channel maps get their volume laid out with the image
         index fastest in memory (same logical shape and values; `.is_contiguous()` is False) -- the layout in which
-        render_spherical's fused forward is fastest.  Leave it off when training through the renderer."""
+        render_spherical's fused kernels are fastest, forward and backward (smaller batches keep NCXYZ whatever the flag says)."""
         super().__init__()
         assert res == 128
         self.res = 128

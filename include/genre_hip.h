@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GENRE_ABI_VERSION 3
+#define GENRE_ABI_VERSION 4
 #define GENRE_MAX_DIMS 5
 
 enum { GENRE_F32 = 0, GENRE_I32 = 1 };
@@ -245,12 +245,18 @@ int genre_nnd_backward_host(const genre_tensor *xyz1, const genre_tensor *xyz2,
  * from dirs); it is then written as sph_pad(map, p) of spherical_proj.py:21-28 lays it out
  * (first/last row replicated, azimuth columns wrapped around) -- the `sph_pad(sph_in, margin)`
  * of depth_pred_with_sph_inpaint.py:126 folded in; backward accepts grad_out of that shape.
+ * live (ABI 4; optional, used with pre_scale != 0 on the brick path): int32 [N*NC*(1 + bricks)], bricks = ceil(X/16) *
+ * ceil(Y/16) * ceil(Z/16).  The forward clears it and sets live[img*(1+bricks)] = 1 if ANY voxel of image img passes the
+ * pre_scale clamp (lo <= vox*pre_scale <= hi) and live[img*(1+bricks) + 1 + b] = 1 if any voxel of brick b does.  Handed to
+ * genre_render_spherical_backward it lets that op skip what the clamp blocks: a dead image's scan pass returns at once, a
+ * dead brick's voxels are written as zeros without reading the sample list.  On GenRe's own chain (clamp(proj * 50) of a
+ * saturated-or-empty volume, depth_pred_with_sph_inpaint.py:124) every image is dead: the gradient is identically zero.
  * Reference builder of the tables: genre-shapehd_amd/toolbox/_fused_render.py. */
 int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *dirs,
                                    const genre_tensor *depth_weight, const genre_tensor *out,
                                    const genre_tensor *v_scratch, const genre_tensor *fwd_table,
                                    const genre_tensor *fwd_chunks, const genre_tensor *kin,
-                                   float pre_scale, void *stream);
+                                   const genre_tensor *live, float pre_scale, void *stream);
 
 /* Adjoint of the above w.r.t. vox (what autograd derives for the reference's
  * op chain).  grad_out [N,NC,R,R] -> grad_vox [N,NC,X,Y,Z], fully written.
@@ -265,6 +271,8 @@ int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *
  *    at least one trilinear corner inside that brick (samples near faces appear in
  *    several bricks).  If v_scratch (as written by the forward) and kin are given too,
  *    the samples are not recomputed from vox.
+ *    live (optional; needs v_scratch + kin and pre_scale != 0): the forward's pass words, see above -- where the clamp
+ *    blocks everything the adjoint is a select of zeros, so a non-finite upstream gradient does not reach a dead image.
  *  - those pointers NULL: global-atomic scatter fallback (grad_vox must be
  *    contiguous, 16-byte aligned, numel % 4 == 0). */
 int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
@@ -272,7 +280,7 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
                                     const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
                                     const genre_tensor *brick_table, const genre_tensor *chunk_list,
                                     const genre_tensor *v_scratch, const genre_tensor *kin,
-                                    float pre_scale, void *stream);
+                                    const genre_tensor *live, float pre_scale, void *stream);
 
 /* ---- batch-minor tile renderer (extension; csrc/sph_render_bm.hip) ------------------------------
  *
@@ -312,8 +320,7 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *              bit i = image i passes clamp(vox*pre_scale); the trailing `groups` words (ABI 3) say whether ANY voxel of
  *              the group passes it -- cleared and set by the forward, read by the backward: a group (or a brick) whose
  *              masks are all zero has an identically zero gradient and the backward only writes its zeros
- *   tr_scratch fp32 [groups*nseg*64]: backward only (genre_render_bm_backward_gather: + groups more elements behind it, the
- *                             row counters of its persistent workgroups)
+ *   tr_scratch fp32 [groups*nseg*64]: backward only
  * out / grad_out [N,1,R+2p,R+2p] (p = padding margin as above, any strides); pre_scale as above.
  * grad_vox must be batch-minor too (stride[0] == 1); every element is written exactly once. */
 int genre_render_bm_forward(const genre_tensor *vox, const genre_tensor *out, const genre_tensor *segs,
@@ -328,36 +335,6 @@ int genre_render_bm_backward(const genre_tensor *grad_out, const genre_tensor *g
                              const genre_tensor *depth_weight, const genre_tensor *ps_scratch,
                              const genre_tensor *tr_scratch, const genre_tensor *p_stash, const genre_tensor *mask,
                              float pre_scale, int pull_brick, void *stream);
-
-/* The same backward in GATHER form (csrc/sph_render_bm.hip: bm_gather_kernel): the voxel sums of a 4x8x8 brick live in
- * registers, the dL/dp of the samples that touch it are parked in LDS, and the adjoint of the trilinear interpolation is
- * a list per voxel of (sample line, weight) contributions -- tables g_ent int32 [E,4], g_chunks int32 [C,4], g_blob int32
- * [..], g_rows int32 [rows,4] of toolbox/_bm_tables.py (_gather_tables).  No LDS atomics.  Same inputs, outputs and
- * scratch buffers as genre_render_bm_backward; gradients equal to fp32 summation order. */
-int genre_render_bm_backward_gather(const genre_tensor *grad_out, const genre_tensor *grad_vox,
-                                    const genre_tensor *segs, const genre_tensor *ray_ptr,
-                                    const genre_tensor *ray_seg, const genre_tensor *ray_pre,
-                                    const genre_tensor *g_ent, const genre_tensor *g_chunks,
-                                    const genre_tensor *g_blob, const genre_tensor *g_rows,
-                                    const genre_tensor *depth_weight, const genre_tensor *ps_scratch,
-                                    const genre_tensor *tr_scratch, const genre_tensor *p_stash,
-                                    const genre_tensor *mask, float pre_scale, void *stream);
-
-/* The same backward in HALO form ("owner computes", round 4; csrc/sph_render_bm.hip: bm_scatter_kernel<HALO> +
- * bm_halo_combine_kernel): every 4x8x8 brick scatters the segments of its OWN samples -- each sample once, all eight corners,
- * no ownership masks -- into a 5x9x9-line fp64 tile, writes its brick to grad_vox and the 149 halo lines to halo_scratch;
- * a second kernel adds each brick's <= 7 neighbours' halo lines onto its low faces (and applies the clamp mask there).
- * Tables: the forward's segs / rec_f, h_ent int32 [nseg,4] = (scratch line, slot, L<<6 | L<<12 | k0<<18, slot) and h_rows
- * int32 [rows,4] = (brick, segment begin, segment end, shared) of toolbox/_bm_tables.py.
- * halo_scratch fp32 [groups * bricks * 149 * 32] (bricks = ceil(X/4) ceil(Y/8) ceil(Z/8)); other buffers as above. */
-int genre_render_bm_backward_halo(const genre_tensor *grad_out, const genre_tensor *grad_vox,
-                                  const genre_tensor *segs, const genre_tensor *ray_ptr,
-                                  const genre_tensor *ray_seg, const genre_tensor *ray_pre,
-                                  const genre_tensor *h_ent, const genre_tensor *rec_f,
-                                  const genre_tensor *h_rows, const genre_tensor *depth_weight,
-                                  const genre_tensor *ps_scratch, const genre_tensor *tr_scratch,
-                                  const genre_tensor *p_stash, const genre_tensor *mask,
-                                  const genre_tensor *halo_scratch, float pre_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -14,8 +14,14 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-m1 --no-train > "$OUT/bench_prof.json" 2> "$OUT/bench_prof.err"
 python "$ROOT/profiles/summarize_rocpd.py" "$OUT"/prof/bench_results.db > "$OUT/kernel_stats.txt" 2>&1 || python "$ROOT/profiles/summarize_rocpd.py" $(ls "$OUT"/prof/*/*_results.db | head -1) > "$OUT/kernel_stats.txt" 2>&1
-# kernel trace of pmc_targets.py alone: the batch-minor renderer there runs on the SOFT volume only (what roofline is quoted on;
-# in the bench trace above the same kernel names mix it with the GenRe volume, whose backward only writes zeros)
+# the headline `value` is the GenRe full-model forward: its own kernels, batch 1 and batch 8 (profiles/m1_target.py, eager launches)
+for b in 1 8; do
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_m1_b$b" -o m1 -- python "$ROOT/profiles/m1_target.py" $b 10 > /dev/null 2> "$OUT/prof_m1_b$b.err"
+python "$ROOT/profiles/summarize_rocpd.py" $(ls "$OUT"/prof_m1_b$b/m1_results.db "$OUT"/prof_m1_b$b/*/m1_results.db 2>/dev/null | head -1) > "$OUT/m1_b${b}_kernel_stats.txt" 2>&1
+rm -rf "$OUT/prof_m1_b$b"
+done
+# kernel trace of pmc_targets.py alone: the renderers run there in two phases, GenRe's own volume (what the timed step renders and
+# `roofline` is quoted on) then the soft volume (`roofline_soft`); min_us / max_us of a kernel's row are the two phases
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_t" -o targets -- python "$ROOT/profiles/pmc_targets.py" "$B" 16 > /dev/null 2> "$OUT/prof_t.err"
 python "$ROOT/profiles/summarize_rocpd.py" $(ls "$OUT"/prof_t/targets_results.db "$OUT"/prof_t/*/targets_results.db 2>/dev/null | head -1) > "$OUT/kernel_stats_soft.txt" 2>&1
 rm -rf "$OUT/prof_t"
@@ -29,7 +35,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAI
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU -d "$OUT/pmc_s2" -o sq2 -- python "$ROOT/profiles/pmc_targets.py" "$B" > /dev/null 2> "$OUT/pmc_s2.err"
 S1=$(ls "$OUT"/pmc_s1/sq1_results.db "$OUT"/pmc_s1/*/sq1_results.db 2>/dev/null | head -1)
 S2=$(ls "$OUT"/pmc_s2/sq2_results.db "$OUT"/pmc_s2/*/sq2_results.db 2>/dev/null | head -1)
-python "$ROOT/profiles/pmc_sq_table.py" $S1 $S2 -- bm_scatter_kernel bm_gather_kernel bm_sample_kernel bm_combine cam_brick > "$OUT/sq_counters.txt" 2>&1
+python "$ROOT/profiles/pmc_sq_table.py" $S1 $S2 -- bm_scatter_kernel bm_sample_kernel bm_combine cam_brick render_sample_brick render_bwd_brick > "$OUT/sq_counters.txt" 2>&1
 # the bench line of the same build reads the table just measured (roofline.traffic must not be null in a committed line)
 cp "$OUT/pmc_hbm_traffic.json" "$ROOT/profiles/${TAG}_pmc_hbm_traffic.json"
 cd "$ROOT" && T0=$(date +%s) && python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench.py wall time: $(( $(date +%s) - T0 )) s" >> "$OUT/bench.err"

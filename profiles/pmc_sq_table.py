@@ -14,16 +14,32 @@ def read(db):
     cur = con.cursor()
     view = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")
             if r[0].startswith("counters_collection")][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({view})")]
+    order = " order by dispatch_id" if "dispatch_id" in cols else ""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for name, cname, value in cur.execute(f"select kernel_name, counter_name, value from {view}"):
+    for name, cname, value in cur.execute(f"select kernel_name, counter_name, value from {view}{order}"):
         acc[name][cname].append(value)
-    return acc
+    # the renderers run in two phases in pmc_targets.py (GenRe's own volume, then the soft volume): split by dispatch order
+    out = collections.defaultdict(dict)
+    for name, counters in acc.items():
+        for c, vals in counters.items():
+            if any(k in name for k in PHASED) and len(vals) >= 2 and len(vals) % 2 == 0:
+                out[name + "@genre"][c], out[name + "@soft"][c] = vals[:len(vals) // 2], vals[len(vals) // 2:]
+            else:
+                out[name][c] = vals
+    return out
+
+
+PHASED = ("bm_sample_kernel", "bm_combine_fwd_kernel", "bm_combine_bwd_kernel", "bm_scatter_kernel", "bm_zero_shared_kernel",
+          "render_sample_brick_group_kernel", "render_scan_fwd_kernel", "render_scan_bwd_kernel", "render_bwd_brick_kernel",
+          "zero_shared_bricks_kernel")
 
 
 def short(name):
+    name, _, phase = name.partition("@")
     name = re.sub(r"genre::\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    return name.split("(")[0]
+    return name.split("(")[0] + ("@" + phase if phase else "")
 
 
 sep = sys.argv.index("--")

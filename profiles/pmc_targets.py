@@ -42,37 +42,47 @@ layer = G.Camera_back_projection_layer(batch_minor=True).to(dev)
 with torch.no_grad():
     proj_bm = layer(d)
 TB = _fused_render.bm_tables_for(proj_bm.shape, dev, mod._dirs64, mod.depth_weight) if B >= 16 else None
+cnt_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev) if B >= 16 else None
 if TB is not None:
     groups = -(-B // 32)
     ps = torch.empty((groups * TB["segs"].shape[0] * 64,), device=dev)
-    trs = torch.empty((ps.numel() + 64,), device=dev)      # + the gather kernel's row counters
+    trs = torch.empty((ps.numel(),), device=dev)
     stash = torch.empty((groups * TB["rec_f"].shape[0] * 32,), device=dev)
     mask = torch.empty((groups * 128 ** 3 + groups,), dtype=torch.int32, device=dev)
     out_p = torch.empty((B, 1, 160, 160), device=dev)
     gout_p = torch.randn_like(out_p)
     gvox_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
-    # the batch-minor renderer is profiled on the SOFT volume (every sample passes the clamps: a gradient everywhere) --
-    # bench.py: kernels.render_bwd_bm_soft, what `roofline` is quoted on.  On GenRe's own volume the x50 clamp blocks every
-    # voxel and the backward kernels only write zeros (kernels.render_bwd_bm).
-    gsoft = torch.Generator(device="cpu").manual_seed(1)
+# The two renderers are profiled in TWO PHASES (round 5): first on GenRe's own volume -- what the timed hot-path step renders;
+# the x50 clamp blocks every voxel there, the backward kernels write zeros (bench.py: kernels.render_fwd_bm / render_bwd_bm /
+# render_bwd_fused, and `roofline`) -- then on the SOFT volume (every sample passes the clamps: a gradient everywhere;
+# kernels.*_soft, `roofline_soft`).  pmc_traffic_table.py splits every renderer kernel's dispatches into the two halves
+# ("name@genre", "name@soft") by dispatch order.
+live = torch.empty((B * (1 + 512),), dtype=torch.int32, device=dev)
+proj_std = torch.empty_like(tdf)
+cam_bp_lib.back_projection_forward_shifted(d, cd, fl, proj_std, cnt)
+gsoft = torch.Generator(device="cpu").manual_seed(1)
+soft_std = ((torch.rand(tdf.shape, generator=gsoft) * 0.9 + 0.05) * 0.02).to(dev)
+soft_bm = None
+if TB is not None:
     soft_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
-    soft_bm.copy_(((torch.rand(proj_bm.shape, generator=gsoft) * 0.9 + 0.05) * 0.02).to(dev))
+    soft_bm.copy_(soft_std)
 for _ in range(ITERS):
     cam_bp_lib.back_projection_forward_shifted(d, cd, fl, tdf, cnt)
     calc_prob_lib.calc_prob_forward(p, s)
     calc_prob_lib.calc_prob_backward_fused(p, s, g, o)
-    lib.render_spherical_forward(tdf, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0)
-    lib.render_spherical_backward(tdf, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"],
-                                  vbuf, T["kin"], 50.0)
     if TB is not None:
-        lib.render_bm_forward(soft_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"], TB["ray_seg"],
-                              TB["ray_pre"], ps, stash, mask, 50.0)
-        lib.render_bm_backward(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"],
-                               TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, trs, stash, mask, 50.0, TB["pull_code"])
-        if "g_ent" in TB:
-            lib.render_bm_backward_gather(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"],
-                                          TB["g_ent"], TB["g_chunks"], TB["g_blob"], TB["g_rows"], mod.depth_weight, ps,
-                                          trs, stash, mask, 50.0)
+        cam_bp_lib.back_projection_forward_shifted(d, cd, fl, proj_bm, cnt_bm)        # the three-launch path of image-minor volumes
+for vol_std, vol_bm in ((proj_std, proj_bm), (soft_std, soft_bm)):
+    for _ in range(ITERS):
+        lib.render_spherical_forward(vol_std, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"],
+                                     50.0, live)
+        lib.render_spherical_backward(vol_std, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"],
+                                      vbuf, T["kin"], 50.0, live)
+        if TB is not None:
+            lib.render_bm_forward(vol_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"], TB["ray_seg"],
+                                  TB["ray_pre"], ps, stash, mask, 50.0)
+            lib.render_bm_backward(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"],
+                                   TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, trs, stash, mask, 50.0, TB["pull_code"])
 # Chamfer forward (VALU-bound: used with --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ...)
 from genre_shapehd_amd.toolbox.nndistance._ext import my_lib  # noqa: E402
 xa = torch.rand((B, 2048, 3), device=dev)

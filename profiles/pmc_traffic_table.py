@@ -21,27 +21,44 @@ WIDE_STREAMS = ("fill2_vec4_kernel", "stop_fwd_vec4_kernel", "stop_bwd_vec4_kern
 FETCH_FACTOR = 2
 
 
+# the renderers' kernels run in two phases in pmc_targets.py (GenRe's own volume, then the soft volume): the first half of a
+# kernel's dispatches becomes the row "name@genre", the second half "name@soft"
+PHASED = ("bm_sample_kernel", "bm_combine_fwd_kernel", "bm_combine_bwd_kernel", "bm_scatter_kernel", "bm_zero_shared_kernel",
+          "render_sample_brick_group_kernel", "render_scan_fwd_kernel", "render_scan_bwd_kernel", "render_bwd_brick_kernel",
+          "zero_shared_bricks_kernel")
+
+
 def per_kernel(db, counter):
     con = sqlite3.connect(db)
     cur = con.cursor()
     view = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")
             if r[0].startswith("counters_collection")][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({view})")]
+    order = " order by dispatch_id" if "dispatch_id" in cols else ""
     acc = collections.defaultdict(list)
-    for name, cname, value in cur.execute(f"select kernel_name, counter_name, value from {view}"):
+    for name, cname, value in cur.execute(f"select kernel_name, counter_name, value from {view}{order}"):
         if cname == counter:
             acc[name].append(value)
-    return acc
+    out = {}
+    for name, vals in acc.items():
+        if any(k in name for k in PHASED) and len(vals) >= 2 and len(vals) % 2 == 0:
+            half = len(vals) // 2
+            out[name + "@genre"], out[name + "@soft"] = vals[:half], vals[half:]
+        else:
+            out[name] = vals
+    return out
 
 
 def short(name):
+    name, _, phase = name.partition("@")
     name = re.sub(r"genre::\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    return name.split("(")[0]
+    return name.split("(")[0] + ("@" + phase if phase else "")
 
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
-print("%-40s %10s %14s %14s %6s %12s" % ("kernel", "dispatches", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "xF", "HBM_MB"))
+print("%-52s %10s %14s %14s %6s %12s" % ("kernel", "dispatches", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "xF", "HBM_MB"))
 table = {}
 for k in sorted(set(fetch) | set(write), key=short):
     if "genre" not in k:
@@ -51,7 +68,7 @@ for k in sorted(set(fetch) | set(write), key=short):
     factor = FETCH_FACTOR
     hbm = (factor * f + w) * 1024
     table[short(k)] = dict(dispatches=len(fetch.get(k, [])), fetch_kb=f, write_kb=w, fetch_factor=factor, hbm_bytes=hbm)
-    print("%-40s %10d %14.0f %14.0f %6d %12.1f" % (short(k)[:40], len(fetch.get(k, [])), f, w, factor, hbm / 1e6))
+    print("%-52s %10d %14.0f %14.0f %6d %12.1f" % (short(k)[:52], len(fetch.get(k, [])), f, w, factor, hbm / 1e6))
 if len(sys.argv) > 3:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench

@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libgenre_hip.so does not export %s" % s
     lib.genre_abi_version.restype = C.c_int
-    assert lib.genre_abi_version() == 3
+    assert lib.genre_abi_version() == 4
 
 
 def test_every_symbol_cites_the_reference_interface():
@@ -80,16 +80,16 @@ def test_validation_errors_do_not_launch(genre):
     assert rc == 0 and b"depth_minmax" in lib.genre_last_error()
     rc = lib.genre_abs_depth_forward(C.byref(m), C.byref(mm), C.byref(m), C.byref(desc((2, 1, 6, 8))), 0.0, None)
     assert rc == 0 and b"scale_25d" in lib.genre_last_error()
-    lib.genre_render_spherical_forward.argtypes = [C.c_void_p] * 8 + [C.c_float, C.c_void_p]
+    lib.genre_render_spherical_forward.argtypes = [C.c_void_p] * 9 + [C.c_float, C.c_void_p]
     dirs, dw = desc((8, 8, 6)), desc((16,))
     rc = lib.genre_render_spherical_forward(C.byref(vox), C.byref(dirs), C.byref(dw), C.byref(desc((1, 1, 11, 11))),
-                                            None, None, None, None, 0.0, None)          # odd padding
+                                            None, None, None, None, None, 0.0, None)    # odd padding
     assert rc == 0 and b"R+2p" in lib.genre_last_error()
     rc = lib.genre_render_spherical_forward(C.byref(vox), C.byref(dirs), C.byref(dw), C.byref(desc((1, 1, 12, 12))),
-                                            None, None, None, None, 0.0, None)          # padded map without the tables
+                                            None, None, None, None, None, 0.0, None)    # padded map without the tables
     assert rc == 0 and b"brick path" in lib.genre_last_error()
-    # batch-minor renderer backward: ABI 3 wants one word per image group behind the clamp masks; the halo form checks its
-    # own tables and scratch (nothing is launched: every call fails validation)
+    # batch-minor renderer backward: one word per image group behind the clamp masks (since ABI 3; nothing is launched: the
+    # call fails validation)
     def bm_vol(n, x, y, z):
         d = T()
         d.data, d.ndim, d.dtype = 0x1000, 5, 0
@@ -105,13 +105,6 @@ def test_validation_errors_do_not_launch(genre):
     args = [C.byref(a) for a in (gout, gvox, segs, rptr, rseg, rpre, ent, rec, rows, dwt, ps, tr, stash)]
     rc = lib.genre_render_bm_backward(*args, C.byref(desc((8 * 8 * 8,), 1)), 50.0, 488, None)      # masks without the group word
     assert rc == 0 and b"+ groups" in lib.genre_last_error()
-    lib.genre_render_bm_backward_halo.argtypes = [C.c_void_p] * 15 + [C.c_float, C.c_void_p]
-    mask = desc((8 * 8 * 8 + 1,), 1)
-    rc = lib.genre_render_bm_backward_halo(*args[:6], C.byref(desc((nseg - 1, 4), 1)), *args[7:], C.byref(mask),
-                                           C.byref(desc((2 * 149 * 32,))), 50.0, None)               # h_ent: one row per segment
-    assert rc == 0 and b"h_ent" in lib.genre_last_error()
-    rc = lib.genre_render_bm_backward_halo(*args, C.byref(mask), C.byref(desc((2 * 149 * 32 - 1,))), 50.0, None)   # 2 bricks x 149 lines
-    assert rc == 0 and b"halo_scratch" in lib.genre_last_error()
     # empty problems succeed without launching anything
     e = desc((0, 1, 8, 8))
     ev = desc((0, 1, 4, 4, 4))

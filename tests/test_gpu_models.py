@@ -109,6 +109,34 @@ def test_genre_end_to_end_and_graph_replay(pair, dev):
     assert (a - c).abs().max().item() > 1e-3 * scale                      # the static inputs really are refreshed
 
 
+def test_genre_geometry_follows_the_batch_size_into_the_batch_minor_layout(pair, dev):
+    """DepthInpaintNet picks the volume's memory layout from the batch size (models/genre.py): at batch 16 the projected
+    volume is image-minor and the renderer's tile kernels run; the geometry outputs equal the NCXYZ path's on the same
+    MarrNet-1 output (multi-hit voxels: float-atomic order, as in test_camera_layer_batch_minor_option)"""
+    from genre_shapehd_amd.models import Inputs
+    gpu = pair[1]
+    di = gpu.depth_and_inpaint
+    rgb, sil = _inputs(16, seed=21)
+    with torch.no_grad():
+        o = di.net1(Inputs(rgb.to(dev), sil.to(dev)))
+        o["depth"] = 50 + 10 * torch.tanh(o["depth"])
+        o["depth_minmax"] = torch.tensor([[1.9, 2.5]], device=dev).repeat(16, 1)
+        d = di.get_abs_depth(o, Inputs(None, sil.to(dev)))
+        proj = di.proj_depth(d)
+        assert proj.stride(0) == 1 and not proj.is_contiguous()         # image-minor at batch 16 ...
+        assert di.proj_depth(d[:8]).is_contiguous()                      # ... NCXYZ at the reference's batch sizes
+        sph = di.render_spherical(proj, pre_scale=50.0, pad=16)
+        std = type(di.proj_depth)()(d)
+        assert std.is_contiguous() and (std - proj).abs().max().item() <= 128e-5
+        assert (di.render_spherical(std, pre_scale=50.0, pad=16) - sph).abs().max().item() <= 1e-5
+        from genre_shapehd_amd.callers import RefinerInput
+        full = torch.rand(16, 1, 160, 160, device=dev) * 0.4 + 0.3
+        grid = gpu.grid.expand(16, -1, -1, -1, -1)
+        ri_bm, _ = RefinerInput.apply(full, grid, proj * 50, 16)        # the refiner input is NCXYZ whatever proj's layout
+        ri_std, _ = RefinerInput.apply(full, grid, std * 50, 16)
+        assert ri_bm.is_contiguous() and (ri_bm - ri_std).abs().max().item() <= 128e-5
+
+
 def test_projection_gradients_of_the_joint_step_against_the_cpu_chain(oracle, dev):
     """What reaches MarrNet-1's depth map THROUGH THE GEOMETRY in the joint step (genre_full_model.py:122-131,
     depth_pred_with_sph_inpaint.py:120-129), branch by branch, against the reference's lines on CPU torch + the oracle

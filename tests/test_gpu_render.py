@@ -162,7 +162,7 @@ def _batch_minor(t):
 @pytest.mark.parametrize("n,pre_scale,pad", [(32, None, 0), (32, 20.0, 16), (19, 20.0, 16), (40, None, 16)])
 def test_batch_minor_layout_matches_standard(n, pre_scale, pad, genre, dev):
     """the same logical volume with the image index fastest in memory takes the batch-minor kernels (half-wave =
-    32 images of one sample, serial per-lane scans, gather backward): values agree with the standard path to fp32
+    32 images of one sample, serial per-lane scans, pull-scatter backward): values agree with the standard path to fp32
     rounding (the scan order differs), gradients to 1e-5 of their maximum"""
     rng = np.random.default_rng(31)
     vox = torch.from_numpy(rng.uniform(0.0, 0.05, (n, 1, 128, 128, 128)).astype(np.float32)).to(dev)
@@ -208,13 +208,64 @@ def test_batch_minor_backward_skips_what_the_clamp_blocks(genre, dev):
     out_a.backward(g)
     out_b.backward(g)
     assert torch.count_nonzero(b.grad[:32]).item() == 0
-    # (the standard-layout path turns the whole gradient of the image with the NaN upstream gradient into NaN -- its per-image
-    # fixed-point scale is NaN; PyTorch 0.4.1's clamp backward, a product with the mask, does the same -- the others are zero)
-    others = [i for i in range(32) if i != 3]
-    assert torch.count_nonzero(a.grad[others]).item() == 0 and torch.isnan(a.grad[3]).all()
+    # (the standard-layout path skips the same work since round 5 -- csrc/sph_render.hip: live words -- and its clamp adjoint is
+    # the same select: zero for all 32 images, the one with the NaN upstream gradient included.  PyTorch 0.4.1's clamp
+    # backward was a product with the mask and would have returned NaN there: a documented deviation on non-finite input)
+    assert torch.count_nonzero(a.grad[:32]).item() == 0
     scale = a.grad[32:].abs().max().item()
     assert scale > 0 and torch.count_nonzero(b.grad[32:, :, 44:56, 56:64, 40:80]).item() == 0
     assert (a.grad[32:] - b.grad[32:]).abs().max().item() <= 1e-5 * max(1.0, scale)
+
+
+def test_standard_layout_backward_skips_what_the_clamp_blocks(genre, dev):
+    """csrc/sph_render.hip, round 5: with pre_scale the forward leaves one word per image and per 16^3 brick ("some voxel
+    passes clamp(x * pre_scale)"), and the backward writes zeros for what the clamp blocks instead of computing it.  Five
+    images (an odd count: the last sampler group holds one image), dead ones -- GenRe's own chain -- between live ones whose
+    saturated blocks cover whole bricks: the gradient with the live words is BIT-IDENTICAL to the gradient computed in full
+    (live = None), and the words are what the volume says."""
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    rng = np.random.default_rng(41)
+    d = torch.from_numpy(inputs.batch_depth(2)).to(dev)
+    with torch.no_grad():
+        proj = genre.Camera_back_projection_layer().to(dev)(d)                       # 1 - 128 tdf: 0 or >= 0.13
+    soft = torch.from_numpy(rng.uniform(0.001, 0.019, (3, 1, 128, 128, 128)).astype(np.float32)).to(dev)
+    soft[:, :, 32:64, 48:80, 16:96] = 0.9                              # whole 16^3 bricks saturated ...
+    soft[1, :, 70:75, 3:9, 100:128] = 0.9                              # ... and a block that covers none
+    soft[2, :, 0:96] = 0.0                                             # most of an image below the lower bound
+    vox = torch.stack((proj[0], soft[0], soft[1], proj[1], soft[2]), 0).contiguous()
+    n = vox.shape[0]
+    mod = genre.render_spherical().to(dev)
+    lib = F._loader().render_lib
+    T = F.tables_for(vox.shape, dev, mod._dirs64, mod.z_res)
+    dirs = mod._dirs64.view(torch.float32)
+    g = torch.from_numpy(rng.standard_normal((n, 1, 160, 160)).astype(np.float32)).to(dev)
+    nb = 8 * 8 * 8
+    grads, maps = [], []
+    for use_live in (False, True):
+        out = torch.empty((n, 1, 160, 160), device=dev)
+        v = torch.empty((n * 128 * 128 * 256,), device=dev)
+        live = torch.full((n * (1 + nb),), 7, dtype=torch.int32, device=dev) if use_live else None
+        lib.render_spherical_forward(vox, dirs, mod.depth_weight, out, v, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0, live)
+        gv = torch.full_like(vox, float("nan"))
+        scratch = torch.empty((v.numel() + n,), device=dev)
+        lib.render_spherical_backward(vox, dirs, mod.depth_weight, g, gv, scratch, T["bwd_table"], T["bwd_chunks"], v, T["kin"],
+                                      50.0, live)
+        grads.append(gv)
+        maps.append(out)
+    assert torch.equal(maps[0], maps[1])
+    assert torch.equal(grads[0], grads[1])                              # NaN prefill: every voxel was written, identically
+    assert torch.count_nonzero(grads[1][[0, 3]]).item() == 0 and grads[1][[1, 2, 4]].abs().max().item() > 0
+    # the words themselves, against the volume
+    lv = live.view(n, 1 + nb).cpu()
+    t = vox * 50
+    passes = ((t >= 1e-5) & (t <= 1 - 1e-5)).view(n, 8, 16, 8, 16, 8, 16).permute(0, 1, 3, 5, 2, 4, 6).reshape(n, nb, -1).any(-1).cpu()
+    assert torch.equal(lv[:, 1:] != 0, passes)
+    assert torch.equal(lv[:, 0] != 0, passes.any(-1)) and lv[:, 0].tolist() == [0, 1, 1, 0, 1]
+    assert (~passes[1]).sum().item() >= 2 * 2 * 5                       # image 1 has dead bricks (its saturated block)
+    # ... and through autograd (RenderSphericalFused allocates the words when a gradient is wanted)
+    x = vox.clone().requires_grad_(True)
+    mod(x, pre_scale=50.0, pad=16).backward(g)
+    assert torch.equal(x.grad, grads[0])
 
 
 def test_camera_layer_batch_minor_option(genre, dev):

@@ -133,17 +133,15 @@ def test_non_finite_upstream_gradient_is_not_swallowed(layout, genre, dev):
     assert torch.isnan(grad[3]).any() and torch.isnan(grad[5]).any()
 
 
-@pytest.mark.parametrize("bwd", ["gather", "scatter", "halo"])
 @pytest.mark.parametrize("n,res,sph,zr,pre_scale,pad", [(16, 32, 24, 64, None, 0), (32, 32, 24, 64, None, 0),
                                                        (17, 33, 20, 100, 3.0, 4), (40, 24, 16, 32, None, 8),
                                                        (16, 13, 8, 12, 2.0, 0)])
-def test_batch_minor_small_geometry_against_oracle(n, res, sph, zr, pre_scale, pad, bwd, genre, oracle, dev, monkeypatch):
+def test_batch_minor_small_geometry_against_oracle(n, res, sph, zr, pre_scale, pad, genre, oracle, dev):
     """the batch-minor kernels (forward and backward) directly against the CPU reference chain at sizes the oracle
     finishes in a second, every image checked: volumes that are not a multiple of the 4x8x8 brick (partial bricks,
     tiles that stick out of the volume), batches that are not a multiple of 32 (a partly filled image group, two
     groups), short rays, the folded clamp and the padded map"""
     from oracle.torch_oracle import RenderSphericalCPU, RenderSphericalExact, sph_pad
-    monkeypatch.setenv("GENRE_BM_BWD", bwd)                              # both forms of the backward (csrc/sph_render_bm.hip)
     rng = np.random.default_rng(90 + n + res)
     ax = (np.arange(res) + 0.5) / res - 0.5
     vols = np.empty((n, 1, res, res, res), np.float32)
@@ -169,67 +167,6 @@ def test_batch_minor_small_geometry_against_oracle(n, res, sph, zr, pre_scale, p
     assert (out.detach().cpu() - ref.detach()).abs().max().item() <= TOL
     err = ((xb.grad.cpu() - vc.grad).abs() / vc.grad.abs().clamp(min=max(1.0, pre_scale or 1.0))).max().item()
     assert err <= TOL, err
-
-
-@pytest.mark.parametrize("n,pre_scale,pad", [(32, 50.0, 16), (19, None, 0), (40, 50.0, 0)])
-def test_batch_minor_gather_backward_equals_the_scatter_backward(n, pre_scale, pad, volumes, genre, dev, monkeypatch):
-    """the two forms of the batch-minor backward -- voxel sums in registers over per-voxel contribution lists
-    (bm_gather_kernel, fp32 partial sums per chunk and row) vs LDS fp64 atomics (bm_scatter_kernel) -- from the same saved
-    state: equal to fp32 summation order on every voxel of every image (GenRe-class volumes, gradient scales
-    1 ... 2^-24); measured on MI355X: 5e-6 of max(|g|, the image's scale) -- half of the 1e-5 parity bar, one more reason
-    why the gather form is opt-in"""
-    vols = np.concatenate([volumes["sharp"], volumes["soft"][:8]])[:n].copy()
-    if pre_scale is not None:
-        vols = (vols / np.float32(pre_scale)).astype(np.float32)
-    side = 128 + 2 * pad
-    scales = _g_scales(n)
-    g = torch.from_numpy((np.random.default_rng(5).standard_normal((n, 1, side, side)).astype(np.float32)
-                          * scales[:, None, None, None]).astype(np.float32)).to(dev)
-    mod = genre.render_spherical(fused=True).to(dev)
-    grads = {}
-    for mode in ("scatter", "gather"):
-        monkeypatch.setenv("GENRE_BM_BWD", mode)
-        x = _batch_minor(torch.from_numpy(vols).to(dev)).requires_grad_(True)
-        mod(x, pre_scale=pre_scale, pad=pad).backward(g)
-        grads[mode] = x.grad.clone()
-    a, b = grads["gather"], grads["scatter"]
-    assert torch.isfinite(a).all()
-    s = torch.from_numpy(scales).to(dev).view(n, 1, 1, 1, 1) * max(1.0, pre_scale or 1.0)
-    rel = ((a - b).abs() / torch.maximum(b.abs(), s)).amax(dim=(1, 2, 3, 4))
-    print("gather vs scatter, worst image: %.2e" % rel.max().item())
-    assert rel.max().item() <= 1e-5, rel
-
-
-@pytest.mark.parametrize("n,pre_scale,pad", [(32, 50.0, 16), (19, None, 0), (40, 50.0, 0), (33, 20.0, 0)])
-def test_batch_minor_halo_backward_equals_the_scatter_backward(n, pre_scale, pad, volumes, genre, dev, monkeypatch):
-    """the halo ("owner computes") form of the batch-minor backward -- every brick scatters its own samples into a tile with
-    halo, a second kernel adds the neighbours' halo lines (bm_scatter_kernel<HALO> + bm_halo_combine_kernel) -- against
-    the pull form: the same fp64 tile sums, rounded to fp32 per brick and added in fp32 over <= 8 bricks instead of once:
-    within 1e-5 of max(|g|, the image's scale) on every voxel of every image (measured on MI355X: 5e-7 ... 2.6e-6;
-    GenRe-class volumes, gradient scales 1 ... 2^-24, partly filled image groups)"""
-    vols = np.concatenate([volumes["sharp"], volumes["soft"][:8]])
-    vols = np.concatenate([vols] * (1 + n // vols.shape[0]))[:n].copy()
-    if pre_scale is not None:
-        vols = (vols / np.float32(pre_scale)).astype(np.float32)
-        if pre_scale == 20.0:
-            vols[:, :, 40:60, 50:70, 30:90] = 0.9                      # a block the clamp saturates: dead tiles beside live ones
-    side = 128 + 2 * pad
-    scales = _g_scales(n)
-    g = torch.from_numpy((np.random.default_rng(5).standard_normal((n, 1, side, side)).astype(np.float32)
-                          * scales[:, None, None, None]).astype(np.float32)).to(dev)
-    mod = genre.render_spherical(fused=True).to(dev)
-    grads = {}
-    for mode in ("scatter", "halo"):
-        monkeypatch.setenv("GENRE_BM_BWD", mode)
-        x = _batch_minor(torch.from_numpy(vols).to(dev)).requires_grad_(True)
-        mod(x, pre_scale=pre_scale, pad=pad).backward(g)
-        grads[mode] = x.grad.clone()
-    a, b = grads["halo"], grads["scatter"]
-    assert torch.isfinite(a).all()
-    s = torch.from_numpy(scales).to(dev).view(n, 1, 1, 1, 1) * max(1.0, pre_scale or 1.0)
-    rel = ((a - b).abs() / torch.maximum(b.abs(), s)).amax(dim=(1, 2, 3, 4))
-    print("halo vs scatter, worst image: %.2e" % rel.max().item())
-    assert rel.max().item() <= 1e-5, rel
 
 
 def test_clamp_boundary_gradient_is_characterised(genre, oracle, dev):

@@ -136,13 +136,6 @@ def worker_bm(tag):
         lib.render_bm_backward(gout, gvox, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"], TB["rec_b"],
                                TB["bwd_rows"], mod.depth_weight, ps, tr, stash, mask if scale else None, scale,
                                TB["pull_code"])
-    nbk = 32 * 16 * 16
-    halo = torch.empty((groups * nbk * 149 * 32,), device=dev)
-
-    def bwd_halo(scale):
-        lib.render_bm_backward_halo(gout, gvox, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["h_ent"],
-                                    TB["rec_f"], TB["h_rows"], mod.depth_weight, ps, tr, stash, mask if scale else None,
-                                    halo, scale)
     g = torch.Generator(device="cpu").manual_seed(1)
     soft = _fused_render.empty_batch_minor(proj.shape, torch.float32, dev)
     soft.copy_((torch.rand(proj.shape, generator=g) * 0.9 + 0.05).to(dev))
@@ -157,12 +150,6 @@ def worker_bm(tag):
         res[name + "_fwd_us"] = round(event_us(lambda: fwd(vol, True, scale), 30, 3), 1)
         fwd(vol, True, scale)
         res[name + "_bwd_us"] = round(min(event_us(lambda: bwd(scale), 30, 3) for _ in range(2)), 1)
-        if "h_ent" in TB:
-            bwd_halo(scale)
-            torch.cuda.synchronize()
-            den = max(1e-30, outs[name + "_gv"].abs().max().item())
-            res[name + "_halo_vs_scatter"] = "%.1e" % ((gvox.cpu() - outs[name + "_gv"]).abs().max().item() / den)
-            res[name + "_bwd_halo_us"] = round(min(event_us(lambda: bwd_halo(scale), 30, 3) for _ in range(2)), 1)
     res["max|g| soft50"] = float(outs["soft50_gv"].abs().max())
     res["max|g| genre"] = float(outs["genre_gv"].abs().max())
     ref_path = "/tmp/ab4_bm_ref.pt"
