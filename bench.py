@@ -276,15 +276,18 @@ def kernel_table(G, dev, B):
             layer = G.Camera_back_projection_layer(batch_minor=True).to(dev)
             with torch.no_grad():
                 proj_bm = layer(d)
-            # the camera forward the batch-minor STEP runs: image-minor volumes have no contiguous z rows, so it is the
-            # three-launch path (fill, tile scatter with global float atomics, per-pixel normalise), not cam_brick_kernel
-            # (the deterministic single-launch alternative, GENRE_CAMBP_MODE=imageminor, measured 2.2x slower: DESIGN 3.1)
+            # the camera forward the batch-minor STEP runs (the layer's call: camera by value): image-minor volumes have no
+            # contiguous z rows for cam_brick_kernel, so fill + the deterministic leader pass (round 5: no atomics, bit-identical
+            # to a serial evaluation of the reference); `cam_bp_fwd_bm_atomics` = the path it replaced there and that tensor
+            # cameras still take (fill, tile scatter with global float atomics, per-pixel normalise)
             cnt_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
+            t = event_time_us(lambda: cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True), iters, 5)
+            rows["cam_bp_fwd_bm"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="fill2_vec4_kernel+cam_leader_kernel<2>",
+                                         pmc=["fill2_vec4_kernel", "cam_leader_kernel<2>"], src=("common.hpp", "cam_bp.hip"))
             t = event_time_us(lambda: cam_bp_lib.back_projection_forward_shifted(d, cd, fl, proj_bm, cnt_bm), iters, 5)
-            rows["cam_bp_fwd_bm"] = dict(us=t, bytes=B * BYTES_CAM_FWD,
-                                         kernels="fill2_vec4_kernel+scatter_tile_kernel<false>+normalise_tile_kernel<false>",
-                                         pmc=["fill2_vec4_kernel", "scatter_tile_kernel<false>", "normalise_tile_kernel<false>"],
-                                         src=("common.hpp", "cam_bp.hip"))
+            rows["cam_bp_fwd_bm_atomics"] = dict(us=t, bytes=B * BYTES_CAM_FWD,
+                                                 kernels="fill2_vec4_kernel+scatter_tile_kernel<false>+normalise_tile_kernel<false>")
+            cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True)
             TB = _fused_render.bm_tables_for(proj_bm.shape, dev, mod._dirs64, mod.depth_weight)
             groups = -(-B // 32)
             ps = torch.empty((groups * TB["segs"].shape[0] * 64,), device=dev)

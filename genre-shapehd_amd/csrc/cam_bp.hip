@@ -748,137 +748,108 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
         }
     }
 }
-
-// ---- camera forward for IMAGE-MINOR volumes (round 4): one launch, LDS bricks, deterministic ---------------------------
-// Volumes whose image index is fastest in memory (element (n,x,y,z) at x*sx + y*sy + z*sz + n: what the batch-minor
-// renderer wants, csrc/sph_render_bm.hip) have no contiguous z rows, so cam_brick_kernel cannot write them and the
-// three-launch path (fill, tile scatter with GLOBAL float atomics in undefined order, per-pixel normalise) serves them:
-// 149 us at batch 32, not run-to-run deterministic.  This kernel is the deterministic alternative (opt-in,
-// GENRE_CAMBP_MODE=imageminor: measured 335 us, forward_impl).  A workgroup owns a 4 x 4 x 8 voxel brick FOR A GROUP OF 32 IMAGES:
-//   * sums [128 voxels][32 images] fp64 + counts u32 in LDS (48 KB; ds_add_f64 as in cam_brick_kernel);
-//   * wave w takes images w, w + 4, ... of the group; for each image the brick's pixel footprint (~10 x 18 px at 128^3 /
-//     256^2 / the GenRe camera) is loaded -- all of a wave's images up front, three 64-pixel rounds each in registers -- and
-//     every pixel goes through the plane-depth test and, if it survives, the reference's arithmetic (pixel_voxel); a point that
-//     lands in the brick is added to [voxel][image];
-//   * flush: a voxel's 32 images are one 128-byte line of the output, eight z-neighbours 1 KB contiguous: float4 stores of
-//     the normalised value (K2, :291-305, exactly cam_brick_kernel's expression) and of the count.
-// Same values as cam_brick_kernel writes into an NCXYZ volume, bit for bit (sums of exact fp32 distances in fp64 are
-// order-independent here: 37 significant bits + the count fit the 53 of a double), so the two layouts agree exactly and the
-// result does not depend on the batch an image travels in.
-constexpr int kMX = 4, kMY = 4, kMZ = 8, kMVox = kMX * kMY * kMZ, kMImgs = 32, kMRounds = 3;
-
-template <bool BYVAL>
-__global__ __launch_bounds__(kBlock) void cam_bm_brick_kernel(Dims D, View4 depth, View2 camdist, View2 fl, View5 vox, View5 cnt,
-                                                              float prefill, float bias, float post_scale, float post_bias,
-                                                              float fill_val, float fl_val, float cd_val)
+// ---- camera forward for volumes WITHOUT contiguous z rows (image-minor, strided): fill + LEADER pass, no atomics (round 5) ----
+// The batch-minor renderer wants the volume image-minor (element (n,x,y,z) at x*sx + y*sy + z*sz + n): no z rows for the brick
+// kernel above, and until round 5 such outputs took fill + scatter_tile_kernel + normalise_tile_kernel -- hardware float
+// atomics in undefined order, like the reference.  When the camera is passed BY VALUE (one camera for the whole batch: what
+// Camera_back_projection_layer does, camera_backprojection_module.py:12-21) the host can bound how far apart, in pixels, two
+// points of one voxel can lie: |du| <= f (dy / x_min + |y|_max dx / x_min^2) with dy, dx <= one voxel, |y| <= 1/2 and
+// x_min = cam_dist - 1/2 the nearest in-grid plane -- 2.49 px for f = 418.3, cam_dist = 2.2, res = 128, so contributors of one
+// voxel lie within +-2 pixels of one another.  A wave then owns an 8x8 pixel tile: it evaluates the reference's per-pixel
+// arithmetic (pixel_voxel) once for every pixel of the tile AND of a halo of HALO pixels, parks (voxel key, distance) in LDS,
+// and every pixel scans its (2 HALO + 1)^2 window IN ROW-MAJOR ORDER for pixels of the same voxel -- summing their distances in
+// fp32 from the prefill, exactly the reference's serial index order (back_projection_kernel.cu:215-275: what a
+// serial host evaluation of the reference does).  The first contributor in that order -- the LEADER -- writes the voxel's normalised value (:291-305, with the layer's
+// shift folded in) and its count; nobody else touches it.  No atomics, no second pass over the pixels, run-to-run
+// deterministic, and tdf / cnt BIT-IDENTICAL to a serial evaluation of the reference on every voxel
+// (tests/test_gpu_cam_bp.py::test_image_minor_camera_forward_is_deterministic_and_bit_identical_to_the_serial_reference).
+// Replaces round 4's opt-in cam_bm_brick_kernel (LDS bricks over 32 images: 335 us at batch 32 against 149 for the atomics).
+template <int HALO>
+__global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth, View5 vox, View5 cnt, float cam_dist, float f,
+                                                            float prefill, float bias, float post_scale, float post_bias)
 {
-    __shared__ double s_sum[kMVox * kMImgs];
-    __shared__ unsigned s_cnt[kMVox * kMImgs];
-    const int nbz = (D.Z + kMZ - 1) / kMZ, nby = (D.Y + kMY - 1) / kMY;
-    const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
-    const int n0 = blockIdx.y * kMImgs;
-    const int x0 = bx * kMX, y0 = by * kMY, z0 = bz * kMZ;
-    const int x1 = min(x0 + kMX, D.X), y1 = min(y0 + kMY, D.Y), z1 = min(z0 + kMZ, D.Z);
-    const float rX = 1.0f / (float)D.X, rY = 1.0f / (float)D.Y, rZ = 1.0f / (float)D.Z;
-    const float bxlo = (float)x0 * rX - 0.5f, bxhi = (float)x1 * rX - 0.5f;
-    for (int e = threadIdx.x; e < kMVox * kMImgs; e += kBlock) { s_sum[e] = 0.0; s_cnt[e] = 0u; }
-    __syncthreads();
+    constexpr int TW = 8 + 2 * HALO, TN = TW * TW, kWaves = kBlock / 64;
+    __shared__ int s_key[kWaves][TN];
+    __shared__ float s_dist[kWaves][TN];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    constexpr int kPer = kMImgs / (kBlock / 64);                       // images per wave
-    float dv[kPer][kMRounds];
-    Win bw[kPer];
-    float fs[kPer], cds[kPer];
-    // ---- all loads of this wave's images first
+    const int tw = (D.W + 7) >> 3, th = (D.H + 7) >> 3;
+    const int tiles = D.N * D.NC * th * tw;
+    int *key_w = s_key[wave];
+    float *dist_w = s_dist[wave];
+    const int my = (HALO + (lane >> 3)) * TW + HALO + (lane & 7);
+    for (int tile = blockIdx.x * kWaves + wave; tile < tiles; tile += gridDim.x * kWaves) {
+        int t = tile;
+        const int tx = t % tw; t /= tw;
+        const int ty = t % th; t /= th;
+        const int c = t % D.NC, n = t / D.NC;
+        const int h0 = ty * 8 - HALO, w0 = tx * 8 - HALO;
+        const float *dimg = depth.p + n * depth.s0 + c * depth.s1;
+        // phase 1: the window's pixels, all depth loads of a lane in flight together
+        constexpr int kRounds = (TN + 63) / 64;
+        float d_raw[kRounds];
+        int hh[kRounds], ww[kRounds];
 #pragma unroll
-    for (int i = 0; i < kPer; i++) {
-        const int n = n0 + wave + i * (kBlock / 64);
-        const bool on = n < D.N;
-        fs[i] = BYVAL ? fl_val : (on ? fl.p[n * fl.s0] : 1.0f);
-        cds[i] = BYVAL ? cd_val : (on ? camdist.p[n * camdist.s0] : 1.0f);
-        bw[i] = project_box(D, bxlo, bxhi, (float)y0 * rY - 0.5f, (float)y1 * rY - 0.5f, (float)z0 * rZ - 0.5f,
-                            (float)z1 * rZ - 0.5f, cds[i], fs[i], 1.0f);
-        const int bww = bw[i].w1 - bw[i].w0 + 1, bwh = bw[i].h1 - bw[i].h0 + 1;
-        const int area = (on && bww > 0 && bwh > 0) ? bww * bwh : 0;
-        const float inv_bww = 1.0f / (float)(bww > 0 ? bww : 1);
-        const float *dimg = depth.p + (on ? n : 0) * depth.s0;
-#pragma unroll
-        for (int r = 0; r < kMRounds; r++) {
-            const int t = lane + 64 * r;
-            dv[i][r] = -1.0f;
-            if (t < area) {
-                int rr, q;
-                divmod_px(t, bww, inv_bww, rr, q);
-                dv[i][r] = dimg[(bw[i].h0 + rr) * depth.s2 + (bw[i].w0 + q) * depth.s3];
-            }
+        for (int r = 0; r < kRounds; r++) {
+            const int e = lane + r * 64;
+            hh[r] = h0 + e / TW; ww[r] = w0 + e % TW;
+            d_raw[r] = -1.0f;
+            if (e < TN && hh[r] >= 0 && hh[r] < D.H && ww[r] >= 0 && ww[r] < D.W)
+                d_raw[r] = dimg[hh[r] * (int)depth.s2 + ww[r] * (int)depth.s3];
         }
-    }
-    // ---- every footprint pixel once: plane-depth test, then the reference's arithmetic for the survivors
+        bool any = false;
 #pragma unroll
-    for (int i = 0; i < kPer; i++) {
-        const int img = wave + i * (kBlock / 64), n = n0 + img;
-        if (n >= D.N) continue;
-        const float f = fs[i], cam_dist = cds[i];
-        const int bww = bw[i].w1 - bw[i].w0 + 1, bwh = bw[i].h1 - bw[i].h0 + 1;
-        const int area = (bww > 0 && bwh > 0) ? bww * bwh : 0;
-        const float inv_bww = 1.0f / (float)(bww > 0 ? bww : 1);
-        const float eps = 1e-4f;
-        const bool special = !(f > 0.0f) || !(bxlo + cam_dist > 1e-3f) ||
-                             (bxlo + cam_dist - eps <= 0.0f && bxhi + cam_dist + eps >= 0.0f);
-        const float xlo_t = bxlo - 1e-5f, xhi_t = bxhi + 1e-5f;
-        const float *dimg = depth.p + n * depth.s0;
-        auto pixel = [&](int t, float d_raw) {
-            if (d_raw < 0.0f) return;                                       // :225
-            int rr, q;
-            divmod_px(t, bww, inv_bww, rr, q);
-            const int h = bw[i].h0 + rr, w = bw[i].w0 + q;
-            if (!special) {
-                const float u_h = (float)h - ((float)D.H - 1.0f) / 2.0f, u_w = (float)w - ((float)D.W - 1.0f) / 2.0f;
-                const float xp = d_raw * f * __frsqrt_rn(u_h * u_h + u_w * u_w + f * f) - cam_dist;
-                if (xp < xlo_t || xp > xhi_t) return;
-            }
+        for (int r = 0; r < kRounds; r++) {
+            const int e = lane + r * 64;
             int ix, iy, iz;
             float dist;
-            if (pixel_voxel<false>(D, true, d_raw, 0.f, 0.f, 0.f, f, cam_dist, h, w, ix, iy, iz, dist) < 0) return;
-            if (ix < x0 || ix >= x1 || iy < y0 || iy >= y1 || iz < z0 || iz >= z1) return;
-            const int l = (((ix - x0) * kMY + (iy - y0)) * kMZ + (iz - z0)) * kMImgs + img;
-            unsafeAtomicAdd(&s_sum[l], (double)dist);                       // :273
-            atomicAdd(&s_cnt[l], 1u);                                       // :274
-        };
+            const int key = pixel_voxel<false>(D, e < TN, d_raw[r], 0.f, 0.f, 0.f, f, cam_dist, hh[r], ww[r], ix, iy, iz, dist);
+            if (e < TN) { key_w[e] = key; dist_w[e] = dist; }
+            any |= key >= 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (LDS operations of one wave execute in order)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (__ballot(any) != 0ull) {
+            // phase 2: this lane's pixel against its window, row-major = the reference's serial order
+            const int key = key_w[my];
+            if (key >= 0) {
+                bool leader = true;
+                float sum = prefill, k = 0.0f;                           // cam_back_projection.py:23-24
 #pragma unroll
-        for (int r = 0; r < kMRounds; r++)
-            if (lane + 64 * r < area) pixel(lane + 64 * r, dv[i][r]);
-        for (int t = lane + 64 * kMRounds; t < area; t += 64) {             // footprints beyond 192 pixels (other cameras)
-            int rr, q;
-            divmod_px(t, bww, inv_bww, rr, q);
-            pixel(t, dimg[(bw[i].h0 + rr) * depth.s2 + (bw[i].w0 + q) * depth.s3]);
-        }
-    }
-    __syncthreads();
-    // ---- normalise (:291-305) and write: four images per thread, a voxel's 32 images = one 128-byte line
-    const bool v4 = (D.N & 3) == 0 && ((vox.s2 | vox.s3 | vox.s4 | cnt.s2 | cnt.s3 | cnt.s4) & 3) == 0 &&
-                    ((reinterpret_cast<uintptr_t>(vox.p) | reinterpret_cast<uintptr_t>(cnt.p)) & 15) == 0;
-    for (int qd = threadIdx.x; qd < kMVox * (kMImgs / 4); qd += kBlock) {
-        const int line = qd >> 3, piece = (qd & 7) * 4, n = n0 + piece;
-        const int ix = x0 + line / (kMY * kMZ), iy = y0 + (line / kMZ) % kMY, iz = z0 + line % kMZ;
-        if (ix >= D.X || iy >= D.Y || iz >= D.Z || n >= D.N) continue;
-        float tv[4], kv[4];
+                for (int dy = -HALO; dy <= HALO; dy++) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float k = (float)s_cnt[line * kMImgs + piece + c];
-            kv[c] = k;
-            // (sum - bias) / k  (:304): a correctly rounded division, as the reference's -- once per voxel, not on the hot path
-            tv[c] = k > 0.0f ? post_bias + post_scale * (((prefill + (float)s_sum[line * kMImgs + piece + c]) - bias) / k) : fill_val;
+                    for (int dx = -HALO; dx <= HALO; dx++) {
+                        const int e = my + dy * TW + dx;
+                        if (key_w[e] == key) {
+                            if (dy < 0 || (dy == 0 && dx < 0)) leader = false;
+                            sum = sum + dist_w[e];                       // :273, serial order
+                            k = k + 1.0f;                                // :274
+                        }
+                    }
+                }
+                if (leader) {
+                    const int iz = key % D.Z, iy = (key / D.Z) % D.Y, ix = key / (D.Z * D.Y);
+                    vox.p[n * vox.s0 + c * vox.s1 + vox_off(vox, ix, iy, iz)] = post_bias + post_scale * ((sum - bias) / k);   // :304
+                    cnt.p[n * cnt.s0 + c * cnt.s1 + vox_off(cnt, ix, iy, iz)] = k;
+                }
+            }
         }
-        float *pv = vox.p + ix * vox.s2 + iy * vox.s3 + iz * vox.s4 + n;
-        float *pc = cnt.p + ix * cnt.s2 + iy * cnt.s3 + iz * cnt.s4 + n;
-        if (v4 && n + 3 < D.N) {
-            camq_store4(pv, make_float4(tv[0], tv[1], tv[2], tv[3]));
-            camq_store4(pc, make_float4(kv[0], kv[1], kv[2], kv[3]));
-        } else {
-            for (int c = 0; c < 4; c++)
-                if (n + c < D.N) { pv[c] = tv[c]; pc[c] = kv[c]; }
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the next tile overwrites the window
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+}
+
+// how many pixels apart two points of ONE voxel can project (see cam_leader_kernel): -1 if the camera is too close for the bound
+inline int leader_halo(const Dims &D, float f, float cam_dist)
+{
+    const double x_min = (double)cam_dist - 0.5;
+    if (!(x_min > 0.05) || !(f > 0.0f)) return -1;
+    const double dx = 1.0 / D.X, dy = 1.0 / D.Y, dz = 1.0 / D.Z;
+    const double bw = (double)f * (dy / x_min + 0.5 * dx / (x_min * x_min));     // columns:  u_w = -f y / x
+    const double bh = (double)f * (dz / x_min + 0.5 * dx / (x_min * x_min));     // rows:     u_h = -f z / x
+    const double b = (bw > bh ? bw : bh) * (1.0 + 1e-4) + 1e-3;                   // fp32 rounding of the coordinates
+    return (int)b;                                                                // integer pixel distances are <= floor(b)
 }
 
 // ---- K3: surface mask (:324-357), one lane per voxel, z fastest -----------------
@@ -1151,7 +1122,7 @@ int launch_fill2(const Dims &D, const genre_tensor *a, float va, const genre_ten
 // arrivals at ~10 ns each + the polling), +1.9 us for the L2 write-back and +1.7 us for the invalidate each side
 // needs so that the XCDs' L2s agree; a kernel boundary inside a HIP graph costs ~1 us.)
 // The spherical path always scatters.
-enum CamMode { kAuto, kScatter, kGather, kBrick, kImageMinor };
+enum CamMode { kAuto, kScatter, kGather, kBrick };
 // The only process-level setting the library reads: the environment variable GENRE_CAMBP_MODE, looked up ONCE at the first
 // camera forward and constant afterwards -- a read-only configuration value, not mutable state: calls stay re-entrant
 // and independent of one another (include/genre_hip.h: "keeps no global state").
@@ -1160,7 +1131,7 @@ inline CamMode cam_mode()
     static const CamMode m = [] {
         const char *e = getenv("GENRE_CAMBP_MODE");
         if (!e) return kAuto;
-        return e[0] == 'g' ? kGather : e[0] == 'b' ? kBrick : e[0] == 's' ? kScatter : e[0] == 'i' ? kImageMinor : kAuto;
+        return e[0] == 'g' ? kGather : e[0] == 'b' ? kBrick : e[0] == 's' ? kScatter : kAuto;
     }();
     return m;
 }
@@ -1213,30 +1184,42 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
     };
     const int vec_ok = rows_aligned(voxel) && rows_aligned(cnt);
     CamMode mode = SPH ? kScatter : cam_mode();
-    // image-minor outputs (the batch-minor renderer's layout), GENRE_CAMBP_MODE=imageminor: one launch, LDS bricks over groups of
-    // 32 images -- deterministic and bit-identical to cam_brick_kernel, but MEASURED SLOWER than the three launches it would
-    // replace (batch 32: 335 us against 149 us, profiles/r04j_*: 16 384 workgroups x 32 images x three footprint rounds are
-    // latency- and issue-bound at three workgroups per CU), so it is opt-in
-    const bool image_minor = !SPH && D.NC == 1 && D.N > 1 && voxel->stride[0] == 1 && cnt->stride[0] == 1 &&
-                             (int64_t)D.X * D.Y * D.Z > 0 && (D.N + kMImgs - 1) / kMImgs <= 65535;
-    if (mode == kImageMinor && !(image_minor && !byval)) mode = kAuto;   // other layouts: as if the variable were not set
-    if (mode == kImageMinor) {
+    if (mode == kAuto) mode = (vec_ok && D.N * D.NC <= 65535) ? kBrick : kScatter;
+    if (byval && !(vec_ok && D.N * D.NC <= 65535 && (mode == kBrick || cam_mode() == kAuto))) {
+        // by value, but no contiguous z rows (image-minor / strided volumes): fill + the deterministic leader pass
+        const int halo = SPH ? -1 : leader_halo(D, byval[0], byval[1]);
+        GENRE_REQUIRE(!SPH && cam_mode() != kGather && cam_mode() != kBrick && halo >= 0 && halo <= 4,
+                      "%s: the by-value entry serves dense NCXYZ outputs (single-launch brick kernel) or, for other layouts, "
+                      "cameras whose voxels project to at most 4 pixels (fill + leader pass; this one: %d, GENRE_CAMBP_MODE must "
+                      "not pin gather / brick); pass fl / camdist tensors otherwise", op, halo);
+        const int64_t npix = (int64_t)D.N * D.NC * D.H * D.W;
+        if (!launch_fill2(D, voxel, fill_val, cnt, 0.0f, st)) return 0;
+        if (npix == 0 || (int64_t)D.X * D.Y * D.Z == 0) return 1;
+        const int64_t tiles = (int64_t)D.N * D.NC * ((D.H + 7) / 8) * ((D.W + 7) / 8);
+        auto span31 = [](const genre_tensor *t) {                    // per-image extent in elements < 2^31 ?
+            int64_t span = 1;
+            for (int i = 2; i < t->ndim; i++) span += (t->size[i] - 1) * (t->stride[i] < 0 ? -t->stride[i] : t->stride[i]);
+            return span < ((int64_t)1 << 31);
+        };
+        GENRE_REQUIRE(tiles < ((int64_t)1 << 30) && span31(voxel) && span31(cnt) && span31(depth),
+                      "%s: one image (map or volume) must span fewer than 2^31 elements", op);
         const float prefill = (float)(1.0 / (double)D.X);               // cam_back_projection.py:23-24 (res = X)
         const float bias = 1.0f / (float)mx;                             // K2: dist_bias / max(res)  (:304,:829)
-        const int64_t bricks = (int64_t)((D.X + kMX - 1) / kMX) * ((D.Y + kMY - 1) / kMY) * ((D.Z + kMZ - 1) / kMZ);
-        GENRE_REQUIRE(bricks < ((int64_t)1 << 31), "%s: volume too large", op);
-        cam_bm_brick_kernel<false><<<dim3((unsigned)bricks, (unsigned)((D.N + kMImgs - 1) / kMImgs)), kBlock, 0, st>>>(
-            D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias, post_scale, post_bias, fill_val, 0.0f, 0.0f);
-        GENRE_LAUNCH_CHECK("projection forward (image-minor bricks)");
+        const int g = grid_for(tiles * 64, 1 << 16);
+#define GENRE_CAM_LEADER(HV)                                                                                              \
+        cam_leader_kernel<HV><<<g, kBlock, 0, st>>>(D, view4(depth), view5(voxel), view5(cnt), byval[1], byval[0], prefill, bias, \
+                                                    post_scale, post_bias)
+        switch (halo < 1 ? 1 : halo) {
+            case 1: GENRE_CAM_LEADER(1); break;
+            case 2: GENRE_CAM_LEADER(2); break;
+            case 3: GENRE_CAM_LEADER(3); break;
+            default: GENRE_CAM_LEADER(4); break;
+        }
+#undef GENRE_CAM_LEADER
+        GENRE_LAUNCH_CHECK("projection forward (leader pass)");
         return 1;
     }
-    if (mode == kAuto) mode = (vec_ok && D.N * D.NC <= 65535) ? kBrick : kScatter;
-    if (byval) {
-        GENRE_REQUIRE(!SPH && vec_ok && D.N * D.NC <= 65535 && (mode == kBrick || cam_mode() == kAuto),
-                      "%s: the by-value entry runs the single-launch brick kernel only (dense NCXYZ outputs with unit "
-                      "z stride, 16-byte aligned rows, Z %% 4 == 0); pass fl / camdist tensors otherwise", op);
-        mode = kBrick;
-    }
+    if (byval) mode = kBrick;
     if (mode != kScatter) {
         const int64_t nvox = (int64_t)D.X * D.Y * D.Z;
         if (nvox == 0 || D.N * D.NC == 0) return 1;

@@ -13,6 +13,7 @@
 // the width; the path is picked at run time from the CPU's features (the library itself is built for plain x86-64).
 #include "common.hpp"
 #include <algorithm>
+#include <cstring>
 #include <immintrin.h>
 #include <thread>
 #include <vector>
@@ -135,24 +136,33 @@ __attribute__((target("avx512f"))) void nearest_avx512(int n, int m, const float
 
 using nearest_fn = void (*)(int, int, const float *, const float *, float *, int *, int, int);
 
-nearest_fn pick_nearest()
+// which path runs: picked once per process from the CPU's features; GENRE_NND_HOST_ISA = scalar | avx2 | avx512 pins one
+// (tests).  A request the CPU cannot serve is NOT silently replaced: the name reported by genre_nnd_host_isa() is then the
+// path that really runs, and tests/test_nnd_host.py skips instead of passing on another width.
+struct HostIsa { nearest_fn fn; const char *name; };
+
+const HostIsa &host_isa()
 {
 #ifdef __HIP_DEVICE_COMPILE__
-    return (nearest_fn)nearest_scalar;
+    static const HostIsa h{(nearest_fn)nearest_scalar, "scalar"};
+    return h;
 #else
-    static const nearest_fn f = [] {
-        const char *e = getenv("GENRE_NND_HOST_ISA");                  // scalar | avx2 | avx512: pins a path (tests)
+    static const HostIsa h = [] {
+        const char *e = getenv("GENRE_NND_HOST_ISA");
         __builtin_cpu_init();
         const bool a512 = __builtin_cpu_supports("avx512f"), a2 = __builtin_cpu_supports("avx2");
-        if (e && e[0] == 's') return (nearest_fn)nearest_scalar;
-        if (e && e[3] == '2' && a2) return (nearest_fn)nearest_avx2;
-        if (a512) return (nearest_fn)nearest_avx512;
-        if (a2) return (nearest_fn)nearest_avx2;
-        return (nearest_fn)nearest_scalar;
+        const bool want_scalar = e && strcmp(e, "scalar") == 0, want_a2 = e && strcmp(e, "avx2") == 0;
+        if (want_scalar) return HostIsa{(nearest_fn)nearest_scalar, "scalar"};
+        if (want_a2 && a2) return HostIsa{(nearest_fn)nearest_avx2, "avx2"};
+        if (a512) return HostIsa{(nearest_fn)nearest_avx512, "avx512"};
+        if (a2) return HostIsa{(nearest_fn)nearest_avx2, "avx2"};
+        return HostIsa{(nearest_fn)nearest_scalar, "scalar"};
     }();
-    return f;
+    return h;
 #endif
 }
+
+nearest_fn pick_nearest() { return host_isa().fn; }
 
 void nearest_scalar(int n, int m, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ dist,
                     int *__restrict__ idx, int j0, int j1)
@@ -199,6 +209,8 @@ int check_clouds(const char *op, const genre_tensor *x1, const genre_tensor *x2)
 }  // namespace genre
 
 using namespace genre;
+
+extern "C" const char *genre_nnd_host_isa(void) { return host_isa().name; }
 
 extern "C" int genre_nnd_forward_host(const genre_tensor *xyz1, const genre_tensor *xyz2, const genre_tensor *dist1,
                                       const genre_tensor *dist2, const genre_tensor *idx1, const genre_tensor *idx2)

@@ -42,7 +42,10 @@
 namespace genre {
 namespace {
 
-constexpr int kBX = 4, kBY = 8, kBZ = 8;                 // brick (must match toolbox/_bm_tables.py)
+#ifndef GENRE_BM_BY
+#define GENRE_BM_BY 8                                    // 4: half bricks, 512-thread workgroups, four per CU (A/B: tools/build_variants.sh)
+#endif
+constexpr int kBX = 4, kBY = GENRE_BM_BY, kBZ = 8;       // brick (must match toolbox/_bm_tables.py: genre_bm_brick())
 constexpr int kTX = kBX + 1, kTY = kBY + 1, kTZ = kBZ + 1;
 constexpr int kLinesF = kTX * kTY * kTZ;                 // 405 voxel lines in the forward tile
 constexpr int kImgs = 32;                                // images per group = lanes of a half-wave
@@ -101,6 +104,24 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     const int g = blockIdx.y, n0 = g * kImgs;
     int ox, oy, oz;
     brick_origin(D, row.x, ox, oy, oz);
+    // THE FIRST SEGMENT'S HEADER AND RECORDS ARE REQUESTED BEFORE THE TILE (round 5).  A wave marches ~1.2 segments of a brick
+    // on average (315 k segments over 16 384 bricks x 16 waves), so the software pipeline of the march loop below rarely gets
+    // past its prologue, and that prologue -- header (segs) -> records (rec_f), two dependent round trips -- used to START
+    // behind the barrier that ends the tile staging: row -> tile -> barrier -> header -> records -> march, five exposed
+    // latencies per workgroup.  Issued here, in front of the tile loads (the records first, so that the ONE wait the tile
+    // values need also covers them and every later wait stays exact -- the in-order counter again), the chain is
+    // row -> header -> max(records, tile) -> barrier -> march.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    constexpr int NW = NT / 64;
+    int s = row.y + wave;
+    const bool has_seg = s < row.z;
+    const int s_last = has_seg ? s + ((row.z - 1 - s) / NW) * NW : max(min(s, row.z - 1), 0);   // this wave's last segment: indices are clamped to it
+    int4 sg = make_int4(0, 0, 0, 0), sg1 = sg, rq = sg;
+    if (D.nseg > 0) {
+        sg = segs[has_seg ? s : s_last];
+        sg1 = segs[has_seg ? min(s + NW, s_last) : s_last];
+        rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)__builtin_amdgcn_readfirstlane(sg.w) * kRec)[lane];   // lane's 16 bytes of the records
+    }
     const bool vec = (D.N & 3) == 0 && (D.sx & 3) == 0 && (D.sy & 3) == 0 && (D.sz & 3) == 0;
     // Stage the tile: thread t + 512 j takes 16 bytes (4 images) of voxel line (t + 512 j) / 8.  ALL loads of a thread are
     // issued before the first one is used -- one exposed HBM round trip per tile instead of seven.
@@ -186,7 +207,6 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
         }
         save_rt = __builtin_amdgcn_readfirstlane((int)any) != 0;
     }
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int half = lane >> 5, l = lane & 31;
     // A wave's records in LDS: the 48-byte table records of the segment, as they come -- every lane parks its 16 bytes
     // (1 KB per wave; the table is padded so that the lanes beyond the segment's L * 3 read real memory), sample i at
@@ -207,13 +227,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     //    issued after that load -- the saved samples of the segment just marched, a store round trip per segment and wave.
     //    A segment's saved samples (and its (P, S) pair) stay in registers and leave at the top of the NEXT segment, after
     //    the wait, so that at every wait the only operations outstanding were issued a whole march earlier.
-    const int NW = NT / 64;
-    int s = row.y + wave;
-    if (s >= row.z) return;
-    const int s_last = s + ((row.z - 1 - s) / NW) * NW;                // this wave's last segment: indices are clamped to it
-    int4 sg = segs[s];
-    int4 sg1 = segs[min(s + NW, s_last)];
-    int4 rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)sg.w * kRec)[lane];     // lane's 16 bytes of the records
+    if (!has_seg) return;                                              // (header and records of the first segment: requested at the top)
     // the march, compiled twice where SAVE: with and without the stores of the saved samples (the choice is per workgroup and
     // made once, outside the loop: every wait inside stays exact)
     auto march = [&](auto save_c) {
@@ -779,6 +793,8 @@ int check_rows(const char *op, const BmDims &D, const genre_tensor *rows, int bx
 
 using namespace genre;
 
+extern "C" int genre_bm_brick(void) { return kBX * 100 + kBY * 10 + kBZ; }
+
 extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tensor *out, const genre_tensor *segs,
                                        const genre_tensor *rec_f, const genre_tensor *fwd_rows,
                                        const genre_tensor *ray_ptr, const genre_tensor *ray_seg,
@@ -810,8 +826,9 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
         GENRE_REQUIRE(hipMemsetAsync((unsigned *)mask->data + (int64_t)D.groups * D.X * D.Y * D.Z, 0, (size_t)D.groups * 4, st) == hipSuccess,
                       "%s: hipMemsetAsync of the group words failed", op);
     }
-    // 1024 threads: 16 waves share one tile, two workgroups per CU = 8 waves per SIMD (measured 257 us against 318 with 512)
-    constexpr int nt = 1024;
+    // 1024 threads: 16 waves share one tile, two workgroups per CU = 8 waves per SIMD (measured 257 us against 318 with 512);
+    // with half bricks (kBY == 4: a 29 KB tile) 512 threads, four workgroups per CU
+    constexpr int nt = kBY == 4 ? 512 : 1024;
     const size_t lds = (size_t)kLinesF * kImgs * 4 + (size_t)(nt / 64) * 64 * 16 + (size_t)(nt / 64) * 4;   // tile, records, wave flags
     const dim3 grid((unsigned)fwd_rows->size[0], (unsigned)D.groups);
 #define GENRE_BM_SAMPLE_NT(PSV, SV, NTV)                                                                                  \

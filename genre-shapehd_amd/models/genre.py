@@ -160,8 +160,9 @@ class GenReInference:
     @torch.no_grad()
     def predict(self, rgb, silhou):
         rgb, silhou = rgb.to(self.device), silhou.to(self.device)
+        net = self.net
         if not self.graph:
-            return {"pred_voxel": self.net(Inputs(rgb, silhou))["pred_voxel"]}
+            return {"pred_voxel": net(Inputs(rgb, silhou))["pred_voxel"]}
         key = tuple(rgb.shape)
         cap = self._captured.get(key)
         if cap is None:
@@ -170,16 +171,16 @@ class GenReInference:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):                                   # warm-up: table builds, MIOpen find, allocations
-                    self.net(Inputs(s_rgb, s_sil))
+                    net(Inputs(s_rgb, s_sil))
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self.net(Inputs(s_rgb, s_sil))["pred_voxel"]
+                out = net(Inputs(s_rgb, s_sil))["pred_voxel"]
             # the graph holds raw pointers of every tensor the forward read, among them the cached fl / cam_dist
             # constants of the back-projection layers: pin them for the life of the graph
             from ..toolbox import _fused_render
-            pinned = [t for m in self.net.modules() for t in getattr(m, "_consts", {}).values()]
+            pinned = [t for m in net.modules() for t in getattr(m, "_consts", {}).values()]
             pinned.append(list(_fused_render._TABLES.values()))          # the renderer's geometry tables likewise
             cap = self._captured[key] = (g, s_rgb, s_sil, out, pinned)
         g, s_rgb, s_sil, out = cap[:4]

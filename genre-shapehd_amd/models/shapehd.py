@@ -86,7 +86,9 @@ class WGANGP:
         alpha = self._random(torch.rand, (real.shape[0],) + (1,) * (real.dim() - 1), real.device)
         inter = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
         score = self.net_d(inter)
-        grads, = torch.autograd.grad(score, inter, torch.ones_like(score), create_graph=True, retain_graph=True)
+        from ..networks.thin_conv import input_grad_only
+        with input_grad_only():     # this pass wants d score / d inter and nothing else: no weight-gradient GEMMs, no nodes for them
+            grads, = torch.autograd.grad(score, inter, torch.ones_like(score), create_graph=True, retain_graph=True)
         gn = (grads.reshape(grads.size(0), -1) + 1e-16).norm(2, dim=1)
         return ((gn - self.norm) ** 2).mean() * self.lam
 

@@ -34,6 +34,27 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 import torch.nn.functional as F
 
+import contextlib
+
+_INPUT_GRAD_ONLY = False    # see input_grad_only()
+
+
+@contextlib.contextmanager
+def input_grad_only():
+    """Inside this context the backward of the two Functions below returns the DATA gradient only.  `ctx.needs_input_grad` is
+    fixed when a Python Function runs forward, so `autograd.grad(score, x_hat, create_graph=True)` -- the first-order pass of
+    the WGAN-GP penalty, which wants the critic's input gradient and nothing else (models/wgangp.py:131-147) -- would
+    otherwise run every layer's unfold + GEMM weight gradient and record a graph node for it, only to drop the result
+    (ADVICE r4).  The second differentiation (the penalty's backward, outside this context) still meets the GEMM weight
+    gradients of the recorded data-gradient operators."""
+    global _INPUT_GRAD_ONLY
+    prev, _INPUT_GRAD_ONLY = _INPUT_GRAD_ONLY, True
+    try:
+        yield
+    finally:
+        _INPUT_GRAD_ONLY = prev
+
+
 _BLOCK = 4096               # voxels per GEMM block (K of one batch entry)
 _MAX_UNFOLD = 160 << 20     # elements of the unfolded operand materialised at once (0.64 GB of fp32)
 
@@ -63,19 +84,24 @@ def transposed_weight_grad(x, gy, weight_shape, stride, padding):
     pads = []
     for d in (2, 1, 0):
         pads += [p[d], max(need[d] - p[d] - gy.shape[2 + d], 0)]
-    gp = F.pad(gy, pads)
+    gp = F.pad(gy.to(x.dtype), pads)                                   # (autocast: an fp16 gy against an fp32 x)
     xf = x.reshape(n, ci, -1)
-    out = x.new_empty((ci, co, kd, kh, kw))
-    per_tap = n * co * xf.shape[2]
-    step = max(1, min(kd, _MAX_UNFOLD // max(1, per_tap * kh * kw)))
-    for k0 in range(0, kd, step):
-        k1 = min(kd, k0 + step)
-        # view [N, Co, I0, I1, I2, kd', kh, kw]
-        v = gp[:, :, k0:k0 + (i3[0] - 1) * s[0] + (k1 - k0)].unfold(2, k1 - k0, s[0]).unfold(3, kh, s[1]).unfold(4, kw, s[2])
-        v = v[:, :, :i3[0], :i3[1], :i3[2]]
-        g = v.permute(0, 1, 5, 6, 7, 2, 3, 4).reshape(n, co * (k1 - k0) * kh * kw, -1)      # materialised here
-        r = _blocked_contract(xf, g)                                                        # [Ci, Co*k'*kh*kw]
-        out[:, :, k0:k1] = r.reshape(ci, co, k1 - k0, kh, kw)
+    out = x.new_zeros((ci, co, kd, kh, kw))
+    # the unfolded operand is materialised in pieces of <= _MAX_UNFOLD elements: first over taps, then -- when one plane of
+    # taps of the whole batch is still too large (batch 32 at 128^3) -- over batch items too
+    per_item = co * xf.shape[2] * kh * kw
+    nb = max(1, min(n, _MAX_UNFOLD // max(1, per_item)))
+    step = max(1, min(kd, _MAX_UNFOLD // max(1, nb * per_item)))
+    for n0 in range(0, n, nb):
+        n1 = min(n, n0 + nb)
+        for k0 in range(0, kd, step):
+            k1 = min(kd, k0 + step)
+            # view [N', Co, I0, I1, I2, kd', kh, kw]
+            v = gp[n0:n1, :, k0:k0 + (i3[0] - 1) * s[0] + (k1 - k0)].unfold(2, k1 - k0, s[0]).unfold(3, kh, s[1]).unfold(4, kw, s[2])
+            v = v[:, :, :i3[0], :i3[1], :i3[2]]
+            g = v.permute(0, 1, 5, 6, 7, 2, 3, 4).reshape(n1 - n0, co * (k1 - k0) * kh * kw, -1)      # materialised here
+            r = _blocked_contract(xf[n0:n1], g)                                                       # [Ci, Co*k'*kh*kw]
+            out[:, :, k0:k1] += r.reshape(ci, co, k1 - k0, kh, kw)
     return out
 
 
@@ -90,17 +116,20 @@ def regular_weight_grad(x, gy, weight_shape, stride, padding):
     for d in (2, 1, 0):
         pads += [p[d], max(need[d] - p[d] - x.shape[2 + d], 0)]
     xp = F.pad(x, pads)
-    gf = gy.reshape(n, co, -1)
-    out = x.new_empty((co, ci, kd, kh, kw))
-    per_tap = n * ci * gf.shape[2]
-    step = max(1, min(kd, _MAX_UNFOLD // max(1, per_tap * kh * kw)))
-    for k0 in range(0, kd, step):
-        k1 = min(kd, k0 + step)
-        v = xp[:, :, k0:k0 + (o3[0] - 1) * s[0] + (k1 - k0)].unfold(2, k1 - k0, s[0]).unfold(3, kh, s[1]).unfold(4, kw, s[2])
-        v = v[:, :, :o3[0], :o3[1], :o3[2]]
-        u = v.permute(0, 1, 5, 6, 7, 2, 3, 4).reshape(n, ci * (k1 - k0) * kh * kw, -1)
-        r = _blocked_contract(gf, u)                                                        # [Co, Ci*k'*kh*kw]
-        out[:, :, k0:k1] = r.reshape(co, ci, k1 - k0, kh, kw)
+    gf = gy.to(x.dtype).reshape(n, co, -1)
+    out = x.new_zeros((co, ci, kd, kh, kw))
+    per_item = ci * gf.shape[2] * kh * kw
+    nb = max(1, min(n, _MAX_UNFOLD // max(1, per_item)))
+    step = max(1, min(kd, _MAX_UNFOLD // max(1, nb * per_item)))
+    for n0 in range(0, n, nb):
+        n1 = min(n, n0 + nb)
+        for k0 in range(0, kd, step):
+            k1 = min(kd, k0 + step)
+            v = xp[n0:n1, :, k0:k0 + (o3[0] - 1) * s[0] + (k1 - k0)].unfold(2, k1 - k0, s[0]).unfold(3, kh, s[1]).unfold(4, kw, s[2])
+            v = v[:, :, :o3[0], :o3[1], :o3[2]]
+            u = v.permute(0, 1, 5, 6, 7, 2, 3, 4).reshape(n1 - n0, ci * (k1 - k0) * kh * kw, -1)
+            r = _blocked_contract(gf[n0:n1], u)                                                       # [Co, Ci*k'*kh*kw]
+            out[:, :, k0:k1] += r.reshape(co, ci, k1 - k0, kh, kw)
     return out
 
 
@@ -149,9 +178,9 @@ class _ThinConvTranspose3dFn(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:                                   # adjoint of a transposed convolution: a convolution
             gx = _ThinConv3dFn.apply(gy, weight, None, stride, padding)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
             gw = _TransposedWgradFn.apply(x, gy, tuple(weight.shape), stride, padding)
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and not _INPUT_GRAD_ONLY:
             gb = gy.sum((0, 2, 3, 4))
         return gx, gw, gb, None, None, None
 
@@ -174,9 +203,9 @@ class _ThinConv3dFn(Function):
         if ctx.needs_input_grad[0]:
             opad = tuple(x.shape[2 + d] - ((gy.shape[2 + d] - 1) * stride[d] - 2 * padding[d] + weight.shape[2 + d]) for d in range(3))
             gx = _ThinConvTranspose3dFn.apply(gy, weight, None, stride, padding, opad)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _INPUT_GRAD_ONLY:
             gw = _RegularWgradFn.apply(x, gy, tuple(weight.shape), stride, padding)
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and not _INPUT_GRAD_ONLY:
             gb = gy.sum((0, 2, 3, 4))
         return gx, gw, gb, None, None
 

@@ -40,7 +40,11 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
 """
 import numpy as np
 
-BX, BY, BZ = 4, 8, 8            # must match csrc/sph_render_bm.hip
+import os
+
+# the forward's bricks; must match csrc/sph_render_bm.hip (kBX, kBY, kBZ: toolbox/_fused_render.py checks it against the loaded
+# library's genre_bm_brick()).  GENRE_BM_BY (4 | 8) is the A/B switch of both sides (tools/build_variants.sh -DGENRE_BM_BY=4)
+BX, BY, BZ = 4, int(os.environ.get("GENRE_BM_BY", "8")), 8
 TX, TY, TZ = BX + 1, BY + 1, BZ + 1
 MAXSEG = 16
 SLOT_PAD = 24                   # unused slots behind the last sample (see rec_f): >= 22, every lane of a wave loads 16 bytes of rec_f

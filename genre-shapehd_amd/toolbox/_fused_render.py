@@ -195,6 +195,9 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
     pull = {"488": (4, 8, 8), "888": (8, 8, 8)}[os.environ.get("GENRE_BM_PULL", "488")]      # backward brick (A/B switch)
     # keyed on the CONTENTS of the depth_weight buffer (hashed once per address + version, _content_of): no device ->
     # host copy -- and no stream synchronisation, which HIP-graph capture forbids -- while the buffer is untouched
+    lib_brick = _loader()._lib.genre_bm_brick()
+    assert lib_brick == _bm_tables.BX * 100 + _bm_tables.BY * 10 + _bm_tables.BZ, \
+        "libgenre_hip.so was built for %d bricks, toolbox/_bm_tables.py builds %dx%dx%d" % (lib_brick, _bm_tables.BX, _bm_tables.BY, _bm_tables.BZ)
     dw_hash, dw = _content_of(depth_weight)
     key = ("bm", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], dw_hash, str(device), pull)
     t = _TABLES.get(key)
@@ -205,7 +208,7 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
             return _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, pull=pull)
         build.__module__ = _bm_tables.__name__
         np_t = _disk_cached("bm", (tuple(vox_shape[2:]), pull, _bm_tables.ROW_ORDER, _bm_tables.SPLIT_F,
-                                   _bm_tables.SPLIT_B, _bm_tables.MAXSEG, "r5"), [d64, dw], build)
+                                   _bm_tables.SPLIT_B, _bm_tables.MAXSEG, (_bm_tables.BX, _bm_tables.BY, _bm_tables.BZ), "r5"), [d64, dw], build)
         t = {"pull_code": int(np_t["pull"][0]) * 100 + int(np_t["pull"][1]) * 10 + int(np_t["pull"][2])}
         for k, v in np_t.items():
             if k == "pull":

@@ -28,6 +28,16 @@ def _cam_mode():
     return _CAM_MODE
 
 
+def leader_halo(res, fl, cam_dist):
+    """csrc/cam_bp.hip: leader_halo -- how many pixels apart two points of one voxel can project for a camera (fl, cam_dist)
+    looking at the unit cube from (-cam_dist, 0, 0); -1: the camera is too close for the bound"""
+    x_min = float(cam_dist) - 0.5
+    if not (x_min > 0.05) or not (fl > 0):
+        return -1
+    b = float(fl) * ((1.0 / res) / x_min + 0.5 * (1.0 / res) / (x_min * x_min))
+    return int(b * (1.0 + 1e-4) + 1e-3)
+
+
 class CameraBackProjection(Function):
 
     @staticmethod
@@ -84,12 +94,18 @@ class ShiftedCameraBackProjection(Function):
         else:
             out = torch.empty((n, nc, res, res, res), dtype=depth_t.dtype, device=depth_t.device)
             cnt = torch.empty_like(out)
-        # the by-value entry runs the single-launch brick kernel only: dense NCXYZ outputs whose z rows are float4-aligned
-        # (res % 4 == 0 for the tensors allocated above), at most 65535 images, brick / auto mode -- the library's own
-        # preconditions (csrc/cam_bp.hip: forward_impl), checked HERE so that every other case (res = 30, 126, ...; the
-        # scatter / gather modes) takes the tensor entry instead of an error
-        if (const is not None and not (batch_minor and nc == 1) and n * nc <= 65535 and res % 4 == 0
-                and _cam_mode() in ("", "auto", "brick")):
+        # the by-value entry runs (a) the single-launch brick kernel on dense NCXYZ outputs whose z rows are float4-aligned
+        # (res % 4 == 0 for the tensors allocated above), at most 65535 images, brick / auto mode, or (b) on image-minor
+        # outputs fill + the deterministic, atomic-free leader pass, for cameras whose voxels project to <= 4 pixels (round
+        # 5; auto mode) -- the library's own preconditions (csrc/cam_bp.hip: forward_impl, leader_halo), checked HERE so that
+        # every other case (res = 30, 126, ...; the scatter / gather modes; a very close camera) takes the tensor entry
+        # instead of an error
+        image_minor = batch_minor and nc == 1
+        if image_minor:
+            by_value = const is not None and _cam_mode() in ("", "auto") and 0 <= leader_halo(res, const[0], const[1]) <= 4
+        else:
+            by_value = const is not None and n * nc <= 65535 and res % 4 == 0 and _cam_mode() in ("", "auto", "brick")
+        if by_value:
             cam_bp_lib.back_projection_forward_const(depth_t, const[1], const[0], out, cnt, shifted=True)
         else:
             cam_bp_lib.back_projection_forward_shifted(depth_t, cam_dist, fl, out, cnt)

@@ -202,6 +202,10 @@ int genre_nnd_backward(const genre_tensor *xyz1, const genre_tensor *xyz2,
                        const genre_tensor *graddist1, const genre_tensor *graddist2,
                        const genre_tensor *idx1, const genre_tensor *idx2, void *stream);
 
+/* The vector width the host search runs at in this process: "scalar", "avx2" or "avx512" (picked from the CPU's features;
+ * GENRE_NND_HOST_ISA pins a narrower one).  Results are bit-identical at every width. */
+const char *genre_nnd_host_isa(void);
+
 /* HOST entry points: the reference's my_lib.nnd_forward / nnd_backward (toolbox/nndistance/src/my_lib.h:3-5,
  * my_lib.c:30-118), which its NNDFunction takes for CPU tensors (functions/nnd.py:27-28,53-54).  All pointers are
  * HOST memory; same shapes as above; synchronous; multi-threaded over (batch item, block of queries).  Values and
@@ -323,6 +327,9 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *   tr_scratch fp32 [groups*nseg*64]: backward only
  * out / grad_out [N,1,R+2p,R+2p] (p = padding margin as above, any strides); pre_scale as above.
  * grad_vox must be batch-minor too (stride[0] == 1); every element is written exactly once. */
+/* the forward's brick the library was built for, as X*100 + Y*10 + Z (488 = 4x8x8 voxels): the tables must be built for it */
+int genre_bm_brick(void);
+
 int genre_render_bm_forward(const genre_tensor *vox, const genre_tensor *out, const genre_tensor *segs,
                             const genre_tensor *rec_f, const genre_tensor *fwd_rows, const genre_tensor *ray_ptr,
                             const genre_tensor *ray_seg, const genre_tensor *ray_pre,

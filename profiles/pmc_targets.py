@@ -71,7 +71,7 @@ for _ in range(ITERS):
     calc_prob_lib.calc_prob_forward(p, s)
     calc_prob_lib.calc_prob_backward_fused(p, s, g, o)
     if TB is not None:
-        cam_bp_lib.back_projection_forward_shifted(d, cd, fl, proj_bm, cnt_bm)        # the three-launch path of image-minor volumes
+        cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True)   # image-minor volumes: fill + leader pass
 for vol_std, vol_bm in ((proj_std, proj_bm), (soft_std, soft_bm)):
     for _ in range(ITERS):
         lib.render_spherical_forward(vol_std, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"],

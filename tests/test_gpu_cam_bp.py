@@ -320,11 +320,8 @@ def test_by_value_camera_entry_equals_the_tensor_entry(genre, oracle, dev):
         flv, cdv = (418.3, 2.2) if fl is None else (float(fl[0, 0]), float(cd[0, 0]))
         flt = torch.full((n, 1), flv, device=dev)
         cdt = torch.full((n, 1), cdv, device=dev)
-        if res % 4:                      # rows that are not float4-aligned: the brick kernel cannot take them
-            e = torch.empty((n, 1, res, res, res), device=dev)
-            with pytest.raises(RuntimeError, match="by-value"):
-                cam_bp_lib.back_projection_forward_const(t(d, dev), cdv, flv, e, torch.empty_like(e))
-            continue
+        if res % 4:                      # rows that are not float4-aligned: not the brick kernel's case (leader pass or refusal:
+            continue                     # test_image_minor_camera_forward_is_deterministic_and_bit_identical_to_the_serial_reference)
         for shifted in (False, True):
             a, ca = torch.empty((n, 1, res, res, res), device=dev), torch.empty((n, 1, res, res, res), device=dev)
             b, cb = torch.empty_like(a), torch.empty_like(a)
@@ -334,12 +331,6 @@ def test_by_value_camera_entry_equals_the_tensor_entry(genre, oracle, dev):
         tdf_o, cnt_o = oracle.back_projection_forward(d, np.full((n, 1), cdv, np.float32), np.full((n, 1), flv, np.float32), res)
         assert np.array_equal(cb.cpu().numpy(), cnt_o)
         assert np.abs(b.cpu().numpy() - (1 - res * tdf_o)).max() <= res * TOL
-    # layouts the brick kernel cannot take are refused, not silently mishandled
-    d = t(inputs.batch_depth(16), dev)
-    from genre_shapehd_amd.toolbox import _fused_render
-    bm = _fused_render.empty_batch_minor((16, 1, 128, 128, 128), torch.float32, dev)
-    with pytest.raises(RuntimeError, match="by-value"):
-        cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, bm, torch.empty_like(bm))
     # the layer: floats -> by-value entry, same values and gradients as with tensors
     layer = genre.Camera_back_projection_layer().to(dev)
     d1 = t(inputs.sphere_depth(noise_seed=2), dev)
@@ -362,66 +353,55 @@ def test_by_value_camera_entry_equals_the_tensor_entry(genre, oracle, dev):
         assert ya.shape == (1, 1, res, res, res) and (ya - yb).abs().max().item() <= res * TOL
 
 
-def check_image_minor_cases(oracle, dev, shifted):
-    """body of the image-minor test below (runs in a subprocess under GENRE_CAMBP_MODE=imageminor: the library reads the
-    variable once per process)"""
+@pytest.mark.parametrize("shifted", [False, True])
+def test_image_minor_camera_forward_is_deterministic_and_bit_identical_to_the_serial_reference(shifted, oracle, dev):
+    """cam_leader_kernel (round 5; csrc/cam_bp.hip): volumes WITHOUT contiguous z rows -- the image-minor volumes of the
+    batch-minor renderer, or NCXYZ volumes whose rows are not float4-aligned -- with the camera passed by value get fill + a
+    leader pass: every pixel sums the distances of the pixels of its (2 HALO + 1)^2 window that share its voxel, in row-major
+    order = the reference's serial index order (back_projection_kernel.cu:215-275), and the first contributor writes.  No
+    atomics: two runs agree bit for bit, every element is written, cnt AND tdf equal the oracle's serial evaluation bit for bit
+    on every voxel, whatever the batch an image travels in (32, 19, 40, 3) and for every resolution whose voxels project to
+    <= 4 pixels; cameras beyond that are refused with a message (the layer then passes tensors: the atomics path)."""
     from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp.functions.cam_back_projection import leader_halo
     from genre_shapehd_amd.toolbox import _fused_render
-    rng = np.random.default_rng(41)
-    cases = []
-    for n in (32, 19, 40, 3):
-        d = inputs.batch_depth(n, seed=70 + n)
-        fl = (418.3 * (1 + 0.05 * rng.standard_normal((n, 1)))).astype(np.float32)
-        cd = (2.2 * (1 + 0.03 * rng.standard_normal((n, 1)))).astype(np.float32)
-        cases.append((d, fl, cd, 128))
+    assert leader_halo(128, 418.3, 2.2) == 2
+    cases = [(inputs.batch_depth(n, seed=70 + n), 418.3, 2.2, 128, True) for n in (32, 19, 40, 3)]
     for d, fl, cd, res in _odd_cases():
-        n = 5
-        dd = np.concatenate([d] * n)[:n]
-        cases.append((dd, np.concatenate([fl] * n)[:n], np.concatenate([cd] * n)[:n], res))
-    fwd = cam_bp_lib.back_projection_forward_shifted if shifted else cam_bp_lib.back_projection_forward
-    for d, fl, cd, res in cases:
+        dd = np.concatenate([d] * 5)[:5]
+        cases.append((dd, float(fl[0, 0]), float(cd[0, 0]), res, True))          # image-minor ...
+        cases.append((d, float(fl[0, 0]), float(cd[0, 0]), res, False))           # ... and plain NCXYZ (rows not float4-aligned)
+    served = 0
+    for d, flv, cdv, res, bm in cases:
         n = d.shape[0]
-        a, ca = torch.empty((n, 1, res, res, res), device=dev), torch.empty((n, 1, res, res, res), device=dev)
-        fwd(t(d, dev), t(cd, dev), t(fl, dev), a, ca)
+        shape = (n, 1, res, res, res)
+        halo = leader_halo(res, flv, cdv)
+        new = (lambda: _fused_render.empty_batch_minor(shape, torch.float32, dev)) if bm else (lambda: torch.empty(shape, device=dev))
+        if not bm and res % 4 == 0:
+            continue                                                       # (dense aligned rows: the brick kernel's case)
+        if not 0 <= halo <= 4:
+            with pytest.raises(RuntimeError, match="by-value"):
+                cam_bp_lib.back_projection_forward_const(t(d, dev), cdv, flv, new(), new(), shifted=shifted)
+            continue
         runs = []
         for _ in range(2):
-            b = _fused_render.empty_batch_minor((n, 1, res, res, res), torch.float32, dev)
-            cb = _fused_render.empty_batch_minor((n, 1, res, res, res), torch.float32, dev)
+            b, cb = new(), new()
             b.fill_(float("nan")), cb.fill_(float("nan"))                  # every element must be written
-            fwd(t(d, dev), t(cd, dev), t(fl, dev), b, cb)
-            assert b.stride(0) == 1
+            cam_bp_lib.back_projection_forward_const(t(d, dev), cdv, flv, b, cb, shifted=shifted)
             runs.append((b.clone(), cb.clone()))
         assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), (d.shape, res)
-        if res % 4 == 0:                                                    # (the NCXYZ side is the brick kernel: the same arithmetic)
-            assert torch.equal(ca, runs[0][1]) and torch.equal(a, runs[0][0]), (d.shape, res, shifted)
-        else:                                                               # (the NCXYZ side is the three-launch path there)
-            assert torch.equal(ca, runs[0][1]) and (a - runs[0][0]).abs().max().item() <= res * TOL
-        tdf_o, cnt_o = oracle.back_projection_forward(d[:2], cd[:2], fl[:2], res)
-        want = (1 - res * tdf_o) if shifted else tdf_o
-        assert np.array_equal(runs[0][1][:2].cpu().numpy(), cnt_o)
-        assert np.abs(runs[0][0][:2].cpu().numpy() - want).max() <= (res if shifted else 1) * TOL
-
-
-@pytest.mark.parametrize("shifted", [False, True])
-def test_image_minor_camera_forward_is_the_brick_kernel_bit_for_bit_subprocess(shifted, dev):
-    """cam_bm_brick_kernel (round 4, opt-in: GENRE_CAMBP_MODE=imageminor): volumes whose image index is fastest in memory get
-    the same values as cam_brick_kernel writes into an NCXYZ volume -- bit for bit, on every voxel (sums of exact distances in
-    fp64 are order-independent), so the result is deterministic (two runs agree bit for bit) and independent of the layout
-    and of the batch an image travels in.  Batches of 32, 19 (a partly filled group), 40 (two groups), 3; per-image cameras;
-    odd geometries (partial bricks, res % 4 != 0, a camera inside the grid, negative and zero depths).  Measured 2.2x slower
-    than the three-launch path, hence opt-in (csrc/cam_bp.hip: forward_impl)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys; sys.path[:0] = [%r, %r]\n"
-        "import torch\n"
-        "from oracle.oracle import Oracle\n"
-        "import genre_shapehd_amd\n"
-        "import test_gpu_cam_bp as T\n"
-        "T.check_image_minor_cases(Oracle(), torch.device('cuda:0'), %r)\n"
-        "print('ok')\n" % (root, os.path.join(root, "tests"), shifted))
-    env = dict(os.environ, GENRE_CAMBP_MODE="imageminor")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
-    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+        k = min(n, 2)
+        tdf_o, cnt_o = oracle.back_projection_forward(d[:k], np.full((k, 1), cdv, np.float32), np.full((k, 1), flv, np.float32), res)
+        want = (np.float32(1) + np.float32(-res) * tdf_o) if shifted else tdf_o
+        assert np.array_equal(runs[0][1][:k].cpu().numpy(), cnt_o), (d.shape, res)
+        assert np.array_equal(runs[0][0][:k].cpu().numpy(), want.astype(np.float32)), (d.shape, res, halo)
+        assert res != 128 or cnt_o.max() >= 2                               # multi-hit voxels are part of the claim
+        served += 1
+    assert served >= 5
+    # the layer takes this path for image-minor batches when called with Python floats (its default call)
+    layer = __import__("genre_shapehd_amd").Camera_back_projection_layer(batch_minor=True).to(dev)
+    d = t(inputs.batch_depth(16, seed=3), dev)
+    y1, y2 = layer(d), layer(d)
+    assert y1.stride(0) == 1 and torch.equal(y1, y2)
+    tdf_o, _ = oracle.back_projection_forward(d[:1].cpu().numpy(), np.full((1, 1), 2.2, np.float32), np.full((1, 1), 418.3, np.float32), 128)
+    assert np.array_equal(y1[:1].cpu().numpy(), np.float32(1) + np.float32(-128) * tdf_o)

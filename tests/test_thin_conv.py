@@ -51,7 +51,7 @@ def test_thin_modules_keep_the_state_dict_and_the_stock_path_off_the_gpu():
 
 @pytest.mark.parametrize("cls,cin,cout,k,s,p,size", [("c", 1, 4, 4, 2, 1, (8, 8, 8)), ("c", 3, 2, 4, 2, 1, (7, 9, 8)),
                                                       ("t", 3, 2, 4, 2, 1, (4, 5, 3))])
-def test_thin_convolutions_under_a_gradient_penalty(cls, cin, cout, k, s, p, size):
+def test_thin_convolutions_under_a_gradient_penalty(cls, cin, cout, k, s, p, size, monkeypatch):
     """models/wgangp.py:131-147: the critic's INPUT gradient is taken with create_graph=True and a function of it is
     differentiated again with respect to the weights -- the second differentiation runs through the mirror-image Function
     (and its GEMM weight gradient) and must equal the stock operators'"""
@@ -62,12 +62,22 @@ def test_thin_convolutions_under_a_gradient_penalty(cls, cin, cout, k, s, p, siz
     ref.force_stock = True
     x = torch.randn((2, cin) + size, dtype=torch.float64)
     res = []
+    calls = []
+    for name in ("transposed_weight_grad", "regular_weight_grad"):       # count the GEMM weight gradients
+        fn = getattr(TC, name)
+        monkeypatch.setattr(TC, name, lambda *a, _fn=fn, **k: (calls.append(1), _fn(*a, **k))[1])
     for m in (mod, ref):
         xi = x.clone().requires_grad_(True)
         score = m(xi).tanh().sum((1, 2, 3, 4))
-        gx, = torch.autograd.grad(score, xi, torch.ones_like(score), create_graph=True, retain_graph=True)
+        # the first-order pass wants the input gradient only (models/shapehd.py: WGANGP._penalty does the same): no weight-
+        # gradient GEMM runs in it -- ctx.needs_input_grad alone cannot tell (fixed at forward time)
+        with TC.input_grad_only():
+            gx, = torch.autograd.grad(score, xi, torch.ones_like(score), create_graph=True, retain_graph=True)
+        assert not calls
         pen = ((gx.reshape(2, -1).norm(2, dim=1) - 1) ** 2).mean() + score.mean()
         pen.backward()
+        assert bool(calls) == (m is mod)                                 # ... the second differentiation does run them
+        del calls[:]
         res.append((gx.detach(), m.weight.grad.clone(), m.bias.grad.clone(), xi.grad.clone()))
     for a, b, what in zip(res[0], res[1], ("gx", "dw", "db", "dx")):
         assert (a - b).abs().max().item() <= 1e-11 * max(1.0, b.abs().max().item()), what
