@@ -298,16 +298,30 @@ def kernel_table(G, dev, B):
             gout_p = torch.randn_like(out_p)
             gvox_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
 
-            def bm_fwd(save):
+            # the volume as the step's layer hands it over: with the leader pass's occupancy words (which bricks of the group hold
+            # anything but the fill value); the sampler copies constants for tiles it knows to be empty instead of reading them
+            words, ps_empty = _fused_render.occupancy_hint(proj_bm, TB, 50.0, render_lib)
+            assert words is not None, "the layer's image-minor volume carries no occupancy words"
+            wl = torch.nn.functional.pad((words != 0).float(), (0, 1, 0, 1, 0, 1))
+            tiles_live = torch.stack([wl[:, a:a + words.shape[1], b:b + words.shape[2], c:c + words.shape[3]]
+                                      for a in (0, 1) for b in (0, 1) for c in (0, 1)]).amax(0).mean().item()
+
+            def bm_fwd(save, hint=True):
                 render_lib.render_bm_forward(proj_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"],
                                              TB["ray_seg"], TB["ray_pre"], ps, stash if save else None,
-                                             mask if save else None, 50.0)
-            rows["render_fwd_bm"] = dict(us=event_time_us(lambda: bm_fwd(True), iters, 5), bytes=B * BYTES_RENDER_FUSED,
-                                         kernels="bm_sample_kernel+bm_combine_fwd_kernel",
+                                             mask if save else None, 50.0, words if hint else None, ps_empty if hint else None)
+            # billed with the volume bytes of the tiles it READS (the live ones) + the map, not with the dense volume
+            rows["render_fwd_bm"] = dict(us=event_time_us(lambda: bm_fwd(True), iters, 5),
+                                         bytes=int(B * (tiles_live * 128 ** 3 * 4 + 128 * 128 * 4)),
+                                         tiles_live_frac=tiles_live,
+                                         kernels="bm_sample_kernel+bm_combine_fwd_kernel on GenRe's volume, %.0f %% of the tiles live "
+                                                 "(occupancy words of the camera forward)" % (100 * tiles_live),
                                          pmc=["bm_sample_kernel<true, true, 1024>@genre", "bm_combine_fwd_kernel@genre"],
                                          src=("common.hpp", "sph_render_bm.hip"))
             rows["render_fwd_bm_nosave"] = dict(us=event_time_us(lambda: bm_fwd(False), iters, 5),
-                                                bytes=B * BYTES_RENDER_FUSED, kernels="bm_sample_kernel (no saved state)")
+                                                bytes=rows["render_fwd_bm"]["bytes"], kernels="the same without saved state (inference)")
+            rows["render_fwd_bm_dense"] = dict(us=event_time_us(lambda: bm_fwd(True, False), iters, 5), bytes=B * BYTES_RENDER_FUSED,
+                                               kernels="the same volume WITHOUT the occupancy words: every tile is read")
             def bm_bwd_scatter():
                 render_lib.render_bm_backward(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"],
                                               TB["ent"], TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, tr, stash,

@@ -44,14 +44,14 @@ def _load():
                "genre_back_projection_forward_const": [C.c_float, C.c_float, C.c_int]}
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
                         ("genre_get_surface_mask", 5), ("genre_back_projection_forward_shifted", 5),
-                        ("genre_back_projection_backward_shifted", 8), ("genre_back_projection_forward_const", 3),
+                        ("genre_back_projection_backward_shifted", 8), ("genre_back_projection_forward_const", 4),
                         ("genre_spherical_back_proj_forward", 4),
                         ("genre_spherical_back_proj_backward", 5), ("genre_spherical_back_proj_forward_shifted", 4),
                         ("genre_spherical_back_proj_backward_shifted", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
                         ("genre_render_spherical_forward", 9), ("genre_render_spherical_backward", 11),
-                        ("genre_render_bm_forward", 11), ("genre_render_bm_backward", 14),
+                        ("genre_render_bm_forward", 13), ("genre_render_bm_backward", 14),
                         ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4),
                         ("genre_nnd_forward_host", 6), ("genre_nnd_backward_host", 8)):
         fn = getattr(lib, name, None)
@@ -131,9 +131,10 @@ class _CamBpLib:
         return _call("genre_back_projection_forward", depth, camdist, fl, voxel, cnt)
 
     @staticmethod
-    def back_projection_forward_const(depth, camdist, fl, voxel, cnt, shifted=False):
-        """extension: camdist / fl are Python floats (one camera for every image), passed by value"""
-        return _call("genre_back_projection_forward_const", depth, voxel, cnt,
+    def back_projection_forward_const(depth, camdist, fl, voxel, cnt, shifted=False, brick_live=None):
+        """extension: camdist / fl are Python floats (one camera for every image), passed by value.  brick_live (int32
+        [groups, nbx, nby, nbz]; leader pass only): receives which bricks of which image group hold anything but the fill value"""
+        return _call("genre_back_projection_forward_const", depth, voxel, cnt, brick_live,
                      scalars=(C.c_float(camdist), C.c_float(fl), C.c_int(1 if shifted else 0)))
 
     @staticmethod
@@ -216,11 +217,12 @@ class _RenderLib:
 
     @staticmethod
     def render_bm_forward(vox, out, segs, rec_f, fwd_rows, ray_ptr, ray_seg, ray_pre_as_f32, ps_scratch,
-                          p_stash=None, mask=None, pre_scale=0.0):
+                          p_stash=None, mask=None, pre_scale=0.0, brick_live=None, ps_empty=None):
         """batch-minor tile renderer (csrc/sph_render_bm.hip; tables: toolbox/_bm_tables.py).  p_stash (and mask when
-        pre_scale != 0) given: the state the backward needs is saved"""
+        pre_scale != 0) given: the state the backward needs is saved.  brick_live + ps_empty: the producer's occupancy words and
+        the geometry's constants -- tiles known to hold only the fill value are not read"""
         return _call("genre_render_bm_forward", vox, out, segs, rec_f, fwd_rows, ray_ptr, ray_seg, ray_pre_as_f32,
-                     ps_scratch, p_stash, mask, scalars=(C.c_float(pre_scale),))
+                     ps_scratch, p_stash, mask, brick_live, ps_empty, scalars=(C.c_float(pre_scale),))
 
     @staticmethod
     def render_bm_backward(grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, ent, rec_b, bwd_rows,

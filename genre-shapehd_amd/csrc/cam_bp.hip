@@ -764,9 +764,12 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
 // deterministic, and tdf / cnt BIT-IDENTICAL to a serial evaluation of the reference on every voxel
 // (tests/test_gpu_cam_bp.py::test_image_minor_camera_forward_is_deterministic_and_bit_identical_to_the_serial_reference).
 // Replaces round 4's opt-in cam_bm_brick_kernel (LDS bricks over 32 images: 335 us at batch 32 against 149 for the atomics).
+struct BrickFlags { int *p; int per_group, nbx, nby, nbz, bx, by, bz; };   // int32 [groups, nbx, nby, nbz]; p == nullptr: none
+
 template <int HALO>
 __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth, View5 vox, View5 cnt, float cam_dist, float f,
-                                                            float prefill, float bias, float post_scale, float post_bias)
+                                                            float prefill, float bias, float post_scale, float post_bias,
+                                                            BrickFlags flags)
 {
     constexpr int TW = 8 + 2 * HALO, TN = TW * TW, kWaves = kBlock / 64;
     __shared__ int s_key[kWaves][TN];
@@ -831,6 +834,10 @@ __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth,
                     const int iz = key % D.Z, iy = (key / D.Z) % D.Y, ix = key / (D.Z * D.Y);
                     vox.p[n * vox.s0 + c * vox.s1 + vox_off(vox, ix, iy, iz)] = post_bias + post_scale * ((sum - bias) / k);   // :304
                     cnt.p[n * cnt.s0 + c * cnt.s1 + vox_off(cnt, ix, iy, iz)] = k;
+                    // occupancy for the consumer (the batch-minor renderer skips tiles whose bricks hold the fill value in every
+                    // image of the group): one word per brick and image group, cleared by the host entry; every writer stores 1
+                    if (flags.p)
+                        flags.p[(((n / flags.per_group) * flags.nbx + ix / flags.bx) * flags.nby + iy / flags.by) * flags.nbz + iz / flags.bz] = 1;
                 }
             }
         }
@@ -1139,7 +1146,7 @@ inline CamMode cam_mode()
 template <bool SPH>
 int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *camdist, const genre_tensor *fl,
                  const genre_tensor *grid, const genre_tensor *voxel, const genre_tensor *cnt, void *stream,
-                 bool shifted = false, const float *byval = nullptr)
+                 bool shifted = false, const float *byval = nullptr, const genre_tensor *brick_live = nullptr)
 {
     Dims D{};
     if (!check_image(op, depth, D)) return 0;
@@ -1206,9 +1213,22 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         const float prefill = (float)(1.0 / (double)D.X);               // cam_back_projection.py:23-24 (res = X)
         const float bias = 1.0f / (float)mx;                             // K2: dist_bias / max(res)  (:304,:829)
         const int g = grid_for(tiles * 64, 1 << 16);
+        BrickFlags flags{nullptr, 1, 1, 1, 1, 1, 1, 1};
+        if (brick_live) {        // int32 [groups, nbx, nby, nbz]: word (g, b) <- 1 iff some voxel of brick b differs from the fill value
+            GENRE_REQUIRE(is_i32(brick_live, 4) && is_contiguous(brick_live) && brick_live->size[0] >= 1 && brick_live->size[1] >= 1 &&
+                              brick_live->size[2] >= 1 && brick_live->size[3] >= 1 && D.NC == 1 && D.N >= 1,
+                          "%s: brick_live must be a contiguous int32 [groups, nbx, nby, nbz] tensor (single-channel volumes)", op);
+            flags.p = (int *)brick_live->data;
+            flags.per_group = (int)((D.N + brick_live->size[0] - 1) / brick_live->size[0]);
+            flags.nbx = (int)brick_live->size[1]; flags.nby = (int)brick_live->size[2]; flags.nbz = (int)brick_live->size[3];
+            flags.bx = (D.X + flags.nbx - 1) / flags.nbx; flags.by = (D.Y + flags.nby - 1) / flags.nby;
+            flags.bz = (D.Z + flags.nbz - 1) / flags.nbz;
+            GENRE_REQUIRE(hipMemsetAsync(flags.p, 0, (size_t)numel(brick_live) * 4, st) == hipSuccess,
+                          "%s: hipMemsetAsync of the brick flags failed", op);
+        }
 #define GENRE_CAM_LEADER(HV)                                                                                              \
         cam_leader_kernel<HV><<<g, kBlock, 0, st>>>(D, view4(depth), view5(voxel), view5(cnt), byval[1], byval[0], prefill, bias, \
-                                                    post_scale, post_bias)
+                                                    post_scale, post_bias, flags)
         switch (halo < 1 ? 1 : halo) {
             case 1: GENRE_CAM_LEADER(1); break;
             case 2: GENRE_CAM_LEADER(2); break;
@@ -1219,6 +1239,8 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         GENRE_LAUNCH_CHECK("projection forward (leader pass)");
         return 1;
     }
+    GENRE_REQUIRE(brick_live == nullptr, "%s: brick_live is produced by the leader pass only (by-value camera, volumes without "
+                                         "contiguous z rows)", op);
     if (byval) mode = kBrick;
     if (mode != kScatter) {
         const int64_t nvox = (int64_t)D.X * D.Y * D.Z;
@@ -1340,12 +1362,12 @@ extern "C" int genre_back_projection_forward_shifted(const genre_tensor *depth, 
 }
 
 extern "C" int genre_back_projection_forward_const(const genre_tensor *depth, const genre_tensor *voxel,
-                                                   const genre_tensor *cnt, float camdist, float fl, int shifted,
-                                                   void *stream)
+                                                   const genre_tensor *cnt, const genre_tensor *brick_live, float camdist,
+                                                   float fl, int shifted, void *stream)
 {
     const float byval[2] = {fl, camdist};
     return forward_impl<false>("back_projection_forward_const", depth, nullptr, nullptr, nullptr, voxel, cnt, stream,
-                               shifted != 0, byval);
+                               shifted != 0, byval, brick_live);
 }
 
 extern "C" int genre_back_projection_backward_shifted(const genre_tensor *depth, const genre_tensor *fl,

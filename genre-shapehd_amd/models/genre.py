@@ -147,8 +147,17 @@ class GenReInference:
     forward of a fixed batch shape is captured once in a HIP graph and replayed (batch-1 latency is launch-bound:
     ~150 kernels of a few microseconds each)."""
 
-    def __init__(self, net=None, device="cuda", graph=False):
+    def __init__(self, net=None, device="cuda", graph=False, channels_last=True):
+        """channels_last: the two 2-D U-ResNets (MarrNet-1, the inpainting network) keep their weights and activations in
+        torch.channels_last.  MIOpen's fastest 2-D solvers on gfx950 are its igemm_*_nhwc kernels, which it wraps in
+        batched_transpose launches when the tensors arrive NCHW (profiles/r05a_m1_b1_kernel_stats.txt: ~70 transposes per
+        forward); NHWC tensors need none: 5.57 -> 5.45 ms per forward at batch 1, 22.3 -> 21.9 ms at batch 8
+        (profiles/r05d_m1_rewrites_experiment.txt), logits equal to 3e-6.  Values, state_dict keys and shapes are unchanged (a
+        memory format is a stride permutation); the 3-D refiner stays NCDHW (channels_last_3d measured 2x slower)"""
         self.net = (net or GenReNet()).to(device).eval()
+        if channels_last and torch.device(device).type == "cuda":
+            self.net.depth_and_inpaint.net1.to(memory_format=torch.channels_last)
+            self.net.depth_and_inpaint.net2.to(memory_format=torch.channels_last)
         self.device = torch.device(device)
         self.graph = graph
         self._captured = {}

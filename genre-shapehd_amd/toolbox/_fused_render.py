@@ -221,6 +221,56 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
     return t
 
 
+# ---- occupancy hint: producer (Camera_back_projection_layer, image-minor volumes) -> consumer (the batch-minor forward) --------
+# The camera forward's leader pass knows which 4x8x8-voxel bricks of which group of 32 images received a point; everything else
+# holds its fill value.  It writes one word per (group, brick) -- include/genre_hip.h: brick_live -- and the layer hangs them on
+# the tensor it returns, with the tensor's version counter.  The renderer uses them only if the SAME tensor object arrives with
+# the same version (any in-place write, any other tensor: the hint is ignored and every tile is read), so nothing can go stale.
+_GROUP = 32                         # images per group = lanes of a half-wave (csrc/sph_render_bm.hip: kImgs)
+
+
+def _bm_brick():
+    code = _loader()._lib.genre_bm_brick()
+    return code // 100, (code // 10) % 10, code % 10
+
+
+def new_brick_words(n, res, device):
+    bx, by, bz = _bm_brick()
+    return torch.empty((-(-n // _GROUP), -(-res // bx), -(-res // by), -(-res // bz)), dtype=torch.int32, device=device)
+
+
+def attach_hint(vol, words, res):
+    import numpy as np
+    fill = float(np.float32(1) - np.float32(res) * np.float32(1.0 / res))      # csrc/cam_bp.hip: fill_val of the shifted op
+    vol._genre_brick_hint = (words, fill, vol._version)
+    return vol
+
+
+def occupancy_hint(vox, t, pre_scale, lib):
+    """(brick_live, ps_empty) for render_bm_forward, or (None, None): the words the producer hung on `vox` -- if it still is what the
+    producer wrote -- and the geometry's (P, S) constants on the constant volume, built on first use by rendering one"""
+    hint = getattr(vox, "_genre_brick_hint", None)
+    if hint is None or hint[2] != vox._version:
+        return None, None
+    words, fill, _ = hint
+    bx, by, bz = _bm_brick()
+    n, _, X, Y, Z = vox.shape
+    if tuple(words.shape) != (-(-n // _GROUP), -(-X // bx), -(-Y // by), -(-Z // bz)) or words.device != vox.device:
+        return None, None
+    key = ("ps_empty", fill, float(pre_scale))
+    if key not in t:
+        if torch.cuda.is_current_stream_capturing():
+            return None, None               # (built outside graph capture only: callers warm up before they capture)
+        const = empty_batch_minor((_GROUP, 1, X, Y, Z), torch.float32, vox.device).fill_(fill)
+        res_map = int(round((t["ray_ptr"].shape[0] - 1) ** 0.5))
+        out = torch.empty((_GROUP, 1, res_map, res_map), dtype=torch.float32, device=vox.device)
+        ps = torch.empty((t["segs"].shape[0] * 2 * _GROUP,), dtype=torch.float32, device=vox.device)
+        lib.render_bm_forward(const, out, t["segs"], t["rec_f"], t["fwd_rows"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], ps,
+                              None, None, float(pre_scale))
+        t[key] = ps.view(-1, 2, _GROUP)[:, :, 0].contiguous()              # [nseg, 2], ray order
+    return words, t[key]
+
+
 def is_batch_minor(vox):
     """image index fastest in memory (the layout the batch-minor kernels of csrc/sph_render.hip want)"""
     return vox.dim() == 5 and vox.shape[1] == 1 and vox.shape[0] >= 16 and vox.stride(0) == 1
@@ -261,8 +311,9 @@ class RenderSphericalFused(Function):
                 if pre_scale:
                     mask = torch.empty((groups * vox.shape[2] * vox.shape[3] * vox.shape[4] + groups,), dtype=torch.int32,
                                        device=vox.device)
+            words, ps_empty = occupancy_hint(vox, t, ctx.pre_scale, lib)
             lib.render_bm_forward(vox, out, t["segs"], t["rec_f"], t["fwd_rows"], t["ray_ptr"], t["ray_seg"],
-                                  t["ray_pre"], ps, stash, mask, ctx.pre_scale)
+                                  t["ray_pre"], ps, stash, mask, ctx.pre_scale, words, ps_empty)
             ctx.vox_shape = vox.shape
             ctx.mask = mask
             ctx.save_for_backward(dirs64, depth_weight, ps, stash)

@@ -38,6 +38,12 @@ def leader_halo(res, fl, cam_dist):
     return int(b * (1.0 + 1e-4) + 1e-3)
 
 
+def leader_pass_serves(res, const):
+    """will an image-minor volume with camera `const` = (fl, cam_dist) (Python floats) take fill + the leader pass?  The
+    library's own precondition (csrc/cam_bp.hip: forward_impl), asked by the Function below and by the layer"""
+    return const is not None and _cam_mode() in ("", "auto") and 0 <= leader_halo(res, const[0], const[1]) <= 4
+
+
 class CameraBackProjection(Function):
 
     @staticmethod
@@ -76,10 +82,12 @@ class ShiftedCameraBackProjection(Function):
     values, one full-volume elementwise pass less in each direction.  Used by the layer."""
 
     @staticmethod
-    def forward(ctx, depth_t, fl, cam_dist, res=128, batch_minor=False, const=None):
+    def forward(ctx, depth_t, fl, cam_dist, res=128, batch_minor=False, const=None, brick_live=None):
         """const = (fl, cam_dist) as Python floats when the two tensors are filled with those constants (the layer's
         default call, camera_backprojection_module.py:16-21): the forward then takes the by-value entry point (no
-        loads of the camera in front of the brick screen); the tensors are still what the backward reads"""
+        loads of the camera in front of the brick screen); the tensors are still what the backward reads.
+        brick_live: optional int32 [groups, nbx, nby, nbz] the op fills with its occupancy words when it takes the leader pass
+        (image-minor output, camera by value) -- ctx.hinted says whether it did"""
         assert depth_t.dim() == 4
         n, nc = depth_t.shape[0], depth_t.shape[1]
         assert fl.dim() == 2 and tuple(fl.shape) == (n, nc)
@@ -102,11 +110,13 @@ class ShiftedCameraBackProjection(Function):
         # instead of an error
         image_minor = batch_minor and nc == 1
         if image_minor:
-            by_value = const is not None and _cam_mode() in ("", "auto") and 0 <= leader_halo(res, const[0], const[1]) <= 4
+            by_value = leader_pass_serves(res, const)
         else:
             by_value = const is not None and n * nc <= 65535 and res % 4 == 0 and _cam_mode() in ("", "auto", "brick")
+        ctx.hinted = bool(by_value and image_minor and brick_live is not None)
         if by_value:
-            cam_bp_lib.back_projection_forward_const(depth_t, const[1], const[0], out, cnt, shifted=True)
+            cam_bp_lib.back_projection_forward_const(depth_t, const[1], const[0], out, cnt, shifted=True,
+                                                     brick_live=brick_live if ctx.hinted else None)
         else:
             cam_bp_lib.back_projection_forward_shifted(depth_t, cam_dist, fl, out, cnt)
         ctx.save_for_backward(depth_t, fl, cam_dist, cnt)
@@ -123,4 +133,4 @@ class ShiftedCameraBackProjection(Function):
         grad_camdist = torch.empty_like(grad_fl)
         cam_bp_lib.back_projection_backward_shifted(depth_t, fl, cam_dist, cnt, grad_output,
                                                     grad_depth, grad_camdist, grad_fl)
-        return grad_depth, grad_fl, grad_camdist, None, None, None
+        return grad_depth, grad_fl, grad_camdist, None, None, None, None

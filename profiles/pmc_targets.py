@@ -79,8 +79,9 @@ for vol_std, vol_bm in ((proj_std, proj_bm), (soft_std, soft_bm)):
         lib.render_spherical_backward(vol_std, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"],
                                       vbuf, T["kin"], 50.0, live)
         if TB is not None:
+            words, ps_empty = (None, None) if vol_bm is soft_bm else _fused_render.occupancy_hint(proj_bm, TB, 50.0, lib)
             lib.render_bm_forward(vol_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"], TB["ray_seg"],
-                                  TB["ray_pre"], ps, stash, mask, 50.0)
+                                  TB["ray_pre"], ps, stash, mask, 50.0, words, ps_empty)
             lib.render_bm_backward(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"],
                                    TB["rec_b"], TB["bwd_rows"], mod.depth_weight, ps, trs, stash, mask, 50.0, TB["pull_code"])
 # Chamfer forward (VALU-bound: used with --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ...)

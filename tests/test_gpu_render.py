@@ -268,6 +268,54 @@ def test_standard_layout_backward_skips_what_the_clamp_blocks(genre, dev):
     assert torch.equal(x.grad, grads[0])
 
 
+@pytest.mark.parametrize("n", [32, 19, 40])
+def test_occupancy_hint_changes_nothing_but_the_traffic(n, genre, dev):
+    """Camera_back_projection_layer (image-minor, camera by value) hangs the leader pass's occupancy words on the volume it
+    returns; the batch-minor forward then copies precomputed constants for tiles whose bricks hold only the fill value instead
+    of reading them (csrc/sph_render_bm.hip).  Same map bit for bit, same gradients (to the 1 ulp of the backward's own atomics) as without the words --
+    at pre_scale 50 (GenRe's chain: zero gradient) and 0.9 (occupied voxels pass the clamp: a live gradient) --, words that
+    really are sparse, and a hint that is ignored as soon as the volume is written to."""
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    d = torch.from_numpy(inputs.batch_depth(n, seed=11)).to(dev)
+    layer = genre.Camera_back_projection_layer(batch_minor=True).to(dev)
+    mod = genre.render_spherical().to(dev)
+    rng = np.random.default_rng(5)
+    g = torch.from_numpy(rng.standard_normal((n, 1, 160, 160)).astype(np.float32)).to(dev)
+    for scale in (50.0, 0.9):
+        da, db = d.clone().requires_grad_(True), d.clone().requires_grad_(True)
+        pa = layer(da)
+        words, fill, ver = pa._genre_brick_hint
+        assert pa.stride(0) == 1 and fill == 0.0 and ver == pa._version
+        live = (words != 0).float().mean().item()
+        assert 0.02 < live < 0.6, live                                   # surfaces: most bricks are empty
+        # every voxel of a dead brick holds the fill value in every image of its group
+        occ = (pa.detach() != fill).reshape(n, 32, 4, 16, 8, 16, 8).any(6).any(4).any(2)          # [n, 32, 16, 16] bricks
+        for gi in range(words.shape[0]):
+            assert torch.equal(occ[gi * 32:(gi + 1) * 32].any(0), words[gi] != 0)
+        pb = layer(db)
+        del pb._genre_brick_hint                                          # the same volume without the words
+        assert F.occupancy_hint(pb, None, scale, None) == (None, None)
+        oa, ob = mod(pa, pre_scale=scale, pad=16), mod(pb, pre_scale=scale, pad=16)
+        assert torch.equal(oa, ob)
+        oa.backward(g)
+        ob.backward(g)
+        # (the forward's whole saved state -- scratch lines, masks, saved samples -- is bit-identical with and without the words;
+        # the renderer's backward itself is reproducible to 1 ulp only: the bricks of the dense centre are split over several
+        # workgroups that add onto pre-zeroed voxels with float atomics, csrc/sph_render_bm.hip -- 12 of 67 M voxels differ by
+        # 1.2e-7 between two runs on identical inputs)
+        scale_g = max(1.0, db.grad.abs().max().item())
+        assert (da.grad - db.grad).abs().max().item() <= 1e-6 * scale_g
+        assert (da.grad.abs().max().item() > 0) == (scale == 0.9)
+    # a volume that was written to after the producer returned it: the words are stale and must not be used
+    with torch.no_grad():
+        pc = layer(d)
+        pc[:, :, 3:9, 100:120, 60:64] += 0.004                            # a dead region becomes non-constant (in place: version moves)
+        assert F.occupancy_hint(pc, None, 50.0, None) == (None, None)
+        ref = F.empty_batch_minor(pc.shape, torch.float32, dev)
+        ref.copy_(pc)
+        assert torch.equal(mod(pc, pre_scale=50.0, pad=16), mod(ref, pre_scale=50.0, pad=16))
+
+
 def test_camera_layer_batch_minor_option(genre, dev):
     """Camera_back_projection_layer(batch_minor=True): same values, image-minor memory; the chain through the
     renderer equals the standard-layout chain"""
