@@ -302,9 +302,7 @@ def kernel_table(G, dev, B):
             # anything but the fill value); the sampler copies constants for tiles it knows to be empty instead of reading them
             words, ps_empty = _fused_render.occupancy_hint(proj_bm, TB, 50.0, render_lib)
             assert words is not None, "the layer's image-minor volume carries no occupancy words"
-            wl = torch.nn.functional.pad((words != 0).float(), (0, 1, 0, 1, 0, 1))
-            tiles_live = torch.stack([wl[:, a:a + words.shape[1], b:b + words.shape[2], c:c + words.shape[3]]
-                                      for a in (0, 1) for b in (0, 1) for c in (0, 1)]).amax(0).mean().item()
+            tiles_live = (words != 0).float().mean().item()             # share of the tiles (brick + high halo) that are read
 
             def bm_fwd(save, hint=True):
                 render_lib.render_bm_forward(proj_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"],

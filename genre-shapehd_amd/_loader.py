@@ -131,10 +131,10 @@ class _CamBpLib:
         return _call("genre_back_projection_forward", depth, camdist, fl, voxel, cnt)
 
     @staticmethod
-    def back_projection_forward_const(depth, camdist, fl, voxel, cnt, shifted=False, brick_live=None):
-        """extension: camdist / fl are Python floats (one camera for every image), passed by value.  brick_live (int32
+    def back_projection_forward_const(depth, camdist, fl, voxel, cnt, shifted=False, tile_live=None):
+        """extension: camdist / fl are Python floats (one camera for every image), passed by value.  tile_live (int32
         [groups, nbx, nby, nbz]; leader pass only): receives which bricks of which image group hold anything but the fill value"""
-        return _call("genre_back_projection_forward_const", depth, voxel, cnt, brick_live,
+        return _call("genre_back_projection_forward_const", depth, voxel, cnt, tile_live,
                      scalars=(C.c_float(camdist), C.c_float(fl), C.c_int(1 if shifted else 0)))
 
     @staticmethod
@@ -217,12 +217,12 @@ class _RenderLib:
 
     @staticmethod
     def render_bm_forward(vox, out, segs, rec_f, fwd_rows, ray_ptr, ray_seg, ray_pre_as_f32, ps_scratch,
-                          p_stash=None, mask=None, pre_scale=0.0, brick_live=None, ps_empty=None):
+                          p_stash=None, mask=None, pre_scale=0.0, tile_live=None, ps_empty=None):
         """batch-minor tile renderer (csrc/sph_render_bm.hip; tables: toolbox/_bm_tables.py).  p_stash (and mask when
-        pre_scale != 0) given: the state the backward needs is saved.  brick_live + ps_empty: the producer's occupancy words and
+        pre_scale != 0) given: the state the backward needs is saved.  tile_live + ps_empty: the producer's occupancy words and
         the geometry's constants -- tiles known to hold only the fill value are not read"""
         return _call("genre_render_bm_forward", vox, out, segs, rec_f, fwd_rows, ray_ptr, ray_seg, ray_pre_as_f32,
-                     ps_scratch, p_stash, mask, brick_live, ps_empty, scalars=(C.c_float(pre_scale),))
+                     ps_scratch, p_stash, mask, tile_live, ps_empty, scalars=(C.c_float(pre_scale),))
 
     @staticmethod
     def render_bm_backward(grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, ent, rec_b, bwd_rows,

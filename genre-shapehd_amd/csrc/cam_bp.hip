@@ -834,10 +834,19 @@ __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth,
                     const int iz = key % D.Z, iy = (key / D.Z) % D.Y, ix = key / (D.Z * D.Y);
                     vox.p[n * vox.s0 + c * vox.s1 + vox_off(vox, ix, iy, iz)] = post_bias + post_scale * ((sum - bias) / k);   // :304
                     cnt.p[n * cnt.s0 + c * cnt.s1 + vox_off(cnt, ix, iy, iz)] = k;
-                    // occupancy for the consumer (the batch-minor renderer skips tiles whose bricks hold the fill value in every
-                    // image of the group): one word per brick and image group, cleared by the host entry; every writer stores 1
-                    if (flags.p)
-                        flags.p[(((n / flags.per_group) * flags.nbx + ix / flags.bx) * flags.nby + iy / flags.by) * flags.nbz + iz / flags.bz] = 1;
+                    // occupancy for the consumer (the batch-minor renderer skips tiles -- a brick plus the voxels one step beyond
+                    // its HIGH faces -- that hold the fill value in every image of the group): one word per brick and image group,
+                    // cleared by the host entry, set for the voxel's brick and its <= 7 neighbours on the LOW side (whose tiles
+                    // may reach this voxel); every writer stores 1
+                    if (flags.p) {
+                        int *fg = flags.p + (size_t)(n / flags.per_group) * flags.nbx * flags.nby * flags.nbz;
+                        const int b0 = ix / flags.bx, b1 = iy / flags.by, b2 = iz / flags.bz;
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const int x = b0 - (q & 1), y = b1 - ((q >> 1) & 1), z = b2 - (q >> 2);
+                            if (x >= 0 && y >= 0 && z >= 0) fg[(x * flags.nby + y) * flags.nbz + z] = 1;
+                        }
+                    }
                 }
             }
         }
@@ -1146,7 +1155,7 @@ inline CamMode cam_mode()
 template <bool SPH>
 int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *camdist, const genre_tensor *fl,
                  const genre_tensor *grid, const genre_tensor *voxel, const genre_tensor *cnt, void *stream,
-                 bool shifted = false, const float *byval = nullptr, const genre_tensor *brick_live = nullptr)
+                 bool shifted = false, const float *byval = nullptr, const genre_tensor *tile_live = nullptr)
 {
     Dims D{};
     if (!check_image(op, depth, D)) return 0;
@@ -1214,16 +1223,20 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         const float bias = 1.0f / (float)mx;                             // K2: dist_bias / max(res)  (:304,:829)
         const int g = grid_for(tiles * 64, 1 << 16);
         BrickFlags flags{nullptr, 1, 1, 1, 1, 1, 1, 1};
-        if (brick_live) {        // int32 [groups, nbx, nby, nbz]: word (g, b) <- 1 iff some voxel of brick b differs from the fill value
-            GENRE_REQUIRE(is_i32(brick_live, 4) && is_contiguous(brick_live) && brick_live->size[0] >= 1 && brick_live->size[1] >= 1 &&
-                              brick_live->size[2] >= 1 && brick_live->size[3] >= 1 && D.NC == 1 && D.N >= 1,
-                          "%s: brick_live must be a contiguous int32 [groups, nbx, nby, nbz] tensor (single-channel volumes)", op);
-            flags.p = (int *)brick_live->data;
-            flags.per_group = (int)((D.N + brick_live->size[0] - 1) / brick_live->size[0]);
-            flags.nbx = (int)brick_live->size[1]; flags.nby = (int)brick_live->size[2]; flags.nbz = (int)brick_live->size[3];
+        if (tile_live) {         // int32 [groups, nbx, nby, nbz]: word (g, b) <- 1 iff brick b or a high-side neighbour received a point
+            GENRE_REQUIRE(is_i32(tile_live, 4) && is_contiguous(tile_live) && tile_live->size[0] >= 1 && tile_live->size[1] >= 1 &&
+                              tile_live->size[2] >= 1 && tile_live->size[3] >= 1 && D.NC == 1 && D.N >= 1,
+                          "%s: tile_live must be a contiguous int32 [groups, nbx, nby, nbz] tensor (single-channel volumes)", op);
+            flags.p = (int *)tile_live->data;
+            constexpr int kGroupImgs = 32;                               // the batch-minor renderer's image groups (sph_render_bm.hip: kImgs)
+            GENRE_REQUIRE(tile_live->size[0] == (D.N + kGroupImgs - 1) / kGroupImgs,
+                          "%s: tile_live needs one slab per group of 32 consecutive images: size[0] == %d", op,
+                          (D.N + kGroupImgs - 1) / kGroupImgs);
+            flags.per_group = kGroupImgs;
+            flags.nbx = (int)tile_live->size[1]; flags.nby = (int)tile_live->size[2]; flags.nbz = (int)tile_live->size[3];
             flags.bx = (D.X + flags.nbx - 1) / flags.nbx; flags.by = (D.Y + flags.nby - 1) / flags.nby;
             flags.bz = (D.Z + flags.nbz - 1) / flags.nbz;
-            GENRE_REQUIRE(hipMemsetAsync(flags.p, 0, (size_t)numel(brick_live) * 4, st) == hipSuccess,
+            GENRE_REQUIRE(hipMemsetAsync(flags.p, 0, (size_t)numel(tile_live) * 4, st) == hipSuccess,
                           "%s: hipMemsetAsync of the brick flags failed", op);
         }
 #define GENRE_CAM_LEADER(HV)                                                                                              \
@@ -1239,7 +1252,7 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         GENRE_LAUNCH_CHECK("projection forward (leader pass)");
         return 1;
     }
-    GENRE_REQUIRE(brick_live == nullptr, "%s: brick_live is produced by the leader pass only (by-value camera, volumes without "
+    GENRE_REQUIRE(tile_live == nullptr, "%s: tile_live is produced by the leader pass only (by-value camera, volumes without "
                                          "contiguous z rows)", op);
     if (byval) mode = kBrick;
     if (mode != kScatter) {
@@ -1362,12 +1375,12 @@ extern "C" int genre_back_projection_forward_shifted(const genre_tensor *depth, 
 }
 
 extern "C" int genre_back_projection_forward_const(const genre_tensor *depth, const genre_tensor *voxel,
-                                                   const genre_tensor *cnt, const genre_tensor *brick_live, float camdist,
+                                                   const genre_tensor *cnt, const genre_tensor *tile_live, float camdist,
                                                    float fl, int shifted, void *stream)
 {
     const float byval[2] = {fl, camdist};
     return forward_impl<false>("back_projection_forward_const", depth, nullptr, nullptr, nullptr, voxel, cnt, stream,
-                               shifted != 0, byval, brick_live);
+                               shifted != 0, byval, tile_live);
 }
 
 extern "C" int genre_back_projection_backward_shifted(const genre_tensor *depth, const genre_tensor *fl,

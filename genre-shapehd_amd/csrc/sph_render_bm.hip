@@ -95,8 +95,8 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
                                                              const int4 *__restrict__ segs, const int *__restrict__ rec_f,
                                                              const int4 *__restrict__ rows, float *__restrict__ ps,
                                                              float *__restrict__ stash, unsigned *__restrict__ mask,
-                                                             const int *__restrict__ brick_live,
-                                                             const float2 *__restrict__ ps_empty)
+                                                             const int *__restrict__ tile_live,
+                                                             const float4 *__restrict__ ps_empty)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     float *tile = lds_f;                                               // [kLinesF][32]
@@ -108,34 +108,27 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     brick_origin(D, row.x, ox, oy, oz);
     // WHAT THE PRODUCER KNOWS TO BE EMPTY IS NOT READ (round 5).  The volumes this renderer sees are surfaces: a depth map
     // back-projected into 128^3 voxels leaves ~0.5 % of them occupied, and over a group of 32 images 61 % of the tiles (brick +
-    // high halo) hold nothing but the producer's fill value.  brick_live [groups][bricks] (written by the camera forward's
-    // leader pass, csrc/cam_bp.hip; include/genre_hip.h) says which bricks hold anything else; a tile all of whose <= 8 bricks
-    // are dead is the constant tile, and the (P, S) pair of each of its segments is a constant of the geometry: ps_empty, the
-    // sampler's own output on the constant volume (built once per geometry by the caller, so the values are bit-identical to
-    // what the march below would compute).  Such a workgroup copies the constants to its segments' scratch lines, clears its
-    // brick's clamp masks and is done: no tile loads (268 MB per group of mostly fill values), no records, no march.
-    if (brick_live != nullptr) {
-        const int nbx = (D.X + kBX - 1) / kBX, nby = (D.Y + kBY - 1) / kBY, nbz = (D.Z + kBZ - 1) / kBZ;
-        const int bz = row.x % nbz, by = (row.x / nbz) % nby, bx = row.x / (nbz * nby);
-        const int *fl = brick_live + (size_t)g * nbx * nby * nbz;
-        int live = 0;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int x = bx + (c & 1), y = by + ((c >> 1) & 1), z = bz + (c >> 2);
-            if (x < nbx && y < nby && z < nbz) live |= fl[(x * nby + y) * nbz + z];
-        }
-        if (live == 0) {
+    // high halo) hold nothing but the producer's fill value.  tile_live [groups][bricks] (written by the camera forward's leader
+    // pass, csrc/cam_bp.hip; include/genre_hip.h) says which tiles hold anything else; on the constant tile the (P, S) pair of
+    // every segment is a constant of the geometry: ps_empty [segment] = (P, S, the segment's scratch line), the sampler's own
+    // output on the constant volume (built once per geometry by the caller: bit-identical to what the march below computes).
+    // A dead workgroup copies the constants to its segments' scratch lines, clears its brick's clamp masks and is done: no
+    // tile loads (268 MB per group, mostly fill values), no records, no march.  (The whole dead path sits HERE, in front of
+    // every load of the live path and with its own loads inside it: a load that is only conditionally outstanding when the
+    // march loop is entered costs that loop its exact waits -- measured: vmcnt(1) -> vmcnt(0), +55 us.)
+    if (tile_live != nullptr) {
+        const int nb = ((D.X + kBX - 1) / kBX) * ((D.Y + kBY - 1) / kBY) * ((D.Z + kBZ - 1) / kBZ);
+        if (tile_live[(size_t)g * nb + row.x] == 0) {
             if (PS && SAVE) {
                 for (int e = threadIdx.x; e < kBX * kBY * kBZ; e += NT) {
                     const int x = ox + e / (kBY * kBZ), y = oy + (e / kBZ) % kBY, z = oz + e % kBZ;
                     if (x < D.X && y < D.Y && z < D.Z) mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] = 0u;
                 }
             }
-            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-            for (int sI = row.y + wv; sI < row.z; sI += NT / 64) {
-                const int line = segs[sI].x;                              // the segment's scratch line (ray order)
-                const float2 c = ps_empty[line];
-                ps[(size_t)(g * D.nseg + line) * 2 * kImgs + ln] = ln < kImgs ? c.x : c.y;
+            const int ln = threadIdx.x & 63;
+            for (int sd = row.y + (int)(threadIdx.x >> 6); sd < row.z; sd += NT / 64) {
+                const float4 pe = ps_empty[sd];
+                ps[(size_t)(g * D.nseg + __float_as_int(pe.z)) * 2 * kImgs + ln] = ln < kImgs ? pe.x : pe.y;
             }
             return;
         }
@@ -836,7 +829,7 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
                                        const genre_tensor *ray_ptr, const genre_tensor *ray_seg,
                                        const genre_tensor *ray_pre, const genre_tensor *ps_scratch,
                                        const genre_tensor *p_stash, const genre_tensor *mask,
-                                       const genre_tensor *brick_live, const genre_tensor *ps_empty, float pre_scale,
+                                       const genre_tensor *tile_live, const genre_tensor *ps_empty, float pre_scale,
                                        void *stream)
 {
     const char *op = "render_bm_forward";
@@ -859,19 +852,19 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
                       "%s: pre_scale with a saved state needs mask int32 [groups*X*Y*Z + groups] (one word per image group behind the voxel masks)", op);
     }
     const int *live_p = nullptr;
-    const float2 *empty_p = nullptr;
-    if (brick_live != nullptr || ps_empty != nullptr) {    // the producer's occupancy words + this geometry's constants (both or none)
-        const int64_t nb = (int64_t)((D.X + kBX - 1) / kBX) * ((D.Y + kBY - 1) / kBY) * ((D.Z + kBZ - 1) / kBZ);
-        GENRE_REQUIRE(brick_live && ps_empty && is_i32(brick_live, 4) && is_contiguous(brick_live) &&
-                          brick_live->size[0] == D.groups && brick_live->size[1] == (D.X + kBX - 1) / kBX &&
-                          brick_live->size[2] == (D.Y + kBY - 1) / kBY && brick_live->size[3] == (D.Z + kBZ - 1) / kBZ && nb > 0,
-                      "%s: brick_live must be int32 [groups = %d, %d, %d, %d] (one word per %dx%dx%d-voxel brick and image group)",
+    const float4 *empty_p = nullptr;
+    if (tile_live != nullptr || ps_empty != nullptr) {     // the producer's occupancy words + this geometry's constants (both or none)
+        GENRE_REQUIRE(tile_live && ps_empty && is_i32(tile_live, 4) && is_contiguous(tile_live) &&
+                          tile_live->size[0] == D.groups && tile_live->size[1] == (D.X + kBX - 1) / kBX &&
+                          tile_live->size[2] == (D.Y + kBY - 1) / kBY && tile_live->size[3] == (D.Z + kBZ - 1) / kBZ,
+                      "%s: tile_live must be int32 [groups = %d, %d, %d, %d] (one word per %dx%dx%d-voxel brick and image group)",
                       op, D.groups, (D.X + kBX - 1) / kBX, (D.Y + kBY - 1) / kBY, (D.Z + kBZ - 1) / kBZ, kBX, kBY, kBZ);
-        GENRE_REQUIRE(is_f32(ps_empty, 2) && is_contiguous(ps_empty) && ps_empty->size[0] == D.nseg && ps_empty->size[1] == 2 &&
-                          ((uintptr_t)ps_empty->data & 7u) == 0,
-                      "%s: ps_empty must be fp32 [nseg, 2]: (P, S) of every segment (in ray order) on the constant volume", op);
-        live_p = (const int *)brick_live->data;
-        empty_p = (const float2 *)ps_empty->data;
+        GENRE_REQUIRE(is_f32(ps_empty, 2) && is_contiguous(ps_empty) && ps_empty->size[0] == D.nseg && ps_empty->size[1] == 4 &&
+                          aligned16(ps_empty->data),
+                      "%s: ps_empty must be fp32 [nseg, 4]: (P, S, scratch line as int32 bits, 0) of every segment on the "
+                      "constant volume", op);
+        live_p = (const int *)tile_live->data;
+        empty_p = (const float4 *)ps_empty->data;
     }
     hipStream_t st = (hipStream_t)stream;
     if (save && pre_scale != 0.0f) {          // the groups' "some voxel passes the clamp" words behind the masks (set by the sampler)

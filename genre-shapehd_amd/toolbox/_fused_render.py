@@ -223,7 +223,8 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
 
 # ---- occupancy hint: producer (Camera_back_projection_layer, image-minor volumes) -> consumer (the batch-minor forward) --------
 # The camera forward's leader pass knows which 4x8x8-voxel bricks of which group of 32 images received a point; everything else
-# holds its fill value.  It writes one word per (group, brick) -- include/genre_hip.h: brick_live -- and the layer hangs them on
+# holds its fill value.  It writes one word per (group, brick) -- set for a brick whose TILE (the brick plus the voxels one step
+# beyond its high faces: what the sampler stages) can reach a point; include/genre_hip.h: tile_live -- and the layer hangs them on
 # the tensor it returns, with the tensor's version counter.  The renderer uses them only if the SAME tensor object arrives with
 # the same version (any in-place write, any other tensor: the hint is ignored and every tile is read), so nothing can go stale.
 _GROUP = 32                         # images per group = lanes of a half-wave (csrc/sph_render_bm.hip: kImgs)
@@ -247,7 +248,7 @@ def attach_hint(vol, words, res):
 
 
 def occupancy_hint(vox, t, pre_scale, lib):
-    """(brick_live, ps_empty) for render_bm_forward, or (None, None): the words the producer hung on `vox` -- if it still is what the
+    """(tile_live, ps_empty) for render_bm_forward, or (None, None): the words the producer hung on `vox` -- if it still is what the
     producer wrote -- and the geometry's (P, S) constants on the constant volume, built on first use by rendering one"""
     hint = getattr(vox, "_genre_brick_hint", None)
     if hint is None or hint[2] != vox._version:
@@ -267,7 +268,11 @@ def occupancy_hint(vox, t, pre_scale, lib):
         ps = torch.empty((t["segs"].shape[0] * 2 * _GROUP,), dtype=torch.float32, device=vox.device)
         lib.render_bm_forward(const, out, t["segs"], t["rec_f"], t["fwd_rows"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], ps,
                               None, None, float(pre_scale))
-        t[key] = ps.view(-1, 2, _GROUP)[:, :, 0].contiguous()              # [nseg, 2], ray order
+        line = t["segs"][:, 0].long()                                     # scratch line (ray order) of every segment, table order
+        pe = torch.zeros((line.shape[0], 4), dtype=torch.int32, device=vox.device)
+        pe.view(torch.float32)[:, :2] = ps.view(-1, 2, _GROUP)[:, :, 0][line]
+        pe[:, 2] = t["segs"][:, 0]
+        t[key] = pe.view(torch.float32)                                    # [nseg, 4] = (P, S, line bits, 0), table order
     return words, t[key]
 
 

@@ -82,11 +82,11 @@ class ShiftedCameraBackProjection(Function):
     values, one full-volume elementwise pass less in each direction.  Used by the layer."""
 
     @staticmethod
-    def forward(ctx, depth_t, fl, cam_dist, res=128, batch_minor=False, const=None, brick_live=None):
+    def forward(ctx, depth_t, fl, cam_dist, res=128, batch_minor=False, const=None, tile_live=None):
         """const = (fl, cam_dist) as Python floats when the two tensors are filled with those constants (the layer's
         default call, camera_backprojection_module.py:16-21): the forward then takes the by-value entry point (no
         loads of the camera in front of the brick screen); the tensors are still what the backward reads.
-        brick_live: optional int32 [groups, nbx, nby, nbz] the op fills with its occupancy words when it takes the leader pass
+        tile_live: optional int32 [groups, nbx, nby, nbz] the op fills with its occupancy words when it takes the leader pass
         (image-minor output, camera by value) -- ctx.hinted says whether it did"""
         assert depth_t.dim() == 4
         n, nc = depth_t.shape[0], depth_t.shape[1]
@@ -113,10 +113,10 @@ class ShiftedCameraBackProjection(Function):
             by_value = leader_pass_serves(res, const)
         else:
             by_value = const is not None and n * nc <= 65535 and res % 4 == 0 and _cam_mode() in ("", "auto", "brick")
-        ctx.hinted = bool(by_value and image_minor and brick_live is not None)
+        ctx.hinted = bool(by_value and image_minor and tile_live is not None)
         if by_value:
             cam_bp_lib.back_projection_forward_const(depth_t, const[1], const[0], out, cnt, shifted=True,
-                                                     brick_live=brick_live if ctx.hinted else None)
+                                                     tile_live=tile_live if ctx.hinted else None)
         else:
             cam_bp_lib.back_projection_forward_shifted(depth_t, cam_dist, fl, out, cnt)
         ctx.save_for_backward(depth_t, fl, cam_dist, cnt)

@@ -112,13 +112,15 @@ int genre_back_projection_backward_shifted(const genre_tensor *depth, const genr
  *    tdf and cnt bit-identical to a serial evaluation of the reference (back_projection_kernel.cu:215-305).  H = how many pixels
  *    apart two points of one voxel can project, bounded on the host from (fl, camdist, res); cameras with H > 4 (or closer than
  *    0.55 to the grid centre) return 0 -- pass tensors there (fill + scatter with float atomics + normalise).
- * brick_live (optional, leader pass only; NULL otherwise): int32 [groups, nbx, nby, nbz], contiguous.  The volume's images are
- * cut into `groups` consecutive groups of ceil(N / groups) and its voxels into nbx x nby x nbz bricks of ceil(X / nbx) x ...
- * voxels; the op clears the tensor and sets word (g, b) = 1 iff some image of group g has a point in brick b -- every voxel of a
- * brick whose word is 0 holds the fill value (tdf: 1/res; shifted: 1 - res/res) in every image of the group.  A consumer that
- * renders such volumes (genre_render_bm_forward) can skip what it knows to be empty. */
+ * tile_live (optional, leader pass only; NULL otherwise): int32 [ceil(N/32), nbx, nby, nbz], contiguous.  The volume's images are
+ * cut into groups of 32 consecutive images (the batch-minor renderer's) and its voxels into nbx x nby x nbz bricks of ceil(X / nbx) x ...
+ * voxels; the op clears the tensor and sets word (g, b) = 1 iff some image of group g has a point in brick b OR in one of b's
+ * <= 7 neighbours on the high side (b + {0,1}^3) -- i.e. in any brick the TILE of b (the brick plus the voxels one step beyond
+ * its high faces: what a trilinear sampler of b's cells reads) can reach.  Every voxel of a tile whose word is 0 holds the fill
+ * value (tdf: 1/res; shifted: 1 - res/res) in every image of the group.  A consumer that renders such volumes
+ * (genre_render_bm_forward) can skip what it knows to be empty. */
 int genre_back_projection_forward_const(const genre_tensor *depth, const genre_tensor *voxel,
-                                        const genre_tensor *cnt, const genre_tensor *brick_live, float camdist, float fl,
+                                        const genre_tensor *cnt, const genre_tensor *tile_live, float camdist, float fl,
                                         int shifted, void *stream);
 
 /* Replaces get_surface_mask (back_projection.c:30-38 -> :840-891, kernel
@@ -336,11 +338,12 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *              the group passes it -- cleared and set by the forward, read by the backward: a group (or a brick) whose
  *              masks are all zero has an identically zero gradient and the backward only writes its zeros
  *   tr_scratch fp32 [groups*nseg*64]: backward only
- * Occupancy hint of the forward (both tensors or both NULL): brick_live int32 [groups, ceil(X/4), ceil(Y/8), ceil(Z/8)] as
- *   genre_back_projection_forward_const writes it -- word 0: every voxel of that brick holds the producer's fill value c in every
- *   image of the group -- and ps_empty fp32 [nseg, 2]: (prod(1-p), sum T p w) of every segment, in ray order, on the CONSTANT
- *   volume vox == c (the forward's own ps_scratch on such a volume, one image's column).  A tile all of whose bricks are dead is
- *   then not read: its segments get the constants.  The caller guarantees that vox still is what the producer wrote.
+ * Occupancy hint of the forward (both tensors or both NULL): tile_live int32 [groups, ceil(X/4), ceil(Y/8), ceil(Z/8)] as
+ *   genre_back_projection_forward_const writes it -- word 0: every voxel of that brick's tile (brick + high halo) holds the
+ *   producer's fill value c in every image of the group -- and ps_empty fp32 [nseg, 4], one row per segment in TABLE order (the
+ *   order of segs): (prod(1-p), sum T p w) of the segment on the CONSTANT volume vox == c -- the forward's own ps_scratch on such a
+ *   volume, one image's column --, the segment's scratch line (= segs[.,0]) as int32 bits, 0.  A dead tile is then not read: its
+ *   segments get the constants.  The caller guarantees that vox still is what the producer wrote.
  * out / grad_out [N,1,R+2p,R+2p] (p = padding margin as above, any strides); pre_scale as above.
  * grad_vox must be batch-minor too (stride[0] == 1); every element is written exactly once. */
 /* the forward's brick the library was built for, as X*100 + Y*10 + Z (488 = 4x8x8 voxels): the tables must be built for it */
@@ -350,7 +353,7 @@ int genre_render_bm_forward(const genre_tensor *vox, const genre_tensor *out, co
                             const genre_tensor *rec_f, const genre_tensor *fwd_rows, const genre_tensor *ray_ptr,
                             const genre_tensor *ray_seg, const genre_tensor *ray_pre,
                             const genre_tensor *ps_scratch, const genre_tensor *p_stash, const genre_tensor *mask,
-                            const genre_tensor *brick_live, const genre_tensor *ps_empty, float pre_scale, void *stream);
+                            const genre_tensor *tile_live, const genre_tensor *ps_empty, float pre_scale, void *stream);
 
 int genre_render_bm_backward(const genre_tensor *grad_out, const genre_tensor *grad_vox, const genre_tensor *segs,
                              const genre_tensor *ray_ptr, const genre_tensor *ray_seg, const genre_tensor *ray_pre,

@@ -23,8 +23,10 @@ def read(db):
     out = collections.defaultdict(dict)
     for name, counters in acc.items():
         for c, vals in counters.items():
-            if any(k in name for k in PHASED) and len(vals) >= 2 and len(vals) % 2 == 0:
-                out[name + "@genre"][c], out[name + "@soft"][c] = vals[:len(vals) // 2], vals[len(vals) // 2:]
+            if any(k in name for k in PHASED) and len(vals) >= 2:
+                half = len(vals) // 2
+                vals = vals[len(vals) - 2 * half:]                       # (odd count: the leading set-up dispatch is dropped)
+                out[name + "@genre"][c], out[name + "@soft"][c] = vals[:half], vals[half:]
             else:
                 out[name][c] = vals
     return out

@@ -41,8 +41,9 @@ def per_kernel(db, counter):
             acc[name].append(value)
     out = {}
     for name, vals in acc.items():
-        if any(k in name for k in PHASED) and len(vals) >= 2 and len(vals) % 2 == 0:
-            half = len(vals) // 2
+        if any(k in name for k in PHASED) and len(vals) >= 2:
+            half = len(vals) // 2                 # (an odd count: the first dispatch is set-up -- the constants of the occupancy
+            vals = vals[len(vals) - 2 * half:]    #  hint are built by rendering a constant volume once -- and is dropped)
             out[name + "@genre"], out[name + "@soft"] = vals[:half], vals[half:]
         else:
             out[name] = vals
