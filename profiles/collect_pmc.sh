@@ -2,6 +2,7 @@
 # One command for the evidence bench.py quotes (run on the MI355X box from the repo root, e.g.
 #   gpurun --timeout 900 -- 'bash profiles/collect_pmc.sh r02a'):
 #   gpurun_out/<tag>/kernel_stats.txt     rocprofv3 --kernel-trace --stats of the default bench run
+#   gpurun_out/<tag>/kernel_stats_phases.txt  the same for profiles/pmc_targets.py, renderer kernels split into @genre / @soft phases
 #   gpurun_out/<tag>/pmc_hbm_traffic.txt  FETCH_SIZE / WRITE_SIZE per kernel, separate passes over profiles/pmc_targets.py
 #   gpurun_out/<tag>/pmc_hbm_traffic.json the same, stamped with the kernel-source hash: copy to profiles/<tag>_pmc_hbm_traffic.json
 #   gpurun_out/<tag>/bench.json           the bench line of the same build
@@ -23,7 +24,7 @@ done
 # kernel trace of pmc_targets.py alone: the renderers run there in two phases, GenRe's own volume (what the timed step renders and
 # `roofline` is quoted on) then the soft volume (`roofline_soft`); min_us / max_us of a kernel's row are the two phases
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_t" -o targets -- python "$ROOT/profiles/pmc_targets.py" "$B" 16 > /dev/null 2> "$OUT/prof_t.err"
-python "$ROOT/profiles/summarize_rocpd.py" $(ls "$OUT"/prof_t/targets_results.db "$OUT"/prof_t/*/targets_results.db 2>/dev/null | head -1) > "$OUT/kernel_stats_soft.txt" 2>&1
+python "$ROOT/profiles/summarize_rocpd.py" --phases $(ls "$OUT"/prof_t/targets_results.db "$OUT"/prof_t/*/targets_results.db 2>/dev/null | head -1) > "$OUT/kernel_stats_phases.txt" 2>&1
 rm -rf "$OUT/prof_t"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_f" -o fetch -- python "$ROOT/profiles/pmc_targets.py" "$B" > /dev/null 2> "$OUT/pmc_f.err"
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_w" -o write -- python "$ROOT/profiles/pmc_targets.py" "$B" > /dev/null 2> "$OUT/pmc_w.err"

@@ -6,9 +6,35 @@ import sqlite3
 import sys
 
 
-def main(path, top=45):
+# the renderers' kernels run in two phases in profiles/pmc_targets.py (GenRe's own volume, then the soft volume): with --phases the
+# first half of a kernel's dispatches (by start time; a leading odd one is set-up and dropped) is reported as "name@genre", the
+# second as "name@soft" -- the rows bench.py's `roofline` (@genre) and `roofline_soft` (@soft) can be recomputed from
+PHASED = ("bm_sample_kernel", "bm_combine_fwd_kernel", "bm_combine_bwd_kernel", "bm_scatter_kernel", "bm_zero_shared_kernel",
+          "render_sample_brick_group_kernel", "render_scan_fwd_kernel", "render_scan_bwd_kernel", "render_bwd_brick_kernel",
+          "zero_shared_bricks_kernel")
+
+
+def phase_rows(cur):
+    per = {}
+    for name, start, end, vg, sg, lds in cur.execute("select name, start, end, vgpr_count, sgpr_count, lds_size from kernels order by start"):
+        per.setdefault(name, []).append(((end - start) / 1e3, vg, sg, lds))
+    rows = []
+    for name, d in per.items():
+        parts = [("", d)]
+        if any(k in name for k in PHASED) and len(d) >= 2:
+            half = len(d) // 2
+            d = d[len(d) - 2 * half:]
+            parts = [("@genre ", d[:half]), ("@soft ", d[half:])]
+        for tag, dd in parts:
+            us = [x[0] for x in dd]
+            rows.append((tag + name, len(us), sum(us), sum(us) / len(us), min(us), max(us), max(x[1] for x in dd),
+                         max(x[2] for x in dd), max(x[3] for x in dd)))
+    return sorted(rows, key=lambda r: -r[2])
+
+
+def main(path, top=45, phases=False):
     cur = sqlite3.connect(path).cursor()
-    rows = cur.execute(
+    rows = phase_rows(cur) if phases else cur.execute(
         "select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, "
         "max(vgpr_count), max(sgpr_count), max(lds_size) from kernels group by name order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows)
@@ -22,4 +48,4 @@ def main(path, top=45):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main([a for a in sys.argv[1:] if a != "--phases"][0], phases="--phases" in sys.argv)
