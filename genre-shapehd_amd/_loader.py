@@ -131,11 +131,12 @@ class _CamBpLib:
         return _call("genre_back_projection_forward", depth, camdist, fl, voxel, cnt)
 
     @staticmethod
-    def back_projection_forward_const(depth, camdist, fl, voxel, cnt, shifted=False, tile_live=None):
+    def back_projection_forward_const(depth, camdist, fl, voxel, cnt, shifted=False, tile_live=None, sparse_cnt=False):
         """extension: camdist / fl are Python floats (one camera for every image), passed by value.  tile_live (int32
-        [groups, nbx, nby, nbz]; leader pass only): receives which bricks of which image group hold anything but the fill value"""
+        [groups, nbx, nby, nbz]; leader pass only): receives which bricks of which image group hold anything but the fill value;
+        sparse_cnt (leader pass only): cnt is written where a point landed and left undefined elsewhere"""
         return _call("genre_back_projection_forward_const", depth, voxel, cnt, tile_live,
-                     scalars=(C.c_float(camdist), C.c_float(fl), C.c_int(1 if shifted else 0)))
+                     scalars=(C.c_float(camdist), C.c_float(fl), C.c_int((1 if shifted else 0) | (2 if sparse_cnt else 0))))
 
     @staticmethod
     def back_projection_backward(depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl):

@@ -115,8 +115,10 @@ class ShiftedCameraBackProjection(Function):
             by_value = const is not None and n * nc <= 65535 and res % 4 == 0 and _cam_mode() in ("", "auto", "brick")
         ctx.hinted = bool(by_value and image_minor and tile_live is not None)
         if by_value:
+            # (image-minor: cnt is kept for THIS Function's backward alone, which reads it at the voxel of every in-grid pixel and
+            # nowhere else -- the leader pass then writes only those elements and half of the fill disappears)
             cam_bp_lib.back_projection_forward_const(depth_t, const[1], const[0], out, cnt, shifted=True,
-                                                     tile_live=tile_live if ctx.hinted else None)
+                                                     tile_live=tile_live if ctx.hinted else None, sparse_cnt=image_minor)
         else:
             cam_bp_lib.back_projection_forward_shifted(depth_t, cam_dist, fl, out, cnt)
         ctx.save_for_backward(depth_t, fl, cam_dist, cnt)

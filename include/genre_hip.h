@@ -102,8 +102,10 @@ int genre_back_projection_backward_shifted(const genre_tensor *depth, const genr
 /* Extension: the camera forward with ONE focal length and ONE camera distance for every image, passed by value --
  * exactly what Camera_back_projection_layer fills its [N,NC] tensors with when it is called with Python floats
  * (camera_backprojection_module.py:16-21).  The kernel then has the camera in its arguments instead of behind two
- * loads (one dependent memory round trip less in front of the brick screen; batch-1 latency).  shifted != 0: output
- * as genre_back_projection_forward_shifted.  Two implementations, picked by the output layout:
+ * loads (one dependent memory round trip less in front of the brick screen; batch-1 latency).  `shifted` is a bit set: bit 0 =
+ * output as genre_back_projection_forward_shifted; bit 1 (leader pass only) = cnt is written ONLY where a point landed and is
+ * undefined elsewhere -- for a caller that, like Camera_back_projection_layer, keeps cnt for genre_back_projection_backward*
+ * alone (which reads it at the voxel of each in-grid pixel and nowhere else): half of the fill is then not written.  Two implementations, picked by the output layout:
  *  - dense NCXYZ outputs (unit z stride, 16-byte aligned rows, Z % 4 == 0): the single-launch brick kernel; results are
  *    identical to the tensor entry points called with constant-filled tensors;
  *  - any other layout (the image-minor volumes of the batch-minor renderer; rows that are not float4-aligned): fill + a LEADER

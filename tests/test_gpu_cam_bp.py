@@ -405,3 +405,19 @@ def test_image_minor_camera_forward_is_deterministic_and_bit_identical_to_the_se
     assert y1.stride(0) == 1 and torch.equal(y1, y2)
     tdf_o, _ = oracle.back_projection_forward(d[:1].cpu().numpy(), np.full((1, 1), 2.2, np.float32), np.full((1, 1), 418.3, np.float32), 128)
     assert np.array_equal(y1[:1].cpu().numpy(), np.float32(1) + np.float32(-128) * tdf_o)
+
+
+def test_image_minor_layer_backward_with_the_sparse_count(genre, dev):
+    """The layer keeps cnt for its own backward only, which reads it at the voxel of every in-grid pixel and nowhere else; on
+    image-minor volumes the leader pass therefore writes cnt only there (half of the fill is not written: csrc/cam_bp.hip,
+    `shifted` bit 1).  Forward values and the gradient of a random upstream gradient equal the standard-layout layer's (whose
+    cnt is dense): the gradient bit for bit -- same pixels, same voxels, same counts."""
+    d = t(inputs.batch_depth(16, seed=5), dev)
+    std, bm = genre.Camera_back_projection_layer().to(dev), genre.Camera_back_projection_layer(batch_minor=True).to(dev)
+    g = torch.randn((16, 1, 128, 128, 128), device=dev)
+    xa, xb = d.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    ya, yb = std(xa), bm(xb)
+    assert yb.stride(0) == 1 and (ya - yb).abs().max().item() <= 128 * TOL
+    ya.backward(g)
+    yb.backward(g)
+    assert xa.grad.abs().max().item() > 0 and torch.equal(xa.grad, xb.grad)
