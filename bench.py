@@ -284,6 +284,15 @@ def kernel_table(G, dev, B):
             t = event_time_us(lambda: cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True), iters, 5)
             rows["cam_bp_fwd_bm"] = dict(us=t, bytes=B * BYTES_CAM_FWD, kernels="fill2_vec4_kernel+cam_leader_kernel<2>",
                                          pmc=["fill2_vec4_kernel", "cam_leader_kernel<2>"], src=("common.hpp", "cam_bp.hip"))
+            # ... and as the LAYER calls it in the step: cnt kept for the layer's own backward only, hence written only where a
+            # point landed (half of the fill is not written), plus the occupancy words for the renderer
+            tl = _fused_render.new_brick_words(B, 128, dev)
+            t = event_time_us(lambda: cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True,
+                                                                                tile_live=tl, sparse_cnt=True), iters, 5)
+            rows["cam_bp_fwd_bm_layer"] = dict(us=t, bytes=B * (256 * 256 * 4 + 128 ** 3 * 4),
+                                               kernels="fill1_vec4_kernel+cam_leader_kernel<2> (cnt only where a point landed; "
+                                                       "occupancy words)",
+                                               pmc=["fill1_vec4_kernel", "cam_leader_kernel<2>"], src=("common.hpp", "cam_bp.hip"))
             t = event_time_us(lambda: cam_bp_lib.back_projection_forward_shifted(d, cd, fl, proj_bm, cnt_bm), iters, 5)
             rows["cam_bp_fwd_bm_atomics"] = dict(us=t, bytes=B * BYTES_CAM_FWD,
                                                  kernels="fill2_vec4_kernel+scatter_tile_kernel<false>+normalise_tile_kernel<false>")
@@ -936,7 +945,7 @@ def main():
         if not fused:
             in_step = ["cam_bp_fwd", "calc_prob_fwd", "calc_prob_bwd_fused"]
         elif bm:
-            in_step = ["cam_bp_fwd_bm", "render_fwd_bm", "render_bwd_bm"]
+            in_step = ["cam_bp_fwd_bm_layer", "render_fwd_bm", "render_bwd_bm"]
         else:
             in_step = ["cam_bp_fwd", "render_fwd_fused", "render_bwd_fused"]
         # `roofline` = the slowest hand-written kernel group OF THE TIMED hot-path step, on the volume the step renders (round 5;

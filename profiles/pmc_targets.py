@@ -72,6 +72,8 @@ for _ in range(ITERS):
     calc_prob_lib.calc_prob_backward_fused(p, s, g, o)
     if TB is not None:
         cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True)   # image-minor volumes: fill + leader pass
+        cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True,   # ... as the layer calls it in the step
+                                                 tile_live=_fused_render.new_brick_words(B, 128, dev), sparse_cnt=True)
 for vol_std, vol_bm in ((proj_std, proj_bm), (soft_std, soft_bm)):
     for _ in range(ITERS):
         lib.render_spherical_forward(vol_std, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"],
