@@ -778,7 +778,7 @@ struct BrickFlags { int *p; int per_group, nbx, nby, nbz, bx, by, bz; };   // in
 template <int HALO>
 __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth, View5 vox, View5 cnt, float cam_dist, float f,
                                                             float prefill, float bias, float post_scale, float post_bias,
-                                                            BrickFlags flags)
+                                                            BrickFlags flags, float d_screen)
 {
     constexpr int TW = 8 + 2 * HALO, TN = TW * TW, kWaves = kBlock / 64;
     __shared__ int s_key[kWaves][TN];
@@ -812,9 +812,13 @@ __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth,
 #pragma unroll
         for (int r = 0; r < kRounds; r++) {
             const int e = lane + r * 64;
-            int ix, iy, iz;
-            float dist;
-            const int key = pixel_voxel<false>(D, e < TN, d_raw[r], 0.f, 0.f, 0.f, f, cam_dist, hh[r], ww[r], ix, iy, iz, dist);
+            int ix, iy, iz, key = -1;
+            float dist = 0.f;
+            // depth screen: a point lands in the grid only if its depth along the optical axis, d_raw cos(theta) <= d_raw, reaches
+            // the grid's near plane cam_dist - 1/2 (d_screen, a hair below it): background pixels (depth 0) and everything in
+            // front of the cube skip the arithmetic -- two thirds of a GenRe depth map, whole rounds of a wave at a time
+            if (d_raw[r] >= d_screen)
+                key = pixel_voxel<false>(D, e < TN, d_raw[r], 0.f, 0.f, 0.f, f, cam_dist, hh[r], ww[r], ix, iy, iz, dist);
             if (e < TN) { key_w[e] = key; dist_w[e] = dist; }
             any |= key >= 0;
         }
@@ -1258,7 +1262,7 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         }
 #define GENRE_CAM_LEADER(HV)                                                                                              \
         cam_leader_kernel<HV><<<g, kBlock, 0, st>>>(D, view4(depth), view5(voxel), view5(cnt), byval[1], byval[0], prefill, bias, \
-                                                    post_scale, post_bias, flags)
+                                                    post_scale, post_bias, flags, (byval[1] - 0.5f) * (1.0f - 1e-5f))
         switch (halo < 1 ? 1 : halo) {
             case 1: GENRE_CAM_LEADER(1); break;
             case 2: GENRE_CAM_LEADER(2); break;
