@@ -289,6 +289,7 @@ def kernel_table(G, dev, B):
             tl = _fused_render.new_brick_words(B, 128, dev)
             t = event_time_us(lambda: cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True,
                                                                                 tile_live=tl, sparse_cnt=True), iters, 5)
+            cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True)     # (cnt dense again)
             rows["cam_bp_fwd_bm_layer"] = dict(us=t, bytes=B * (256 * 256 * 4 + 128 ** 3 * 4),
                                                kernels="fill1_vec4_kernel+cam_leader_kernel<2> (cnt only where a point landed; "
                                                        "occupancy words)",
@@ -310,8 +311,8 @@ def kernel_table(G, dev, B):
             # the volume as the step's layer hands it over: with the leader pass's occupancy words (which bricks of the group hold
             # anything but the fill value); the sampler copies constants for tiles it knows to be empty instead of reading them
             words, ps_empty = _fused_render.occupancy_hint(proj_bm, TB, 50.0, render_lib)
-            assert words is not None, "the layer's image-minor volume carries no occupancy words"
-            tiles_live = (words != 0).float().mean().item()             # share of the tiles (brick + high halo) that are read
+            # (None when GENRE_CAMBP_MODE pins another camera forward: every tile is read then)
+            tiles_live = (words != 0).float().mean().item() if words is not None else 1.0   # share of the tiles that are read
 
             def bm_fwd(save, hint=True):
                 render_lib.render_bm_forward(proj_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"],
