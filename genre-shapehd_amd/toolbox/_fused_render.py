@@ -272,6 +272,8 @@ def occupancy_hint(vox, t, pre_scale, lib):
         pe = torch.zeros((line.shape[0], 4), dtype=torch.int32, device=vox.device)
         pe.view(torch.float32)[:, :2] = ps.view(-1, 2, _GROUP)[:, :, 0][line]
         pe[:, 2] = t["segs"][:, 0]
+        for old_key in [k for k in t if isinstance(k, tuple) and k[:1] == ("ps_empty",)][3:]:
+            del t[old_key]                                                 # (a handful of (fill, pre_scale) pairs per geometry at most)
         t[key] = pe.view(torch.float32)                                    # [nseg, 4] = (P, S, line bits, 0), table order
     return words, t[key]
 
