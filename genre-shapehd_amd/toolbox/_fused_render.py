@@ -262,6 +262,9 @@ def occupancy_hint(vox, t, pre_scale, lib):
     if key not in t:
         if torch.cuda.is_current_stream_capturing():
             return None, None               # (built outside graph capture only: callers warm up before they capture)
+        if sum(1 for k in t if isinstance(k, tuple) and k[:1] == ("ps_empty",)) >= 4:
+            return None, None               # a handful of (fill, pre_scale) pairs per geometry; never evicted: captured HIP
+                                            # graphs hold raw pointers into these tables
         const = empty_batch_minor((_GROUP, 1, X, Y, Z), torch.float32, vox.device).fill_(fill)
         res_map = int(round((t["ray_ptr"].shape[0] - 1) ** 0.5))
         out = torch.empty((_GROUP, 1, res_map, res_map), dtype=torch.float32, device=vox.device)
@@ -272,8 +275,6 @@ def occupancy_hint(vox, t, pre_scale, lib):
         pe = torch.zeros((line.shape[0], 4), dtype=torch.int32, device=vox.device)
         pe.view(torch.float32)[:, :2] = ps.view(-1, 2, _GROUP)[:, :, 0][line]
         pe[:, 2] = t["segs"][:, 0]
-        for old_key in [k for k in t if isinstance(k, tuple) and k[:1] == ("ps_empty",)][3:]:
-            del t[old_key]                                                 # (a handful of (fill, pre_scale) pairs per geometry at most)
         t[key] = pe.view(torch.float32)                                    # [nseg, 4] = (P, S, line bits, 0), table order
     return words, t[key]
 
