@@ -105,6 +105,31 @@ def test_validation_errors_do_not_launch(genre):
     args = [C.byref(a) for a in (gout, gvox, segs, rptr, rseg, rpre, ent, rec, rows, dwt, ps, tr, stash)]
     rc = lib.genre_render_bm_backward(*args, C.byref(desc((8 * 8 * 8,), 1)), 50.0, 488, None)      # masks without the group word
     assert rc == 0 and b"+ groups" in lib.genre_last_error()
+    # ABI 4: the standard-layout renderer's pass words, the occupancy words between the camera forward and the batch-minor
+    # forward -- wrong sizes / half-given pairs / the wrong producer are refused before anything is launched or cleared
+    tab, chunks, kin = desc((1, 4), 1), desc((64,), 1), desc((64,), 1)
+    v16 = desc((1, 1, 16, 16, 16))
+    rc = lib.genre_render_spherical_forward(C.byref(v16), C.byref(dirs), C.byref(dw), C.byref(desc((1, 1, 8, 8))),
+                                            C.byref(desc((8 * 8 * 16,))), C.byref(tab), C.byref(chunks), C.byref(kin),
+                                            C.byref(desc((1,), 1)), 50.0, None)         # live: needs 1 * (1 + 1 brick) words
+    assert rc == 0 and b"live" in lib.genre_last_error()
+    lib.genre_render_bm_forward.argtypes = [C.c_void_p] * 13 + [C.c_float, C.c_void_p]
+    fargs = [C.byref(a) for a in (gvox, gout, segs, rec, rows, rptr, rseg, rpre, ps)]
+    rc = lib.genre_render_bm_forward(*fargs, None, None, C.byref(desc((1, 2, 1, 1), 1)), None, 0.0, None)   # words without constants
+    assert rc == 0 and b"tile_live" in lib.genre_last_error()
+    rc = lib.genre_render_bm_forward(*fargs, None, None, C.byref(desc((1, 2, 1, 1), 1)), C.byref(desc((nseg, 2))), 0.0, None)
+    assert rc == 0 and b"ps_empty" in lib.genre_last_error()
+    rc = lib.genre_render_bm_forward(*fargs, None, None, C.byref(desc((2, 2, 1, 1), 1)), C.byref(desc((nseg, 4))), 0.0, None)
+    assert rc == 0 and b"tile_live" in lib.genre_last_error()                            # one slab per image group
+    lib.genre_back_projection_forward_const.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int, C.c_void_p]
+    rc = lib.genre_back_projection_forward_const(C.byref(depth), C.byref(vox), C.byref(vox), C.byref(desc((1, 1, 1, 1), 1)),
+                                                 2.2, 418.3, 1, None)                    # dense rows: the brick kernel writes no words
+    assert rc == 0 and b"tile_live" in lib.genre_last_error()
+    rc = lib.genre_back_projection_forward_const(C.byref(depth), C.byref(vox), C.byref(vox), None, 2.2, 418.3, 3, None)
+    assert rc == 0 and b"sparse cnt" in lib.genre_last_error()                           # ... and no sparse cnt either
+    bmv = bm_vol(2, 4, 4, 4)
+    rc = lib.genre_back_projection_forward_const(C.byref(desc((2, 1, 8, 8))), C.byref(bmv), C.byref(bmv), None, 0.6, 418.3, 1, None)
+    assert rc == 0 and b"by-value" in lib.genre_last_error()                             # image-minor, but voxels project too wide
     # empty problems succeed without launching anything
     e = desc((0, 1, 8, 8))
     ev = desc((0, 1, 4, 4, 4))
