@@ -557,9 +557,26 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
         // its zeros and is done -- no entries, no scans, no atomics.  On GenRe's own chain (x50 of a saturated or empty
         // voxel) that is every brick; the group word behind the masks says so without reading them.
         static_assert(kMaskThreads <= kThreadsB, "one mask word per thread");
+        auto write_zeros = [&]() {                                       // this brick's voxels of all 32 images <- 0 (plain stores)
+            const bool v4 = (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
+                            (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
+            for (int q = threadIdx.x; q < PX * PY * PZ * (kImgs / 4); q += kThreadsB) {
+                const int line = q >> 3, n = n0 + (q & 7) * 4;
+                const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
+                if (x >= D.X || y >= D.Y || z >= D.Z) continue;
+                float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
+                if (v4 && n + 3 < D.N) *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+                else
+                    for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] = 0.f;
+            }
+        };
         const bool group_live = mask[(size_t)D.groups * D.X * D.Y * D.Z + g] != 0u;
+        if (!group_live) {          // nothing of this group passes the clamp: the zeros at once -- no tile to clear, no masks, no barrier
+            if (row.w == 0) write_zeros();                              // (a shared brick: bm_zero_shared_kernel wrote its zeros)
+            return;
+        }
         unsigned m = 0u;
-        if (group_live && (int)threadIdx.x < kLinesB) {
+        if ((int)threadIdx.x < kLinesB) {
             const int line = threadIdx.x;
             const int x = ox + line / (QY * QZ), y = oy + (line / QZ) % QY, z = oz + line % QZ;
             if (x < D.X && y < D.Y && z < D.Z) m = mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z];
@@ -578,18 +595,7 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
             brick_live |= w.x | w.y | w.z | w.w;
         }
         if (!brick_live) {
-            if (row.w != 0) return;                                     // a shared brick: bm_zero_shared_kernel wrote its zeros
-            const bool v4 = (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
-                            (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
-            for (int q = threadIdx.x; q < PX * PY * PZ * (kImgs / 4); q += kThreadsB) {
-                const int line = q >> 3, n = n0 + (q & 7) * 4;
-                const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
-                if (x >= D.X || y >= D.Y || z >= D.Z) continue;
-                float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
-                if (v4 && n + 3 < D.N) *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
-                else
-                    for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] = 0.f;
-            }
+            if (row.w == 0) write_zeros();                              // (a shared brick: bm_zero_shared_kernel wrote its zeros)
             return;
         }
     } else {
