@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgenre_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 _MAX_DIMS = 5
 _F32, _I32 = 0, 1
 
@@ -39,6 +39,7 @@ def _load():
         raise ImportError("libgenre_hip.so ABI %d != expected %d -- rebuild" % (lib.genre_abi_version(), ABI_VERSION))
     T, V = C.POINTER(GenreTensor), C.c_void_p
     scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float],
+               "genre_render_seg_forward": [C.c_float, C.c_int],
                "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float, C.c_int],
                "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float],
                "genre_back_projection_forward_const": [C.c_float, C.c_float, C.c_int]}
@@ -50,7 +51,8 @@ def _load():
                         ("genre_spherical_back_proj_backward_shifted", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
-                        ("genre_render_spherical_forward", 9), ("genre_render_spherical_backward", 11),
+                        ("genre_render_spherical_forward", 9), ("genre_render_spherical_backward", 13),
+                        ("genre_render_seg_forward", 12),
                         ("genre_render_bm_forward", 13), ("genre_render_bm_backward", 14),
                         ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4),
                         ("genre_nnd_forward_host", 6), ("genre_nnd_backward_host", 8)):
@@ -59,6 +61,9 @@ def _load():
             raise ImportError("libgenre_hip.so does not export %s -- rebuild (make -C genre-shapehd_amd/csrc)" % name)
         fn.argtypes = [T] * nargs + scalars.get(name, []) + ([] if name.endswith("_host") else [V])
         fn.restype = C.c_int
+    lib.genre_cam_forward_plan.argtypes = [T, T, C.c_float, C.c_float]
+    lib.genre_cam_forward_plan.restype = C.c_int
+    lib.genre_cam_cell.restype = C.c_int
     return lib
 
 
@@ -91,10 +96,20 @@ def _desc(t, what, host=False):
     return d
 
 
-def _call(name, *tensors, scalars=()):
+_HINTS = ("_genre_brick_hint", "_genre_cell_hint")       # occupancy words a producer hung on its volume (toolbox/_fused_render.py)
+
+
+def _call(name, *tensors, scalars=(), out=()):
     """Enqueue `name` on torch's current stream of the tensors' device; raise on failure
-    (the reference raised via THError("aborting"), back_projection.c:13-15)."""
+    (the reference raised via THError("aborting"), back_projection.c:13-15).  `out`: positions of the tensors the op WRITES --
+    a raw write through the C ABI does not bump the version counter an occupancy hint is guarded by, so a hinted volume that is
+    re-used as an output (the reference's caller-allocates convention, cam_back_projection.py:22-25) loses its hint here."""
     dev = tensors[0].device
+    for i in out:
+        d = getattr(tensors[i], "__dict__", None)
+        if d:
+            for a in _HINTS:
+                d.pop(a, None)
     descs = []
     for k, t in enumerate(tensors):
         if t is None:                       # optional argument -> NULL
@@ -128,7 +143,7 @@ class _CamBpLib:
 
     @staticmethod
     def back_projection_forward(depth, camdist, fl, voxel, cnt):
-        return _call("genre_back_projection_forward", depth, camdist, fl, voxel, cnt)
+        return _call("genre_back_projection_forward", depth, camdist, fl, voxel, cnt, out=(3, 4))
 
     @staticmethod
     def back_projection_forward_const(depth, camdist, fl, voxel, cnt, shifted=False, tile_live=None, sparse_cnt=False):
@@ -136,44 +151,59 @@ class _CamBpLib:
         [groups, nbx, nby, nbz]; leader pass only): receives which bricks of which image group hold anything but the fill value;
         sparse_cnt (leader pass only): cnt is written where a point landed and left undefined elsewhere"""
         return _call("genre_back_projection_forward_const", depth, voxel, cnt, tile_live,
-                     scalars=(C.c_float(camdist), C.c_float(fl), C.c_int((1 if shifted else 0) | (2 if sparse_cnt else 0))))
+                     scalars=(C.c_float(camdist), C.c_float(fl), C.c_int((1 if shifted else 0) | (2 if sparse_cnt else 0))), out=(1, 2, 3))
+
+    PLAN_NONE, PLAN_BRICK, PLAN_LEADER = 0, 1, 2
+
+    @staticmethod
+    def forward_plan(voxel, cnt, camdist, fl):
+        """which implementation back_projection_forward_const takes for these outputs and this camera (the library's own
+        decision -- nothing is mirrored in Python): PLAN_BRICK (dense NCXYZ; occupancy words per image and cam_cell()),
+        PLAN_LEADER (other layouts; words per group of 32 images and renderer brick) or PLAN_NONE (pass tensors instead)"""
+        return _lib.genre_cam_forward_plan(C.byref(_desc(voxel, "forward_plan voxel")), C.byref(_desc(cnt, "forward_plan cnt")),
+                                           C.c_float(camdist), C.c_float(fl))
+
+    @staticmethod
+    def cam_cell():
+        code = _lib.genre_cam_cell()
+        return code // 10000, (code // 100) % 100, code % 100
 
     @staticmethod
     def back_projection_backward(depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl):
         return _call("genre_back_projection_backward", depth, fl, camdist, cnt, grad_in, grad_depth,
-                     grad_camdist, grad_fl)
+                     grad_camdist, grad_fl, out=(5, 6, 7))
 
     @staticmethod
     def back_projection_forward_shifted(depth, camdist, fl, voxel, cnt):
         """extension: writes 1 - res*tdf (Camera_back_projection_layer.shift_tdf folded in)"""
-        return _call("genre_back_projection_forward_shifted", depth, camdist, fl, voxel, cnt)
+        return _call("genre_back_projection_forward_shifted", depth, camdist, fl, voxel, cnt, out=(3, 4))
 
     @staticmethod
     def back_projection_backward_shifted(depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl):
         return _call("genre_back_projection_backward_shifted", depth, fl, camdist, cnt, grad_in, grad_depth,
-                     grad_camdist, grad_fl)
+                     grad_camdist, grad_fl, out=(5, 6, 7))
 
     @staticmethod
     def get_surface_mask(depth, camdist, fl, cnt, mask):
-        return _call("genre_get_surface_mask", depth, camdist, fl, cnt, mask)
+        return _call("genre_get_surface_mask", depth, camdist, fl, cnt, mask, out=(4,))
 
     @staticmethod
     def spherical_back_proj_forward(depth, grid_in, voxel, cnt):
-        return _call("genre_spherical_back_proj_forward", depth, grid_in, voxel, cnt)
+        return _call("genre_spherical_back_proj_forward", depth, grid_in, voxel, cnt, out=(2, 3))
 
     @staticmethod
     def spherical_back_proj_backward(depth, grid_in, cnt, grad_in, grad_depth):
-        return _call("genre_spherical_back_proj_backward", depth, grid_in, cnt, grad_in, grad_depth)
+        return _call("genre_spherical_back_proj_backward", depth, grid_in, cnt, grad_in, grad_depth, out=(4,))
 
 
     @staticmethod
     def spherical_back_proj_forward_shifted(depth, grid_in, voxel, cnt):
         """extension: writes (-tdf + 1/res) * res * clamp(cnt,0,1) (genre_full_model.py:139-142 folded in)"""
-        return _call("genre_spherical_back_proj_forward_shifted", depth, grid_in, voxel, cnt)
+        return _call("genre_spherical_back_proj_forward_shifted", depth, grid_in, voxel, cnt, out=(2, 3))
 
     @staticmethod
     def spherical_back_proj_backward_shifted(depth, grid_in, cnt, grad_in, grad_depth):
-        return _call("genre_spherical_back_proj_backward_shifted", depth, grid_in, cnt, grad_in, grad_depth)
+        return _call("genre_spherical_back_proj_backward_shifted", depth, grid_in, cnt, grad_in, grad_depth, out=(4,))
 
 
 class _CalcProbLib:
@@ -181,16 +211,16 @@ class _CalcProbLib:
 
     @staticmethod
     def calc_prob_forward(prob_in, prob_out):
-        return _call("genre_calc_prob_forward", prob_in, prob_out)
+        return _call("genre_calc_prob_forward", prob_in, prob_out, out=(1,))
 
     @staticmethod
     def calc_prob_backward(prob_in, stop_prob_weighted, grad_out):
-        return _call("genre_calc_prob_backward", prob_in, stop_prob_weighted, grad_out)
+        return _call("genre_calc_prob_backward", prob_in, stop_prob_weighted, grad_out, out=(2,))
 
     @staticmethod
     def calc_prob_backward_fused(prob_in, stop_prob, grad_in, grad_out):
         """extension: forms stop_prob*grad_in in-kernel (calc_prob.py:27 folded in)"""
-        return _call("genre_calc_prob_backward_fused", prob_in, stop_prob, grad_in, grad_out)
+        return _call("genre_calc_prob_backward_fused", prob_in, stop_prob, grad_in, grad_out, out=(3,))
 
 
 class _RenderLib:
@@ -203,17 +233,28 @@ class _RenderLib:
         sample values); without: one wave-per-ray gather kernel.  live (int32 [N*NC*(1 + bricks)], with pre_scale): receives
         the clamp's pass words per image and per 16^3 brick for the backward"""
         return _call("genre_render_spherical_forward", vox, dirs64_as_f32, depth_weight, out,
-                     v_scratch, fwd_table, fwd_chunks, kin, live, scalars=(C.c_float(pre_scale),))
+                     v_scratch, fwd_table, fwd_chunks, kin, live, scalars=(C.c_float(pre_scale),), out=(3, 4, 8))
 
     @staticmethod
     def render_spherical_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
                                   dp_scratch=None, brick_table=None, chunk_list=None, v_scratch=None, kin=None,
-                                  pre_scale=0.0, live=None):
+                                  pre_scale=0.0, live=None, fwd_table=None, fwd_chunks=None):
         """dp_scratch/brick_table/chunk_list given: brick-owned backward (no global atomics), re-using the
         forward's v_scratch when it is passed too; without: global-atomic scatter fallback.  live: the forward's pass words --
-        what the pre_scale clamp blocks is written as zeros without being computed"""
+        what the pre_scale clamp blocks is written as zeros without being computed.  fwd_table + fwd_chunks: v_scratch is
+        scratch space, the raw sample values are recomputed from vox first (the segment forward saves nothing)"""
         return _call("genre_render_spherical_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                     dp_scratch, brick_table, chunk_list, v_scratch, kin, live, scalars=(C.c_float(pre_scale),))
+                     dp_scratch, brick_table, chunk_list, v_scratch, kin, live, fwd_table, fwd_chunks,
+                     scalars=(C.c_float(pre_scale),), out=(4, 5, 8))
+
+    @staticmethod
+    def render_seg_forward(vox, dirs64_as_f32, depth_weight, out, seg_rows, segs, ray_nseg, ray_pre_as_f32, ps_scratch,
+                           pre_scale=0.0, live=None, occ=None, ps_empty=None, occ_cell=0):
+        """segment renderer, standard layout (csrc/sph_render_seg.hip; tables: toolbox/_seg_tables.py): one (P, S) pair per
+        segment instead of one value per sample.  occ + ps_empty + occ_cell: the producer's occupancy words -- tiles known to
+        hold only the fill value are not read"""
+        return _call("genre_render_seg_forward", vox, dirs64_as_f32, depth_weight, out, seg_rows, segs, ray_nseg,
+                     ray_pre_as_f32, ps_scratch, live, occ, ps_empty, scalars=(C.c_float(pre_scale), C.c_int(occ_cell)), out=(3, 8, 9))
 
 
     @staticmethod
@@ -223,14 +264,14 @@ class _RenderLib:
         pre_scale != 0) given: the state the backward needs is saved.  tile_live + ps_empty: the producer's occupancy words and
         the geometry's constants -- tiles known to hold only the fill value are not read"""
         return _call("genre_render_bm_forward", vox, out, segs, rec_f, fwd_rows, ray_ptr, ray_seg, ray_pre_as_f32,
-                     ps_scratch, p_stash, mask, tile_live, ps_empty, scalars=(C.c_float(pre_scale),))
+                     ps_scratch, p_stash, mask, tile_live, ps_empty, scalars=(C.c_float(pre_scale),), out=(1, 8, 9, 10))
 
     @staticmethod
     def render_bm_backward(grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, ent, rec_b, bwd_rows,
                            depth_weight, ps_scratch, tr_scratch, p_stash, mask=None, pre_scale=0.0, pull_brick=488):
         return _call("genre_render_bm_backward", grad_out, grad_vox, segs, ray_ptr, ray_seg, ray_pre_as_f32, ent,
                      rec_b, bwd_rows, depth_weight, ps_scratch, tr_scratch, p_stash, mask,
-                     scalars=(C.c_float(pre_scale), C.c_int(pull_brick)))
+                     scalars=(C.c_float(pre_scale), C.c_int(pull_brick)), out=(1, 11))
 
 
 
@@ -240,12 +281,12 @@ class _GlueLib:
     @staticmethod
     def abs_depth_forward(pred_depth, depth_minmax, silhou, out, scale_25d=100.0):
         """depth_pred_with_sph_inpaint.py:131-142 (get_abs_depth) in one pass"""
-        return _call("genre_abs_depth_forward", pred_depth, depth_minmax, silhou, out, scalars=(C.c_float(scale_25d),))
+        return _call("genre_abs_depth_forward", pred_depth, depth_minmax, silhou, out, scalars=(C.c_float(scale_25d),), out=(3,))
 
     @staticmethod
     def abs_depth_backward(grad_out, depth_minmax, silhou, grad_pred, scale_25d=100.0):
         return _call("genre_abs_depth_backward", grad_out, depth_minmax, silhou, grad_pred,
-                     scalars=(C.c_float(scale_25d),))
+                     scalars=(C.c_float(scale_25d),), out=(3,))
 
 
 class _MyLib:
@@ -254,11 +295,11 @@ class _MyLib:
 
     @staticmethod
     def nnd_forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2):
-        return _call("genre_nnd_forward", xyz1, xyz2, dist1, dist2, idx1, idx2)
+        return _call("genre_nnd_forward", xyz1, xyz2, dist1, dist2, idx1, idx2, out=(2, 3, 4, 5))
 
     @staticmethod
     def nnd_backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
-        return _call("genre_nnd_backward", xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
+        return _call("genre_nnd_backward", xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2, out=(2, 3))
 
     @staticmethod
     def nnd_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):

@@ -622,7 +622,7 @@ template <bool BYVAL, bool PIXELSCREEN = false>
 __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, View2 camdist, View2 fl, View5 vox,
                                                             View5 cnt, float prefill, float bias, float post_scale,
                                                             float post_bias, float fill_val, int vec_ok, float fl_val,
-                                                            float cd_val)
+                                                            float cd_val, int *__restrict__ cell_live)
 {
     __shared__ double s_sum[kQVox];
     __shared__ unsigned s_cnt[kQVox];
@@ -726,6 +726,10 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
         __syncthreads();
         if (PIXELSCREEN) live = s_hit != 0;
     }
+    // occupancy for the consumer (the segment renderer, csrc/sph_render_seg.hip, does not read tiles none of whose cells
+    // received a point): one word per image and cell = this workgroup's brick, written by its owner -- no clearing pass, no
+    // atomics.  0 => every voxel of the cell holds fill_val.
+    if (cell_live != nullptr && threadIdx.x == 0) cell_live[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = live ? 1 : 0;
     // ---- (c) normalise (:291-305) and write the brick; a dead brick streams the fill values ---------------------
     auto value = [&](int l, float &k) {
         k = (float)s_cnt[l];
@@ -1165,6 +1169,25 @@ inline CamMode cam_mode()
     return m;
 }
 
+// float4 rows (brick kernel; dead bricks of the gather kernel) need unit z stride and 16-byte aligned z-rows
+inline bool rows_aligned(const Dims &D, const genre_tensor *t)
+{
+    if (t->stride[4] != 1 || !aligned16(t->data) || (D.Z % 4) != 0) return false;
+    for (int i = 0; i < 4; i++)
+        if (t->size[i] != 1 && (t->stride[i] % 4) != 0) return false;
+    return true;
+}
+
+// which implementation genre_back_projection_forward_const takes for these outputs and this camera (genre_cam_forward_plan)
+enum { kPlanNone = 0, kPlanBrick = 1, kPlanLeader = 2 };
+inline int byval_plan(const Dims &D, const genre_tensor *voxel, const genre_tensor *cnt, float f, float cam_dist)
+{
+    const CamMode m = cam_mode();
+    if (rows_aligned(D, voxel) && rows_aligned(D, cnt) && D.N * D.NC <= 65535 && (m == kBrick || m == kAuto)) return kPlanBrick;
+    const int halo = leader_halo(D, f, cam_dist);
+    return (m != kGather && m != kBrick && halo >= 0 && halo <= 4) ? kPlanLeader : kPlanNone;
+}
+
 template <bool SPH>
 int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *camdist, const genre_tensor *fl,
                  const genre_tensor *grid, const genre_tensor *voxel, const genre_tensor *cnt, void *stream,
@@ -1205,17 +1228,10 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
             fill_val = 1.0f - (float)mx * empty_val;
         }
     }
-    // float4 rows (brick kernel; dead bricks of the gather kernel) need unit z stride and 16-byte aligned z-rows in both outputs
-    auto rows_aligned = [&](const genre_tensor *t) {
-        if (t->stride[4] != 1 || !aligned16(t->data) || (D.Z % 4) != 0) return false;
-        for (int i = 0; i < 4; i++)
-            if (t->size[i] != 1 && (t->stride[i] % 4) != 0) return false;
-        return true;
-    };
-    const int vec_ok = rows_aligned(voxel) && rows_aligned(cnt);
+    const int vec_ok = rows_aligned(D, voxel) && rows_aligned(D, cnt);
     CamMode mode = SPH ? kScatter : cam_mode();
     if (mode == kAuto) mode = (vec_ok && D.N * D.NC <= 65535) ? kBrick : kScatter;
-    if (byval && !(vec_ok && D.N * D.NC <= 65535 && (mode == kBrick || cam_mode() == kAuto))) {
+    if (byval && (SPH || byval_plan(D, voxel, cnt, byval[0], byval[1]) != kPlanBrick)) {
         // by value, but no contiguous z rows (image-minor / strided volumes): fill + the deterministic leader pass
         const int halo = SPH ? -1 : leader_halo(D, byval[0], byval[1]);
         GENRE_REQUIRE(!SPH && cam_mode() != kGather && cam_mode() != kBrick && halo >= 0 && halo <= 4,
@@ -1273,11 +1289,20 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         GENRE_LAUNCH_CHECK("projection forward (leader pass)");
         return 1;
     }
-    GENRE_REQUIRE(!sparse_cnt, "%s: a sparse cnt is produced by the leader pass only (by-value camera, volumes without contiguous "
-                               "z rows)", op);
-    GENRE_REQUIRE(tile_live == nullptr, "%s: tile_live is produced by the leader pass only (by-value camera, volumes without "
-                                         "contiguous z rows)", op);
+    // (sparse_cnt is a permission, not a request: the brick kernel writes cnt densely)
     if (byval) mode = kBrick;
+    int *cell_live = nullptr;
+    if (tile_live != nullptr) {
+        // dense outputs: the words are per image and per cell of the brick kernel (genre_cam_cell()), each written by its owner
+        const int ncx = (D.X + kQX - 1) / kQX, ncy = (D.Y + kQY - 1) / kQY, ncz = (D.Z + kQZ - 1) / kQZ;
+        GENRE_REQUIRE(mode == kBrick, "%s: tile_live is produced by the brick kernel (dense outputs) or the leader pass (by-value "
+                                      "camera, other layouts) only", op);
+        GENRE_REQUIRE(is_i32(tile_live, 4) && is_contiguous(tile_live) && tile_live->size[0] == (int64_t)D.N * D.NC &&
+                          tile_live->size[1] == ncx && tile_live->size[2] == ncy && tile_live->size[3] == ncz,
+                      "%s: for dense outputs tile_live must be a contiguous int32 [N*NC, %d, %d, %d] tensor (one word per image "
+                      "and %dx%dx%d-voxel cell)", op, ncx, ncy, ncz, kQX, kQY, kQZ);
+        cell_live = (int *)tile_live->data;
+    }
     if (mode != kScatter) {
         const int64_t nvox = (int64_t)D.X * D.Y * D.Z;
         if (nvox == 0 || D.N * D.NC == 0) return 1;
@@ -1291,7 +1316,7 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
             const bool pixelscreen = D.N * D.NC <= GENRE_CAMQ_PIXELSCREEN_MAXN;
 #define GENRE_CAMQ_LAUNCH(BV, PXS, A, B_)                                                                                 \
             cam_brick_kernel<BV, PXS><<<bgrid, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias, \
-                                                                post_scale, post_bias, fill_val, vec_ok, A, B_)
+                                                                post_scale, post_bias, fill_val, vec_ok, A, B_, cell_live)
             if (byval) { if (pixelscreen) GENRE_CAMQ_LAUNCH(true, true, byval[0], byval[1]); else GENRE_CAMQ_LAUNCH(true, false, byval[0], byval[1]); }
             else { if (pixelscreen) GENRE_CAMQ_LAUNCH(false, true, 0.0f, 0.0f); else GENRE_CAMQ_LAUNCH(false, false, 0.0f, 0.0f); }
 #undef GENRE_CAMQ_LAUNCH
@@ -1404,6 +1429,18 @@ extern "C" int genre_back_projection_forward_const(const genre_tensor *depth, co
     const float byval[2] = {fl, camdist};
     return forward_impl<false>("back_projection_forward_const", depth, nullptr, nullptr, nullptr, voxel, cnt, stream,
                                (shifted & 1) != 0, byval, tile_live, (shifted & 2) != 0);
+}
+
+extern "C" int genre_cam_cell(void) { return kQX * 10000 + kQY * 100 + kQZ; }
+
+extern "C" int genre_cam_forward_plan(const genre_tensor *voxel, const genre_tensor *cnt, float camdist, float fl)
+{
+    const char *op = "cam_forward_plan";
+    Dims D{};
+    GENRE_REQUIRE(is_f32(voxel, 5) && is_f32(cnt, 5) && same_shape(voxel, cnt), "%s: voxel and cnt must be 5-D fp32 tensors of one shape", op);
+    D.N = (int)voxel->size[0]; D.NC = (int)voxel->size[1];
+    D.X = (int)voxel->size[2]; D.Y = (int)voxel->size[3]; D.Z = (int)voxel->size[4];
+    return byval_plan(D, voxel, cnt, fl, camdist);
 }
 
 extern "C" int genre_back_projection_backward_shifted(const genre_tensor *depth, const genre_tensor *fl,

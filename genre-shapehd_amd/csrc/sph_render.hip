@@ -36,7 +36,7 @@
 // FALLBACKS without the tables: render_fwd_kernel / render_bwd_dp_kernel (a wave renders one ray with gathers from
 //   global memory) and render_bwd_atomic_kernel (8 global fp32 atomics per sample: 1.3 ms/image, 95 % of it atomic
 //   throughput -- all 16 384 rays converge on the central voxels).
-#include "common.hpp"
+#include "render_common.hpp"
 #include <cstdlib>
 #include "wave_scan.hpp"
 
@@ -47,29 +47,6 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kBrick = 16;                       // brick edge (voxels)
-
-struct RenderDims {
-    int N, NC, X, Y, Z, R, ZR;
-    int sx, sy, sz;                              // element strides of one image's volume (fit in int)
-    double step;                                 // 1/(ZR-1)
-    float lo, hi;                                // clamp bounds of spherical_proj.py:66
-    float pre_scale;                             // != 0: the volume is clamp(vox * pre_scale, lo, hi), formed on the
-                                                 //       fly (the caller's `clamp(proj * 50, 1e-5, 1 - 1e-5)` folded in)
-    int pad;                                     // > 0: the map is written / read as sph_pad(map, pad) would lay it out
-};
-
-// sph_pad (spherical_proj.py:21-28) as a fan-out of map pixel (i, j): replicate padding repeats the first / last
-// row pad more times (:23); the left margin is then overwritten by the last pad interior columns and the right
-// margin by the first pad ones (:25-26, azimuth wraps around), rows included.  Output rows r_lo .. r_lo+r_n-1,
-// column c0 and (if >= 0) c1.  Needs 2*pad <= R.
-__device__ __forceinline__ void pad_span(int R, int pm, int i, int j, int &r_lo, int &r_n, int &c0, int &c1)
-{
-    r_lo = (i == 0) ? 0 : i + pm;
-    r_n = ((i == R - 1) ? R - 1 + 2 * pm : i + pm) - r_lo + 1;
-    c0 = j + pm;
-    c1 = (j >= R - pm) ? j - (R - pm) : (j < pm ? j + R + pm : -1);
-}
 
 // lane-parallel store of one ray's value to all its padded positions (value is wave-uniform)
 __device__ __forceinline__ void store_map(const RenderDims &D, float *oimg, const View4 &out, int q, int lane, float v)
@@ -105,40 +82,6 @@ __device__ __forceinline__ float load_map_grad(const RenderDims &D, const float 
         if (c1 >= 0) g += gimg[(r_lo + r) * gout.s2 + c1 * gout.s3];
     }
     return g;
-}
-
-// sample k of the ray with doubled direction 2*dir (fp64): spherical_proj.py:50-56
-__device__ __forceinline__ void sample_pos(const RenderDims &D, double dx2, double dy2, double dz2, int k,
-                                           float &gx, float &gy, float &gz)
-{
-    const double alpha = (k == D.ZR - 1) ? 1.0 : (double)k * D.step;       // numpy.linspace(0,1,ZR)[k]
-    const double a = 1.0 - alpha;
-    gx = (float)(dx2 * a); gy = (float)(dy2 * a); gz = (float)(dz2 * a);
-}
-
-// ATen grid_sampler_3d coordinates (align_corners=True): base corner + weights of the two corners
-// per axis.  x -> X axis, y -> Y, z -> Z (vox.permute(0,1,4,3,2) in spherical_proj.py:64).
-struct Cell { int x0, y0, z0; float wx0, wx1, wy0, wy1, wz0, wz1; };
-
-__device__ __forceinline__ bool locate(const RenderDims &D, float gx, float gy, float gz, Cell &c)
-{
-    const float ix = ((gx + 1.f) / 2) * (D.X - 1);
-    const float iy = ((gy + 1.f) / 2) * (D.Y - 1);
-    const float iz = ((gz + 1.f) / 2) * (D.Z - 1);
-    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    c.x0 = (int)fx; c.y0 = (int)fy; c.z0 = (int)fz;
-    c.wx1 = ix - fx; c.wy1 = iy - fy; c.wz1 = iz - fz;                       // weight of the +1 corner
-    c.wx0 = (fx + 1) - ix; c.wy0 = (fy + 1) - iy; c.wz0 = (fz + 1) - iz;
-    // at least one of the 8 corners inside the volume?
-    return c.x0 >= -1 && c.x0 < D.X && c.y0 >= -1 && c.y0 < D.Y && c.z0 >= -1 && c.z0 < D.Z;
-}
-
-// ATen corner order: tnw, tne, tsw, tse, bnw, bne, bsw, bse (t/b: z, n/s: y, w/e: x); weight
-// products evaluated left to right as ATen does.
-__device__ __forceinline__ float corner_w(const Cell &c, int i)
-{
-    const float wx = (i & 1) ? c.wx1 : c.wx0, wy = (i & 2) ? c.wy1 : c.wy0, wz = (i & 4) ? c.wz1 : c.wz0;
-    return wx * wy * wz;
 }
 
 __device__ __forceinline__ float gather(const RenderDims &D, const float *__restrict__ base, const Cell &c)
@@ -408,7 +351,6 @@ __global__ __launch_bounds__(kBlock) void render_bwd_dp_kernel(RenderDims D, Vie
 // (18^3 floats, zeros outside the volume) with coalesced row reads -- each voxel leaves HBM/L2 once per
 // row instead of once per tap -- then evaluates its samples with 8 LDS reads each and writes the raw
 // value v[ray, k].
-constexpr int kTile = kBrick + 2;
 
 // Which cell a listed sample falls in and its eight trilinear weights depend on the geometry only, not on the
 // image -- and that arithmetic (fp64 position, floor/convert, weight products: ~80 of the ~100 VALU instructions
@@ -419,7 +361,6 @@ constexpr int kTile = kBrick + 2;
 // Measured at batch 32 (sample kernel alone): one image per workgroup 390 us; G = 2 x 512 threads, 3 x 512 and
 // 4 x 1024 all 330 us -- of which ~120 us is tile staging and ~90 us the v stores (ablations), i.e. the kernel is
 // now bound by its memory phases, not by the geometry arithmetic; G = 2 keeps three workgroups per CU.
-constexpr int kTile3 = kTile * kTile * kTile;
 constexpr int kGroup = 2, kGroupBlock = 512;
 
 template <int G, int NT>
@@ -428,13 +369,22 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
                                                                         const int *__restrict__ fwd_table,
                                                                         const int *__restrict__ fwd_list,
                                                                         float *__restrict__ vbuf, int imgs,
-                                                                        int *__restrict__ live)
+                                                                        int *__restrict__ live, int live_is_input)
 {
     extern __shared__ float gtile[];                                     // [G][kTile3]
     // (placing all rows of an image group on one XCD, as render_bwd_brick_kernel does, made THIS kernel 6 % slower)
     const int trow = blockIdx.x;
     const int img0 = blockIdx.y * G;
     const int ng = (imgs - img0 < G) ? imgs - img0 : G;
+    if (live_is_input) {
+        // the backward's recomputation of v: images in which no voxel passes the pre_scale clamp (the forward's live words) have an
+        // identically zero gradient -- nothing reads their sample values
+        const int nb_all = ((D.X + kBrick - 1) / kBrick) * ((D.Y + kBrick - 1) / kBrick) * ((D.Z + kBrick - 1) / kBrick);
+        bool any = false;
+        for (int g = 0; g < ng; g++) any |= live[(int64_t)(img0 + g) * (nb_all + 1)] != 0;
+        if (!any) return;
+        live = nullptr;
+    }
     const int brick = fwd_table[trow * 4 + 0];
     const int begin = fwd_table[trow * 4 + 1], end = fwd_table[trow * 4 + 2];
     const int nby = (D.Y + kBrick - 1) / kBrick, nbz = (D.Z + kBrick - 1) / kBrick;
@@ -554,14 +504,14 @@ __global__ __launch_bounds__(NT) void render_sample_brick_group_kernel(RenderDim
 template <int G, int NT>
 int launch_sample_group(const char *op, const RenderDims &D, const genre_tensor *vox, const genre_tensor *dirs,
                         const genre_tensor *fwd_table, const genre_tensor *fwd_chunks, const genre_tensor *v_scratch,
-                        int rows, int imgs, int *live, hipStream_t st)
+                        int rows, int imgs, int *live, int live_is_input, hipStream_t st)
 {
     constexpr size_t lds = (size_t)G * kTile3 * sizeof(float);
     static std::atomic<uint64_t> done{0};
     if (!reserve_lds(op, reinterpret_cast<const void *>(&render_sample_brick_group_kernel<G, NT>), lds, done)) return 0;
     render_sample_brick_group_kernel<G, NT><<<dim3(rows, (imgs + G - 1) / G), NT, lds, st>>>(
         D, view5(vox), (const double *)dirs->data, (const int *)fwd_table->data, (const int *)fwd_chunks->data,
-        (float *)v_scratch->data, imgs, live);
+        (float *)v_scratch->data, imgs, live, live_is_input);
     return 1;
 }
 
@@ -884,38 +834,6 @@ __global__ __launch_bounds__(kBlock) void zero_vec4_kernel(float4 *__restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) a[i] = z;
 }
 
-int check_render(const char *op, const genre_tensor *vox, const genre_tensor *dirs, const genre_tensor *dw,
-                 const genre_tensor *map, RenderDims &D)
-{
-    GENRE_REQUIRE(is_f32(vox, 5), "%s: vox must be a 5-D fp32 tensor [N,NC,X,Y,Z]", op);
-    GENRE_REQUIRE(dirs && dirs->ndim == 3 && dirs->size[0] >= 0, "%s: dirs must be a 3-D tensor", op);
-    D.N = (int)vox->size[0]; D.NC = (int)vox->size[1];
-    D.X = (int)vox->size[2]; D.Y = (int)vox->size[3]; D.Z = (int)vox->size[4];
-    D.R = (int)dirs->size[0];
-    // the map is [N,NC,R,R], or [N,NC,R+2p,R+2p] laid out as sph_pad(map, p) (spherical_proj.py:21-28)
-    GENRE_REQUIRE(is_f32(map, 4) && map->size[0] == vox->size[0] && map->size[1] == vox->size[1] &&
-                      map->size[2] == map->size[3] && map->size[2] >= D.R && ((map->size[2] - D.R) & 1) == 0 &&
-                      (map->size[2] - D.R) <= D.R,
-                  "%s: the spherical map must be a 4-D fp32 tensor [N,NC,R+2p,R+2p] with 0 <= 2p <= R = %d", op, D.R);
-    D.pad = (int)(map->size[2] - D.R) / 2;
-    int64_t span = 1;
-    for (int i = 2; i < 5; i++) {
-        GENRE_REQUIRE(vox->stride[i] >= 0, "%s: negative vox strides are not supported", op);
-        span += (vox->size[i] - 1) * vox->stride[i];
-    }
-    GENRE_REQUIRE(span < ((int64_t)1 << 31), "%s: one image's volume must span < 2^31 elements", op);
-    D.sx = (int)vox->stride[2]; D.sy = (int)vox->stride[3]; D.sz = (int)vox->stride[4];
-    // dirs: [R,R,6] fp32 words = [R,R,3] float64 unit directions (the caller passes the raw storage)
-    GENRE_REQUIRE(dirs && dirs->data && dirs->ndim == 3 && dirs->size[0] == D.R && dirs->size[1] == D.R &&
-                      dirs->size[2] == 6 && is_contiguous(dirs) && ((uintptr_t)dirs->data & 7u) == 0,
-                  "%s: dirs must be the contiguous float64 [R,R,3] direction table viewed as fp32 [R,R,6]", op);
-    GENRE_REQUIRE(is_f32(dw, 1) && is_contiguous(dw) && dw->size[0] >= 1, "%s: depth_weight must be a 1-D fp32 tensor", op);
-    D.ZR = (int)dw->size[0];
-    D.step = D.ZR > 1 ? 1.0 / (double)(D.ZR - 1) : 0.0;
-    D.lo = 1e-5f; D.hi = (float)(1 - 1e-5);                              // spherical_proj.py:66
-    return 1;
-}
-
 inline int grid_for_rays(int64_t rays)
 {
     int64_t b = (rays + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -993,8 +911,8 @@ extern "C" int genre_render_spherical_forward(const genre_tensor *vox, const gen
         // batches: kGroup images share one walk over the sample list; a lone image gets the same kernel with G = 1
         // (512 threads per workgroup: 38.9 us for the batch-1 forward chain against 42.1 with 256, 42.2 with 1024)
         const int ok = imgs >= 2
-            ? launch_sample_group<kGroup, kGroupBlock>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, live_p, st)
-            : launch_sample_group<1, 512>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, live_p, st);
+            ? launch_sample_group<kGroup, kGroupBlock>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, live_p, 0, st)
+            : launch_sample_group<1, 512>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, rows, imgs, live_p, 0, st);
         if (!ok) return 0;
         GENRE_LAUNCH_CHECK("render_spherical forward (bricks)");
         // (LDS-transposed per-lane serial scans for this layout -- 64 rays per wave, 16-sample tiles -- measured 136 us
@@ -1017,7 +935,8 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                                                const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
                                                const genre_tensor *brick_table, const genre_tensor *chunk_list,
                                                const genre_tensor *v_scratch, const genre_tensor *kin,
-                                               const genre_tensor *live, float pre_scale, void *stream)
+                                               const genre_tensor *live, const genre_tensor *fwd_table,
+                                               const genre_tensor *fwd_chunks, float pre_scale, void *stream)
 {
     const char *op = "render_spherical_backward";
     RenderDims D{};
@@ -1054,6 +973,19 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                           "%s: v_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR elements", op);
             GENRE_REQUIRE(is_i32(kin, 1) && is_contiguous(kin) && kin->size[0] == (int64_t)D.R * D.R,
                           "%s: kin must be int32 [R*R]", op);
+            if (fwd_table != nullptr && fwd_chunks != nullptr) {
+                // the forward saved nothing (genre_render_seg_forward): the raw sample values are recomputed from the volume, for
+                // the images with a live gradient only
+                int frows = 0;
+                if (!check_tables(op, D, fwd_table, fwd_chunks, frows)) return 0;
+                const int ok = imgs >= 2
+                    ? launch_sample_group<kGroup, kGroupBlock>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, frows, imgs,
+                                                               const_cast<int *>(live_p), live_p != nullptr, st)
+                    : launch_sample_group<1, 512>(op, D, vox, dirs, fwd_table, fwd_chunks, v_scratch, frows, imgs,
+                                                  const_cast<int *>(live_p), live_p != nullptr, st);
+                if (!ok) return 0;
+                GENRE_LAUNCH_CHECK("render_spherical backward (resample)");
+            }
             render_scan_bwd_kernel<<<scan_grid(D), kBlock, 0, st>>>(
                 D, (const float *)v_scratch->data, (const int *)kin->data, (const float *)depth_weight->data,
                 view4(grad_out), (float *)dp_scratch->data, dpmax, live_p, nb + 1);

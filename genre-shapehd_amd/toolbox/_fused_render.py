@@ -2,11 +2,11 @@
 grid_sample -> clamp -> CalcStopProb -> matmul -> prod -> add chain
 (toolbox/spherical_proj.py:62-72).
 
-Forward : brick kernel (18^3 voxel tile staged in LDS with coalesced reads, trilinear taps read
-          from LDS) writes the raw sample values v[ray, k]; a wave-per-ray scan kernel turns them
-          into the spherical map.  v is what is saved for backward (16 MiB/image, half of what
-          the reference's autograd keeps: prob_sph + stop_prob).
-Backward: scan kernel v -> dL/dp[ray, k]; brick kernel accumulates the trilinear adjoint in
+Forward : segment kernel (csrc/sph_render_seg.hip: 18^3 voxel tile staged in LDS with coalesced reads, one lane marches one
+          segment of a ray through it, trilinear taps read from LDS) leaves one (P, S) pair per segment; a per-ray pass
+          chains them into the spherical map.  Nothing per sample goes through memory and nothing is saved for backward.
+Backward: the raw sample values v[ray, k] are recomputed from the volume (only for images in which some voxel passes the
+          pre_scale clamp); scan kernel v -> dL/dp[ray, k]; brick kernel accumulates the trilinear adjoint in
           64-bit fixed-point LDS tiles and writes every voxel of grad_vox once (no global atomics).
 Which samples touch which brick depends only on the geometry; the lists are built once here
 with exactly the kernel's fp64/fp32 arithmetic and cached per geometry/device."""
@@ -182,6 +182,35 @@ def tables_for(vox_shape, device, dirs64, z_res):
     return t
 
 
+def seg_tables_for(vox_shape, device, dirs64, depth_weight):
+    """tables of the segment forward (toolbox/_seg_tables.py), built on first use and cached per geometry and device; small
+    batches get rows of fewer segments (more workgroups for 256 CUs).  Keyed on the CONTENTS of depth_weight (the prefix table
+    depends on it), read back once per address + version (_content_of)."""
+    from . import _seg_tables
+    small = vox_shape[0] * vox_shape[1] < SMALL_BATCH
+    dw_hash, dw = _content_of(depth_weight)
+    key = ("seg", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], dw_hash, str(device), small)
+    t = _TABLES.get(key)
+    if t is None:
+        d64 = dirs64.cpu().numpy()
+        split = _seg_tables.SPLIT_SMALL if small else _seg_tables.SPLIT
+
+        def build():
+            return _seg_tables.build_seg_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, split=split)
+        build.__module__ = _seg_tables.__name__
+        np_t = _disk_cached("seg", (tuple(vox_shape[2:]), split, _seg_tables.MAX_SEG, _seg_tables.BRICK, "r6"), [d64, dw], build)
+        t = {"smax": int(np_t["smax"][0])}
+        for k, v in np_t.items():
+            if k == "smax":
+                continue
+            tv = torch.from_numpy(np.ascontiguousarray(v))
+            if k == "ray_pre":
+                tv = tv.view(torch.float32).reshape(-1, 4)
+            t[k] = tv.to(device)
+        _remember(key, t)
+    return t
+
+
 def _bm_tables_module():
     from . import _bm_tables
     return _bm_tables
@@ -240,31 +269,84 @@ def new_brick_words(n, res, device):
     return torch.empty((-(-n // _GROUP), -(-res // bx), -(-res // by), -(-res // bz)), dtype=torch.int32, device=device)
 
 
-def attach_hint(vol, words, res):
-    import numpy as np
-    fill = float(np.float32(1) - np.float32(res) * np.float32(1.0 / res))      # csrc/cam_bp.hip: fill_val of the shifted op
-    vol._genre_brick_hint = (words, fill, vol._version)
+def shifted_fill(res):
+    """csrc/cam_bp.hip: fill_val of the shifted op, 1 - res * (1 / res) in fp32"""
+    return float(np.float32(1) - np.float32(res) * np.float32(1.0 / res))
+
+
+def attach_hint(vol, words, res, cell=None):
+    """hang the producer's occupancy words on the volume it returns.  cell = None: the leader pass's words per group of 32 images
+    and 4x8x8-voxel brick (image-minor volumes -> csrc/sph_render_bm.hip); cell = cx*10000 + cy*100 + cz: the brick kernel's
+    words per image and cx x cy x cz-voxel cell (dense NCXYZ volumes -> csrc/sph_render_seg.hip).  Tensors of
+    torch.inference_mode() carry no version counter, i.e. nothing a later in-place write would invalidate the hint with:
+    they get none."""
+    if vol.is_inference():
+        return vol
+    if cell is None:
+        vol._genre_brick_hint = (words, shifted_fill(res), vol._version)
+    else:
+        vol._genre_cell_hint = (words, shifted_fill(res), vol._version, int(cell))
     return vol
 
 
-def occupancy_hint(vox, t, pre_scale, lib):
+_LO, _HI = float(np.float32(1e-5)), float(np.float32(1 - 1e-5))            # spherical_proj.py:66
+_WARNED = set()
+
+
+def _fill_passes_clamp(fill, pre_scale):
+    """does clamp(fill * pre_scale, lo, hi) pass the gradient (lo <= fill * pre_scale <= hi, fp32)?"""
+    raw = float(np.float32(fill) * np.float32(pre_scale))
+    return _LO <= raw <= _HI
+
+
+def _hint_usable(fill, pre_scale, with_grad):
+    """A dead tile's saved state is not written (csrc/sph_render_bm.hip) / its clamp pass words stay 0 (sph_render_seg.hip):
+    only right when no gradient can come back through it -- pre_scale folded in AND the fill value blocked by its clamp
+    (GenRe: fill 0 at pre_scale 50).  Without a gradient the constants are all that matters."""
+    return not with_grad or (pre_scale != 0.0 and not _fill_passes_clamp(fill, pre_scale))
+
+
+def _ps_empty_slot(t, key):
+    """a handful of (fill, pre_scale) constant tables per geometry, never evicted (captured HIP graphs hold raw pointers into
+    them); the fifth pair is refused -- loudly, once: every tile is read from then on"""
+    if key in t:
+        return True
+    if torch.cuda.is_current_stream_capturing():
+        return False                        # (built outside graph capture only: callers warm up before they capture)
+    if sum(1 for k in t if isinstance(k, tuple) and k[:1] == key[:1]) >= 4:
+        if key[:1] not in _WARNED:
+            import warnings
+            _WARNED.add(key[:1])
+            warnings.warn("render_spherical: more than four (fill, pre_scale) pairs on one geometry -- the occupancy hint is "
+                          "ignored for the new ones (every tile is read)")
+        return False
+    return True
+
+
+def _live_hint(vox, name):
+    """the hint `name` of vox if the tensor still is what the producer wrote: same object, same version counter (any ATen
+    in-place write bumps it; a raw write through the C ABI drops the attribute: _loader._call)"""
+    hint = getattr(vox, name, None)
+    if hint is None or vox.is_inference() or hint[2] != vox._version:
+        return None
+    return hint
+
+
+def occupancy_hint(vox, t, pre_scale, lib, with_grad=False):
     """(tile_live, ps_empty) for render_bm_forward, or (None, None): the words the producer hung on `vox` -- if it still is what the
     producer wrote -- and the geometry's (P, S) constants on the constant volume, built on first use by rendering one"""
-    hint = getattr(vox, "_genre_brick_hint", None)
-    if hint is None or hint[2] != vox._version:
+    hint = _live_hint(vox, "_genre_brick_hint")
+    if hint is None or not _hint_usable(hint[1], float(pre_scale), with_grad):
         return None, None
-    words, fill, _ = hint
+    words, fill = hint[0], hint[1]
     bx, by, bz = _bm_brick()
     n, _, X, Y, Z = vox.shape
     if tuple(words.shape) != (-(-n // _GROUP), -(-X // bx), -(-Y // by), -(-Z // bz)) or words.device != vox.device:
         return None, None
     key = ("ps_empty", fill, float(pre_scale))
+    if not _ps_empty_slot(t, key):
+        return None, None
     if key not in t:
-        if torch.cuda.is_current_stream_capturing():
-            return None, None               # (built outside graph capture only: callers warm up before they capture)
-        if sum(1 for k in t if isinstance(k, tuple) and k[:1] == ("ps_empty",)) >= 4:
-            return None, None               # a handful of (fill, pre_scale) pairs per geometry; never evicted: captured HIP
-                                            # graphs hold raw pointers into these tables
         const = empty_batch_minor((_GROUP, 1, X, Y, Z), torch.float32, vox.device).fill_(fill)
         res_map = int(round((t["ray_ptr"].shape[0] - 1) ** 0.5))
         out = torch.empty((_GROUP, 1, res_map, res_map), dtype=torch.float32, device=vox.device)
@@ -277,6 +359,32 @@ def occupancy_hint(vox, t, pre_scale, lib):
         pe[:, 2] = t["segs"][:, 0]
         t[key] = pe.view(torch.float32)                                    # [nseg, 4] = (P, S, line bits, 0), table order
     return words, t[key]
+
+
+def occupancy_hint_std(vox, t, dirs64, depth_weight, pre_scale, lib, with_grad=False):
+    """(occ, ps_empty, occ_cell) for render_seg_forward, or (None, None, 0): the per-image cell words the camera forward's brick
+    kernel hung on the dense volume `vox` -- if it still is what that op wrote -- and the (P, S) pair of every segment on the
+    constant volume, built on first use by rendering one (the sampler's own output: bit-identical to what the march computes)"""
+    hint = _live_hint(vox, "_genre_cell_hint")
+    if hint is None or not _hint_usable(hint[1], float(pre_scale), with_grad):
+        return None, None, 0
+    words, fill, _, cell = hint
+    n, nc, X, Y, Z = vox.shape
+    cx, cy, cz = cell // 10000, (cell // 100) % 100, cell % 100
+    if tuple(words.shape) != (n * nc, -(-X // cx), -(-Y // cy), -(-Z // cz)) or words.device != vox.device:
+        return None, None, 0
+    key = ("ps_empty_std", fill, float(pre_scale))
+    if not _ps_empty_slot(t, key):
+        return None, None, 0
+    if key not in t:
+        res = dirs64.shape[0]
+        const = torch.full((1, 1, X, Y, Z), fill, dtype=torch.float32, device=vox.device)
+        out = torch.empty((1, 1, res, res), dtype=torch.float32, device=vox.device)
+        ps = torch.empty((t["smax"] * res * res * 2,), dtype=torch.float32, device=vox.device)
+        lib.render_seg_forward(const, dirs64.view(torch.float32), depth_weight, out, t["seg_rows"], t["segs"], t["ray_nseg"],
+                               t["ray_pre"], ps, float(pre_scale))
+        t[key] = ps.view(-1, 2)[t["segs"][:, 2].long()].contiguous()            # [nseg, 2], table order
+    return words, t[key], cell
 
 
 def is_batch_minor(vox):
@@ -319,25 +427,28 @@ class RenderSphericalFused(Function):
                 if pre_scale:
                     mask = torch.empty((groups * vox.shape[2] * vox.shape[3] * vox.shape[4] + groups,), dtype=torch.int32,
                                        device=vox.device)
-            words, ps_empty = occupancy_hint(vox, t, ctx.pre_scale, lib)
+            words, ps_empty = occupancy_hint(vox, t, ctx.pre_scale, lib, with_grad=stash is not None)
             lib.render_bm_forward(vox, out, t["segs"], t["rec_f"], t["fwd_rows"], t["ray_ptr"], t["ray_seg"],
                                   t["ray_pre"], ps, stash, mask, ctx.pre_scale, words, ps_empty)
             ctx.vox_shape = vox.shape
             ctx.mask = mask
             ctx.save_for_backward(dirs64, depth_weight, ps, stash)
             return out
-        t = tables_for(vox.shape, vox.device, dirs64, z_res)
-        rays = vox.shape[0] * vox.shape[1] * res * res
-        v = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
-        # with pre_scale and a backward to come: the clamp's pass words per image and per 16^3 brick (csrc/sph_render.hip) --
-        # what the clamp blocks is then written as zeros by the backward, not computed (GenRe's own volumes: everything)
+        # standard layout: the segment forward (csrc/sph_render_seg.hip) -- one (P, S) pair per segment, nothing saved
+        t = seg_tables_for(vox.shape, vox.device, dirs64, depth_weight)
+        imgs = vox.shape[0] * vox.shape[1]
+        ps = torch.empty((imgs * t["smax"] * res * res * 2,), dtype=torch.float32, device=vox.device)
+        # with pre_scale and a backward to come: the clamp's pass words per image and per 16^3 brick -- what the clamp blocks
+        # is then written as zeros by the backward, not computed (GenRe's own volumes: everything)
         ctx.live = None
         if pre_scale and ctx.needs_input_grad[0]:
             nb = -(-vox.shape[2] // BRICK) * -(-vox.shape[3] // BRICK) * -(-vox.shape[4] // BRICK)
-            ctx.live = torch.empty((vox.shape[0] * vox.shape[1] * (1 + nb),), dtype=torch.int32, device=vox.device)
-        lib.render_spherical_forward(vox, dirs64.view(torch.float32), depth_weight, out,
-                                     v, t["fwd_table"], t["fwd_chunks"], t["kin"], float(pre_scale), ctx.live)
-        ctx.save_for_backward(vox, dirs64, depth_weight, v)
+            ctx.live = torch.empty((imgs * (1 + nb),), dtype=torch.int32, device=vox.device)
+        occ, ps_empty, cell = occupancy_hint_std(vox, t, dirs64, depth_weight, ctx.pre_scale, lib,
+                                                 with_grad=bool(ctx.needs_input_grad[0]))
+        lib.render_seg_forward(vox, dirs64.view(torch.float32), depth_weight, out, t["seg_rows"], t["segs"], t["ray_nseg"],
+                               t["ray_pre"], ps, ctx.pre_scale, ctx.live, occ, ps_empty, cell)
+        ctx.save_for_backward(vox, dirs64, depth_weight)
         return out
 
     @staticmethod
@@ -353,12 +464,15 @@ class RenderSphericalFused(Function):
                                    t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,
                                    ctx.pre_scale, t["pull_code"])
             return grad_vox, None, None, None, None
-        vox, dirs64, depth_weight, v = ctx.saved_tensors
+        vox, dirs64, depth_weight = ctx.saved_tensors
         z_res = depth_weight.shape[0]
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
         rays = vox.shape[0] * vox.shape[1] * dirs64.shape[0] * dirs64.shape[0]
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
+        # the raw sample values are recomputed from the volume here (fwd tables), for images with a live gradient only
+        v = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
         scratch = torch.empty((rays * z_res + vox.shape[0] * vox.shape[1],), dtype=torch.float32, device=vox.device)
         lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,
-                                      scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"], ctx.pre_scale, ctx.live)
+                                      scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"], ctx.pre_scale, ctx.live,
+                                      t["fwd_table"], t["fwd_chunks"])
         return grad_vox, None, None, None, None

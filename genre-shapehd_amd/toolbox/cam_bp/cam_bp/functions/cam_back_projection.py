@@ -7,8 +7,6 @@ op writes every element, so the reference's two ``zero_()`` passes and the
 ``+ 1/res`` pass, :22-24, disappear), and ``cnt`` is kept both on ``ctx`` (as the
 reference does, :28) and in ``saved_tensors``.
 """
-import os
-
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -16,32 +14,15 @@ from torch.autograd.function import once_differentiable
 from .._ext import cam_bp_lib
 
 
-_CAM_MODE = None
-
-
-def _cam_mode():
-    """GENRE_CAMBP_MODE as the LIBRARY sees it: read once per process (csrc/cam_bp.hip caches it at its first call), so that the
-    Python-side routing and the C side never disagree when the variable changes mid-process"""
-    global _CAM_MODE
-    if _CAM_MODE is None:
-        _CAM_MODE = os.environ.get("GENRE_CAMBP_MODE", "")
-    return _CAM_MODE
-
-
 def leader_halo(res, fl, cam_dist):
-    """csrc/cam_bp.hip: leader_halo -- how many pixels apart two points of one voxel can project for a camera (fl, cam_dist)
-    looking at the unit cube from (-cam_dist, 0, 0); -1: the camera is too close for the bound"""
+    """csrc/cam_bp.hip: leader_halo restated -- how many pixels apart two points of one voxel can project for a camera (fl,
+    cam_dist) looking at the unit cube from (-cam_dist, 0, 0); -1: the camera is too close for the bound.  The product does not
+    call it (the library decides: cam_bp_lib.forward_plan); tests/test_cam_leader_host.py pins the bound against it."""
     x_min = float(cam_dist) - 0.5
     if not (x_min > 0.05) or not (fl > 0):
         return -1
     b = float(fl) * ((1.0 / res) / x_min + 0.5 * (1.0 / res) / (x_min * x_min))
     return int(b * (1.0 + 1e-4) + 1e-3)
-
-
-def leader_pass_serves(res, const):
-    """will an image-minor volume with camera `const` = (fl, cam_dist) (Python floats) take fill + the leader pass?  The
-    library's own precondition (csrc/cam_bp.hip: forward_impl), asked by the Function below and by the layer"""
-    return const is not None and _cam_mode() in ("", "auto") and 0 <= leader_halo(res, const[0], const[1]) <= 4
 
 
 class CameraBackProjection(Function):
@@ -82,12 +63,13 @@ class ShiftedCameraBackProjection(Function):
     values, one full-volume elementwise pass less in each direction.  Used by the layer."""
 
     @staticmethod
-    def forward(ctx, depth_t, fl, cam_dist, res=128, batch_minor=False, const=None, tile_live=None):
+    def forward(ctx, depth_t, fl, cam_dist, res=128, batch_minor=False, const=None, hint=None):
         """const = (fl, cam_dist) as Python floats when the two tensors are filled with those constants (the layer's
         default call, camera_backprojection_module.py:16-21): the forward then takes the by-value entry point (no
         loads of the camera in front of the brick screen); the tensors are still what the backward reads.
-        tile_live: optional int32 [groups, nbx, nby, nbz] the op fills with its occupancy words when it takes the leader pass
-        (image-minor output, camera by value) -- ctx.hinted says whether it did"""
+        hint: an empty dict the op fills with its occupancy words for the renderer -- hint["words"] (int32) and hint["cell"]
+        (None: the leader pass's words per group of 32 images and renderer brick, image-minor volumes; cx*10000 + cy*100 + cz:
+        the brick kernel's words per image and cell, dense volumes) -- when the by-value entry serves the call"""
         assert depth_t.dim() == 4
         n, nc = depth_t.shape[0], depth_t.shape[1]
         assert fl.dim() == 2 and tuple(fl.shape) == (n, nc)
@@ -102,23 +84,29 @@ class ShiftedCameraBackProjection(Function):
         else:
             out = torch.empty((n, nc, res, res, res), dtype=depth_t.dtype, device=depth_t.device)
             cnt = torch.empty_like(out)
-        # the by-value entry runs (a) the single-launch brick kernel on dense NCXYZ outputs whose z rows are float4-aligned
-        # (res % 4 == 0 for the tensors allocated above), at most 65535 images, brick / auto mode, or (b) on image-minor
-        # outputs fill + the deterministic, atomic-free leader pass, for cameras whose voxels project to <= 4 pixels (round
-        # 5; auto mode) -- the library's own preconditions (csrc/cam_bp.hip: forward_impl, leader_halo), checked HERE so that
-        # every other case (res = 30, 126, ...; the scatter / gather modes; a very close camera) takes the tensor entry
-        # instead of an error
-        image_minor = batch_minor and nc == 1
-        if image_minor:
-            by_value = leader_pass_serves(res, const)
-        else:
-            by_value = const is not None and n * nc <= 65535 and res % 4 == 0 and _cam_mode() in ("", "auto", "brick")
-        ctx.hinted = bool(by_value and image_minor and tile_live is not None)
-        if by_value:
-            # (image-minor: cnt is kept for THIS Function's backward alone, which reads it at the voxel of every in-grid pixel and
+        # the by-value entry runs (a) the single-launch brick kernel on dense NCXYZ outputs whose z rows are float4-aligned, or
+        # (b) fill + the deterministic, atomic-free leader pass on other layouts, for cameras whose voxels project to <= 4 pixels.
+        # Which one -- or neither (res = 30, 126, ...; the scatter / gather modes; a very close camera: the tensor entry then) --
+        # is the LIBRARY's decision, asked of it for the very tensors it will write (cam_bp_lib.forward_plan; ADVICE r3 / r5:
+        # nothing is mirrored here)
+        plan = cam_bp_lib.forward_plan(out, cnt, const[1], const[0]) if const is not None else cam_bp_lib.PLAN_NONE
+        if plan != cam_bp_lib.PLAN_NONE:
+            words = None
+            if hint is not None and nc == 1:
+                if plan == cam_bp_lib.PLAN_LEADER:
+                    from ...._fused_render import new_brick_words
+                    words = new_brick_words(n, res, depth_t.device)
+                    hint["cell"] = None
+                else:
+                    cx, cy, cz = cam_bp_lib.cam_cell()
+                    words = torch.empty((n * nc, -(-res // cx), -(-res // cy), -(-res // cz)), dtype=torch.int32,
+                                        device=depth_t.device)
+                    hint["cell"] = cx * 10000 + cy * 100 + cz
+                hint["words"] = words
+            # (leader pass: cnt is kept for THIS Function's backward alone, which reads it at the voxel of every in-grid pixel and
             # nowhere else -- the leader pass then writes only those elements and half of the fill disappears)
-            cam_bp_lib.back_projection_forward_const(depth_t, const[1], const[0], out, cnt, shifted=True,
-                                                     tile_live=tile_live if ctx.hinted else None, sparse_cnt=image_minor)
+            cam_bp_lib.back_projection_forward_const(depth_t, const[1], const[0], out, cnt, shifted=True, tile_live=words,
+                                                     sparse_cnt=plan == cam_bp_lib.PLAN_LEADER)
         else:
             cam_bp_lib.back_projection_forward_shifted(depth_t, cam_dist, fl, out, cnt)
         ctx.save_for_backward(depth_t, fl, cam_dist, cnt)

@@ -6,7 +6,7 @@ import torch
 from torch import nn
 
 from ..functions import CameraBackProjection
-from ..functions.cam_back_projection import ShiftedCameraBackProjection, leader_pass_serves
+from ..functions.cam_back_projection import ShiftedCameraBackProjection
 
 
 class Camera_back_projection_layer(nn.Module):
@@ -47,15 +47,18 @@ class Camera_back_projection_layer(nn.Module):
             cam_dist = self._const(cam_dist, n, depth_t.device)
         if shift:       # 1 - res*tdf evaluated inside the native op (same values as shift_tdf(df))
             bm = self.batch_minor and n >= 16 and depth_t.size(1) == 1
-            if not (bm and leader_pass_serves(self.res, const)):
-                return ShiftedCameraBackProjection.apply(depth_t, fl, cam_dist, self.res, bm, const)
-            # image-minor volume, camera by value: the op's leader pass also says which bricks of which group of 32 images hold
-            # anything but the fill value -- the batch-minor renderer then does not read what it knows to be empty
-            # (toolbox/_fused_render.py: occupancy_hint; csrc/sph_render_bm.hip)
-            from ...._fused_render import new_brick_words, attach_hint
-            words = new_brick_words(n, self.res, depth_t.device)
-            out = ShiftedCameraBackProjection.apply(depth_t, fl, cam_dist, self.res, bm, const, words)
-            return attach_hint(out, words, self.res)
+            if const is None:
+                return ShiftedCameraBackProjection.apply(depth_t, fl, cam_dist, self.res, bm, None)
+            # camera by value: the op also says which parts of the volume hold anything but the fill value -- per group of 32
+            # images and renderer brick (leader pass, image-minor volumes) or per image and 8x8x32-voxel cell (brick kernel, dense
+            # volumes); render_spherical then does not read what it knows to be empty (toolbox/_fused_render.py: occupancy_hint,
+            # occupancy_hint_std; csrc/sph_render_bm.hip, csrc/sph_render_seg.hip)
+            from ...._fused_render import attach_hint
+            hint = {}
+            out = ShiftedCameraBackProjection.apply(depth_t, fl, cam_dist, self.res, bm, const, hint)
+            if hint.get("words") is None:
+                return out
+            return attach_hint(out, hint["words"], self.res, hint["cell"])
         return CameraBackProjection.apply(depth_t, fl, cam_dist, self.res)
 
     @staticmethod

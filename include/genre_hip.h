@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GENRE_ABI_VERSION 4
+#define GENRE_ABI_VERSION 5
 #define GENRE_MAX_DIMS 5
 
 enum { GENRE_F32 = 0, GENRE_I32 = 1 };
@@ -114,16 +114,28 @@ int genre_back_projection_backward_shifted(const genre_tensor *depth, const genr
  *    tdf and cnt bit-identical to a serial evaluation of the reference (back_projection_kernel.cu:215-305).  H = how many pixels
  *    apart two points of one voxel can project, bounded on the host from (fl, camdist, res); cameras with H > 4 (or closer than
  *    0.55 to the grid centre) return 0 -- pass tensors there (fill + scatter with float atomics + normalise).
- * tile_live (optional, leader pass only; NULL otherwise): int32 [ceil(N/32), nbx, nby, nbz], contiguous.  The volume's images are
- * cut into groups of 32 consecutive images (the batch-minor renderer's) and its voxels into nbx x nby x nbz bricks of ceil(X / nbx) x ...
- * voxels; the op clears the tensor and sets word (g, b) = 1 iff some image of group g has a point in brick b OR in one of b's
- * <= 7 neighbours on the high side (b + {0,1}^3) -- i.e. in any brick the TILE of b (the brick plus the voxels one step beyond
- * its high faces: what a trilinear sampler of b's cells reads) can reach.  Every voxel of a tile whose word is 0 holds the fill
- * value (tdf: 1/res; shifted: 1 - res/res) in every image of the group.  A consumer that renders such volumes
- * (genre_render_bm_forward) can skip what it knows to be empty. */
+ * (bit 1 of `shifted` is a permission: the brick kernel writes cnt densely whatever it says.)
+ * tile_live (optional occupancy words for the renderer that consumes the volume; NULL: none), by implementation --
+ * genre_cam_forward_plan() says which one a call will take:
+ *  - leader pass: int32 [ceil(N/32), nbx, nby, nbz], contiguous.  The volume's images are cut into groups of 32 consecutive
+ *    images (the batch-minor renderer's) and its voxels into nbx x nby x nbz bricks of ceil(X / nbx) x ... voxels; the op clears
+ *    the tensor and sets word (g, b) = 1 iff some image of group g has a point in brick b OR in one of b's <= 7 neighbours on the
+ *    high side (b + {0,1}^3) -- i.e. in any brick the TILE of b (the brick plus the voxels one step beyond its high faces: what a
+ *    trilinear sampler of b's cells reads) can reach.  Consumer: genre_render_bm_forward.
+ *  - brick kernel (ABI 5): int32 [N*NC, ceil(X/cx), ceil(Y/cy), ceil(Z/cz)], contiguous, (cx, cy, cz) = genre_cam_cell(): one
+ *    word per image and cell, written by the workgroup that owns the cell (no clearing pass): 1 iff a point landed in the cell
+ *    (or could have: a superset is legal).  Consumer: genre_render_seg_forward.
+ * Every voxel of a tile / cell whose word is 0 holds the fill value (tdf: 1/res; shifted: 1 - res/res). */
 int genre_back_projection_forward_const(const genre_tensor *depth, const genre_tensor *voxel,
                                         const genre_tensor *cnt, const genre_tensor *tile_live, float camdist, float fl,
                                         int shifted, void *stream);
+
+/* cells of the brick kernel's occupancy words, as cx*10000 + cy*100 + cz voxels (80832 = 8 x 8 x 32) */
+int genre_cam_cell(void);
+
+/* which implementation genre_back_projection_forward_const takes for these outputs and this camera: 1 = brick kernel (dense
+ * NCXYZ, float4-aligned z rows), 2 = fill + leader pass, 0 = the call would be refused (pass fl / camdist tensors) */
+int genre_cam_forward_plan(const genre_tensor *voxel, const genre_tensor *cnt, float camdist, float fl);
 
 /* Replaces get_surface_mask (back_projection.c:30-38 -> :840-891, kernel
  * :310-358).  mask [N,NC,X,Y,Z] := 1, except 0 for empty voxels (cnt <= 1e-5)
@@ -292,6 +304,9 @@ int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *
  *    the samples are not recomputed from vox.
  *    live (optional; needs v_scratch + kin and pre_scale != 0): the forward's pass words, see above -- where the clamp
  *    blocks everything the adjoint is a select of zeros, so a non-finite upstream gradient does not reach a dead image.
+ *    fwd_table + fwd_chunks (ABI 5; optional, with v_scratch + kin): the forward saved nothing (genre_render_seg_forward) --
+ *    v_scratch is then plain scratch space and the raw sample values are recomputed from vox first (for the images whose live
+ *    word is set, when live is given).
  *  - those pointers NULL: global-atomic scatter fallback (grad_vox must be
  *    contiguous, 16-byte aligned, numel % 4 == 0). */
 int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
@@ -299,7 +314,33 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
                                     const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
                                     const genre_tensor *brick_table, const genre_tensor *chunk_list,
                                     const genre_tensor *v_scratch, const genre_tensor *kin,
-                                    const genre_tensor *live, float pre_scale, void *stream);
+                                    const genre_tensor *live, const genre_tensor *fwd_table,
+                                    const genre_tensor *fwd_chunks, float pre_scale, void *stream);
+
+/* ---- segment renderer: the forward for the standard (NCXYZ) layout (ABI 5; csrc/sph_render_seg.hip) ----------------
+ *
+ * Same operator and arguments as genre_render_spherical_forward (vox, dirs, depth_weight, out, pre_scale, padded `out`, `live`),
+ * but nothing per SAMPLE goes through memory: a lane marches one SEGMENT -- a run of consecutive samples of one ray whose base
+ * voxel lies in one 16^3-voxel brick -- through the brick's tile in LDS and leaves the pair (prod(1-p), sum T p w); a per-ray
+ * pass chains the pairs.  Tables (genre-shapehd_amd/toolbox/_seg_tables.py: build_seg_tables):
+ *   seg_rows  int32 [rows,4]    (brick, seg begin, seg end, 0): one workgroup each; every brick in >= 1 row (an empty row stages
+ *                               its tile for the live words only)
+ *   segs      int32 [nseg,4]    (ray, k0 | L << 8, scratch line, brick); inside a row sorted by L descending -- the first of every
+ *                               64 consecutive segments is the longest
+ *   ray_nseg  int32 [R*R]       segments per ray; segment s (sample order) of ray q owns scratch line s*R*R + q
+ *   ray_pre   float64 [R*R,2] viewed as fp32 [R*R,4]: (transmittance, partial sum) of the samples before the volume
+ *   ps_scratch fp32 [N*NC * smax*R*R * 2], 8-byte aligned, smax = max(ray_nseg): receives the pairs
+ * Occupancy hint (both or neither): occ int32 [N*NC, ceil(X/cx), ceil(Y/cy), ceil(Z/cz)] with occ_cell = cx*10000 + cy*100 + cz --
+ *   word 0 <=> every voxel of that cx x cy x cz cell of that image holds the producer's fill value c (what
+ *   genre_back_projection_forward_const writes for dense volumes: genre_cam_cell()) -- and ps_empty fp32 [nseg,2], table order:
+ *   the pairs of every segment on the CONSTANT volume vox == c (this op's own ps_scratch on such a volume).  A tile none of whose
+ *   cells is occupied is not read: its segments get the constants.  The caller guarantees that vox still is what the producer
+ *   wrote and, when it passes `live`, that c * pre_scale does not pass the clamp. */
+int genre_render_seg_forward(const genre_tensor *vox, const genre_tensor *dirs, const genre_tensor *depth_weight,
+                             const genre_tensor *out, const genre_tensor *seg_rows, const genre_tensor *segs,
+                             const genre_tensor *ray_nseg, const genre_tensor *ray_pre, const genre_tensor *ps_scratch,
+                             const genre_tensor *live, const genre_tensor *occ, const genre_tensor *ps_empty,
+                             float pre_scale, int occ_cell, void *stream);
 
 /* ---- batch-minor tile renderer (extension; csrc/sph_render_bm.hip) ------------------------------
  *

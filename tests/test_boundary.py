@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libgenre_hip.so does not export %s" % s
     lib.genre_abi_version.restype = C.c_int
-    assert lib.genre_abi_version() == 4
+    assert lib.genre_abi_version() == 5
 
 
 def test_every_symbol_cites_the_reference_interface():
@@ -122,14 +122,38 @@ def test_validation_errors_do_not_launch(genre):
     rc = lib.genre_render_bm_forward(*fargs, None, None, C.byref(desc((2, 2, 1, 1), 1)), C.byref(desc((nseg, 4))), 0.0, None)
     assert rc == 0 and b"tile_live" in lib.genre_last_error()                            # one slab per image group
     lib.genre_back_projection_forward_const.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int, C.c_void_p]
-    rc = lib.genre_back_projection_forward_const(C.byref(depth), C.byref(vox), C.byref(vox), C.byref(desc((1, 1, 1, 1), 1)),
-                                                 2.2, 418.3, 1, None)                    # dense rows: the brick kernel writes no words
-    assert rc == 0 and b"tile_live" in lib.genre_last_error()
-    rc = lib.genre_back_projection_forward_const(C.byref(depth), C.byref(vox), C.byref(vox), None, 2.2, 418.3, 3, None)
-    assert rc == 0 and b"sparse cnt" in lib.genre_last_error()                           # ... and no sparse cnt either
+    rc = lib.genre_back_projection_forward_const(C.byref(depth), C.byref(vox), C.byref(vox), C.byref(desc((2, 1, 1, 1), 1)),
+                                                 2.2, 418.3, 1, None)       # dense rows: the brick kernel's words are per image and cell
+    assert rc == 0 and b"tile_live" in lib.genre_last_error() and b"N*NC, 1, 1, 1" in lib.genre_last_error()
     bmv = bm_vol(2, 4, 4, 4)
     rc = lib.genre_back_projection_forward_const(C.byref(desc((2, 1, 8, 8))), C.byref(bmv), C.byref(bmv), None, 0.6, 418.3, 1, None)
     assert rc == 0 and b"by-value" in lib.genre_last_error()                             # image-minor, but voxels project too wide
+    # ABI 5: which implementation the by-value entry takes is the library's answer (nothing is mirrored in Python) ...
+    lib.genre_cam_forward_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+    assert lib.genre_cam_cell() == 80832
+    assert lib.genre_cam_forward_plan(C.byref(vox), C.byref(vox), 2.2, 418.3) == 1      # dense, float4 rows: brick kernel
+    big_bm = bm_vol(32, 128, 128, 128)
+    assert lib.genre_cam_forward_plan(C.byref(big_bm), C.byref(big_bm), 2.2, 418.3) == 2    # image-minor: fill + leader pass
+    assert lib.genre_cam_forward_plan(C.byref(bmv), C.byref(bmv), 0.6, 418.3) == 0      # ... too close a camera: tensors
+    odd = desc((1, 1, 126, 126, 126))
+    assert lib.genre_cam_forward_plan(C.byref(odd), C.byref(odd), 2.2, 418.3) == 2       # rows not float4-aligned
+    # ... and the segment forward's arguments: the occupancy pair, its cell grid, the scratch size
+    lib.genre_render_seg_forward.argtypes = [C.c_void_p] * 12 + [C.c_float, C.c_int, C.c_void_p]
+    srow, sseg, rn = desc((1, 4), 1), desc((10, 4), 1), desc((64,), 1)
+    sargs = [C.byref(a) for a in (v16, dirs, dw, desc((1, 1, 8, 8)), srow, sseg, rn, desc((64, 4)))]
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(desc((100,))), None, None, None, 0.0, 0, None)
+    assert rc == 0 and b"ps_scratch" in lib.genre_last_error()                          # not a multiple of 2 * R*R
+    pss = desc((3 * 64 * 2,))
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, C.byref(desc((1, 2, 2, 1), 1)), None, 0.0, 80832, None)
+    assert rc == 0 and b"come together" in lib.genre_last_error()
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, C.byref(desc((1, 2, 2, 2), 1)), C.byref(desc((10, 2))),
+                                      0.0, 80832, None)
+    assert rc == 0 and b"occ must be" in lib.genre_last_error()                         # 16^3 voxels in 8x8x32 cells: [1,2,2,1]
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, C.byref(desc((1, 2, 2, 1), 1)), C.byref(desc((9, 2))),
+                                      0.0, 80832, None)
+    assert rc == 0 and b"ps_empty" in lib.genre_last_error()
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), C.byref(desc((1,), 1)), None, None, 50.0, 0, None)
+    assert rc == 0 and b"live" in lib.genre_last_error()
     # empty problems succeed without launching anything
     e = desc((0, 1, 8, 8))
     ev = desc((0, 1, 4, 4, 4))

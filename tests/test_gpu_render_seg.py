@@ -1,0 +1,177 @@
+"""GPU parity of the segment forward (csrc/sph_render_seg.hip; SURVEY 8 f-1 on the layout the reference's callers run): against
+the reference's op sequence on the host (oracle/torch_oracle.py: CPU torch with align_corners=True + the C oracle's calc_prob), against the
+per-sample forward it replaces (csrc/sph_render.hip: fp64 scan over the raw sample values), with and without the camera
+forward's occupancy words, and the backward that now recomputes what the forward no longer saves."""
+import numpy as np
+import pytest
+import torch
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _old_forward(F, mod, vox, pre_scale=0.0, pad=0, live=None):
+    """the per-sample forward of csrc/sph_render.hip (v[ray, k] scratch + fp64 scan per ray)"""
+    lib = F._loader().render_lib
+    n, c = vox.shape[:2]
+    res, zr = mod.sph_res, mod.z_res
+    T = F.tables_for(vox.shape, vox.device, mod._dirs64, zr)
+    out = torch.empty((n, c, res + 2 * pad, res + 2 * pad), device=vox.device)
+    v = torch.empty((n * c * res * res * zr,), device=vox.device)
+    lib.render_spherical_forward(vox, mod._dirs64.view(torch.float32), mod.depth_weight, out, v, T["fwd_table"], T["fwd_chunks"],
+                                 T["kin"], pre_scale, live)
+    return out
+
+
+@pytest.mark.parametrize("shape,sph,zr", [((1, 1, 128, 128, 128), 128, 256), ((3, 1, 128, 128, 128), 128, 256),
+                                          ((5, 2, 33, 33, 33), 24, 64), ((2, 1, 40, 24, 56), 16, 32), ((7, 1, 16, 16, 16), 8, 12)])
+@pytest.mark.parametrize("pre_scale,pad", [(0.0, 0), (50.0, 16), (0.9, 3)])
+def test_segment_forward_equals_the_per_sample_forward(shape, sph, zr, pre_scale, pad, genre, dev):
+    """same operator, two formulations: fp32 (P, S) per segment of <= 16 samples chained in fp64 against an fp64 scan over every
+    sample -- 1e-6 on maps in (0, 1]; odd geometries, several channels, odd image counts (the last workgroup holds one image)"""
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    if 2 * pad > sph:
+        pad = sph // 4
+    rng = np.random.default_rng(sum(shape) + sph)
+    vox = rng.uniform(0.0, 0.03 if pre_scale == 50.0 else 0.6, shape).astype(np.float32)
+    vox[:, :, : shape[2] // 3] = 0.0                                     # an empty slab and a saturated block
+    vox[:, :, shape[2] // 2:, shape[3] // 2:, : shape[4] // 4] = 1.0
+    vt = torch.from_numpy(vox).to(dev)
+    mod = genre.render_spherical(sph_res=sph, z_res=zr, fused=True).to(dev)
+    with torch.no_grad():
+        new = mod(vt, pre_scale=pre_scale or None, pad=pad)
+    old = _old_forward(F, mod, vt, pre_scale, pad)
+    assert new.shape == old.shape and torch.isfinite(new).all()
+    assert (new - old).abs().max().item() <= 1e-6, (new - old).abs().max().item()
+
+
+def test_segment_forward_against_the_reference_chain_on_the_host(genre, oracle, dev):
+    """configs[1]'s renderer on its stated input, against toolbox/spherical_proj.py:62-72 on CPU torch + the C oracle"""
+    from oracle.torch_oracle import RenderSphericalCPU
+    d = inputs.sphere_depth(noise_seed=2)
+    fl, cd = inputs.cam_params(1)
+    tdf, _ = oracle.back_projection_forward(d, cd, fl)
+    for vol in (np.clip((1 - 128 * tdf) * 50, 1e-5, 1 - 1e-5).astype(np.float32),
+                np.random.default_rng(5).uniform(0.001, 0.05, tdf.shape).astype(np.float32)):
+        ref = RenderSphericalCPU(oracle)(torch.from_numpy(vol))
+        with torch.no_grad():
+            out = genre.render_spherical(fused=True).to(dev)(torch.from_numpy(vol).to(dev))
+        assert (out.cpu() - ref).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_camera_cell_words_and_the_hinted_forward(n, genre, dev):
+    """Camera_back_projection_layer (dense volume, camera by value: the brick kernel) hangs one word per image and 8x8x32-voxel
+    cell on the volume it returns -- set iff a point landed in the cell -- and the segment forward copies the geometry's constants
+    for tiles none of whose cells is set instead of reading them: the same map BIT FOR BIT, words that are what the volume says,
+    a hint that dies with any write to the volume (ATen in place: version counter; raw C ABI: _loader drops it)."""
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    d = torch.from_numpy(inputs.batch_depth(n, seed=3)).to(dev)
+    layer = genre.Camera_back_projection_layer().to(dev)
+    mod = genre.render_spherical().to(dev)
+    with torch.no_grad():
+        pa = layer(d)
+        words, fill, ver, cell = pa._genre_cell_hint
+        assert pa.is_contiguous() and fill == 0.0 and ver == pa._version and cell == 80832
+        occ = (pa != fill).reshape(n, 16, 8, 16, 8, 4, 32).any(6).any(4).any(2)
+        assert torch.equal(occ, words.view(n, 16, 16, 4) != 0)
+        assert 0.01 < occ.float().mean().item() < 0.5
+        pb = pa.clone()                                                   # the same values without the words
+        for scale, pad in ((50.0, 16), (None, 0), (0.9, 4)):
+            assert torch.equal(mod(pa, pre_scale=scale, pad=pad), mod(pb, pre_scale=scale, pad=pad))
+        # written to after the producer returned it -- through ATen (version counter) ...
+        pc = layer(d)
+        pc[:, :, 3:9, 100:120, 60:64] += 0.004
+        t = F.seg_tables_for(pc.shape, dev, mod._dirs64, mod.depth_weight)
+        assert F.occupancy_hint_std(pc, t, mod._dirs64, mod.depth_weight, 50.0, None) == (None, None, 0)
+        assert torch.equal(mod(pc, pre_scale=50.0, pad=16), mod(pc.clone(), pre_scale=50.0, pad=16))
+        # ... and through the raw C ABI, as the reference's caller-allocates convention invites (cam_back_projection.py:22-25):
+        # the hinted volume is re-used as the OUTPUT of another camera forward
+        pd = layer(d)
+        assert getattr(pd, "_genre_cell_hint", None) is not None
+        d2 = torch.from_numpy(inputs.batch_depth(n, seed=99)).to(dev)
+        cam_bp_lib.back_projection_forward_const(d2, 2.2, 418.3, pd, torch.empty_like(pd), shifted=True)
+        assert getattr(pd, "_genre_cell_hint", None) is None
+        assert torch.equal(mod(pd, pre_scale=50.0, pad=16), mod(pd.clone(), pre_scale=50.0, pad=16))
+        assert not torch.equal(pd, pa)
+
+
+def test_hint_is_not_used_where_a_gradient_could_come_back_through_a_dead_tile(genre, dev):
+    """a dead tile's clamp pass words / saved state are only right when the fill value is blocked by the
+    pre_scale clamp.  Without pre_scale (or with a fill value that passes it) and a gradient wanted, the hint is ignored --
+    both layouts -- and the gradient equals the un-hinted one."""
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    assert F._hint_usable(0.0, 50.0, True) and F._hint_usable(0.0, 0.0, False)
+    assert not F._hint_usable(0.0, 0.0, True) and not F._hint_usable(1.0 / 128, 50.0, True)
+    mod = genre.render_spherical().to(dev)
+    g = torch.from_numpy(np.random.default_rng(2).standard_normal((16, 1, 128, 128)).astype(np.float32)).to(dev)
+    d = torch.from_numpy(inputs.batch_depth(16, seed=4)).to(dev)
+    for bm in (False, True):
+        layer = genre.Camera_back_projection_layer(batch_minor=bm).to(dev)
+        da, db = d.clone().requires_grad_(True), d.clone().requires_grad_(True)
+        pa, pb = layer(da), layer(db)
+        name = "_genre_brick_hint" if bm else "_genre_cell_hint"
+        assert getattr(pa, name, None) is not None
+        delattr(pb, name)
+        oa, ob = mod(pa), mod(pb)                                          # no pre_scale: raw volume, gradient everywhere
+        assert torch.equal(oa, ob)
+        oa.backward(g)
+        ob.backward(g)
+        assert torch.isfinite(da.grad).all() and da.grad.abs().max().item() > 0
+        assert (da.grad - db.grad).abs().max().item() <= 1e-6 * max(1.0, db.grad.abs().max().item())
+
+
+def test_layer_under_inference_mode_and_single_image_batch_minor(genre, dev):
+    """tensors of torch.inference_mode() have no version counter -- the layer returns them without a hint
+    instead of raising; ShiftedCameraBackProjection(batch_minor=True) on ONE image has float4-aligned rows -- the library takes
+    the brick kernel there and Python no longer insists on the leader pass's sparse cnt"""
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp.functions.cam_back_projection import ShiftedCameraBackProjection
+    mod = genre.render_spherical().to(dev)
+    for n, bm in ((16, True), (2, False)):
+        d = torch.from_numpy(inputs.batch_depth(n, seed=6)).to(dev)
+        layer = genre.Camera_back_projection_layer(batch_minor=bm).to(dev)
+        with torch.no_grad():
+            ref = mod(layer(d), pre_scale=50.0, pad=16)
+        with torch.inference_mode():
+            p = layer(d)
+            assert getattr(p, "_genre_brick_hint", None) is None and getattr(p, "_genre_cell_hint", None) is None
+            assert torch.equal(mod(p, pre_scale=50.0, pad=16), ref)
+    d1 = torch.from_numpy(inputs.batch_depth(1, seed=6)).to(dev)
+    fl, cd = torch.full((1, 1), 418.3, device=dev), torch.full((1, 1), 2.2, device=dev)
+    with torch.no_grad():
+        a = ShiftedCameraBackProjection.apply(d1, fl, cd, 128, True, (418.3, 2.2))
+        b = ShiftedCameraBackProjection.apply(d1, fl, cd, 128, False, (418.3, 2.2))
+    assert torch.equal(a, b)
+
+
+def test_backward_recomputes_what_the_forward_no_longer_saves(genre, dev):
+    """the segment forward saves nothing; genre_render_spherical_backward recomputes the raw sample values from the volume (for
+    images with a live clamp word only) -- bit-identical to the backward that read the forward's saved values"""
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    rng = np.random.default_rng(8)
+    vox = torch.from_numpy(rng.uniform(0.001, 0.019, (3, 1, 128, 128, 128)).astype(np.float32)).to(dev)
+    vox[1] = 0.0                                                         # a dead image between two live ones
+    vox[2, :, 32:64, 48:80, 16:96] = 0.9
+    mod = genre.render_spherical().to(dev)
+    lib = F._loader().render_lib
+    T = F.tables_for(vox.shape, dev, mod._dirs64, mod.z_res)
+    dirs = mod._dirs64.view(torch.float32)
+    g = torch.from_numpy(rng.standard_normal((3, 1, 160, 160)).astype(np.float32)).to(dev)
+    for scale in (50.0, 0.0):
+        live = torch.empty((3 * 513,), dtype=torch.int32, device=dev) if scale else None
+        out = torch.empty((3, 1, 160, 160), device=dev)
+        v = torch.empty((3 * 128 * 128 * 256,), device=dev)
+        lib.render_spherical_forward(vox, dirs, mod.depth_weight, out, v, T["fwd_table"], T["fwd_chunks"], T["kin"], scale, live)
+        gv = torch.full_like(vox, float("nan"))
+        scratch = torch.empty((v.numel() + 3,), device=dev)
+        lib.render_spherical_backward(vox, dirs, mod.depth_weight, g, gv, scratch, T["bwd_table"], T["bwd_chunks"], v, T["kin"],
+                                      scale, live)
+        x = vox.clone().requires_grad_(True)
+        y = mod(x, pre_scale=scale or None, pad=16)
+        assert (y - out).abs().max().item() <= 1e-6
+        y.backward(g)
+        assert torch.equal(x.grad, gv)
+        assert (torch.count_nonzero(x.grad[1]).item() == 0) == bool(scale)

@@ -1,0 +1,84 @@
+"""Host logic of the segment forward (toolbox/_seg_tables.py; csrc/sph_render_seg.hip): the tables against a brute-force
+enumeration of the samples, and the segment algebra -- (P, S) per segment chained per ray from the closed-form prefix -- against
+the reference's op sequence (toolbox/spherical_proj.py:62-72) evaluated per ray in float64.  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import genre_shapehd_amd as G
+from genre_shapehd_amd.toolbox import _seg_tables as S
+from test_tables import brute_force
+
+
+@pytest.mark.parametrize("res,sph,zr,max_seg,split", [(16, 8, 12, 4, 64), (24, 12, 32, 16, 128), (33, 10, 20, 5, 64),
+                                                      (40, 16, 64, 16, 64)])
+def test_segments_partition_the_in_volume_samples(res, sph, zr, max_seg, split):
+    mod = G.render_spherical(sph_res=sph, z_res=zr, fused=False)
+    dirs = mod._dirs64.numpy()
+    t = S.build_seg_tables(res, res, res, dirs, zr, mod.depth_weight.numpy(), max_seg=max_seg, split=split)
+    cells, inside = brute_force(res, res, res, dirs, zr)
+    RR = sph * sph
+    assert np.array_equal(inside, np.arange(zr)[None, :] >= t["kin"][:, None])
+    segs = t["segs"].astype(np.int64)
+    q, k0, L, line, brick = segs[:, 0], segs[:, 1] & 255, segs[:, 1] >> 8, segs[:, 2], segs[:, 3]
+    assert (L >= 1).all() and (L <= max_seg).all()
+    # every in-volume sample in exactly one segment; all samples of a segment have their (clamped) base corner in its brick
+    seen = np.zeros((RR, zr), int)
+    nb = -(-res // S.BRICK)
+    for i in range(len(segs)):
+        ks = np.arange(k0[i], k0[i] + L[i])
+        seen[q[i], ks] += 1
+        b = [np.clip(cells[ax][q[i], ks], 0, res - 1) // S.BRICK for ax in range(3)]
+        assert ((b[0] * nb + b[1]) * nb + b[2] == brick[i]).all()
+    assert np.array_equal(seen, inside.astype(int))
+    # scratch lines: segment s (sample order) of ray q owns line s * RR + q
+    assert len(np.unique(line)) == len(line)
+    assert np.array_equal(np.bincount(q, minlength=RR), t["ray_nseg"])
+    order = np.lexsort((k0, q))
+    s_in_ray = np.concatenate([np.arange(n) for n in t["ray_nseg"]])
+    assert np.array_equal(line[order], s_in_ray * RR + q[order])
+    assert t["smax"][0] == t["ray_nseg"].max()
+    # rows: every brick in at least one, every segment in exactly one, lengths non-increasing (lane 0 of a wave is the longest)
+    rows = t["seg_rows"]
+    assert set(rows[:, 0].tolist()) == set(range(nb ** 3))
+    covered = np.zeros(len(segs), int)
+    for b, beg, end, _ in rows:
+        covered[beg:end] += 1
+        assert (brick[beg:end] == b).all() and end - beg <= -(-split // 64) * 64
+        assert (np.diff(L[beg:end]) <= 0).all()
+    assert (covered == 1).all()
+
+
+def test_segment_algebra_reproduces_the_ray_integral():
+    res, sph, zr = 24, 12, 32
+    mod = G.render_spherical(sph_res=sph, z_res=zr, fused=False)
+    dirs = mod._dirs64.numpy()
+    dw = mod.depth_weight.numpy()
+    t = S.build_seg_tables(res, res, res, dirs, zr, dw, max_seg=5, split=64)
+    rng = np.random.default_rng(0)
+    vox = torch.from_numpy(rng.uniform(0, 1, (1, 1, res, res, res)).astype(np.float32))
+    grid = mod.grid[None]
+    p = torch.nn.functional.grid_sample(vox.permute(0, 1, 4, 3, 2), grid, mode="bilinear", padding_mode="zeros",
+                                        align_corners=True)                    # spherical_proj.py:63-65
+    p = torch.clamp(p, 1e-5, 1 - 1e-5)[0, 0].reshape(sph * sph, zr).double().numpy()
+    T = np.cumprod(np.concatenate([np.ones((sph * sph, 1)), 1 - p[:, :-1]], 1), 1)      # transmittance before sample k
+    want = (T * p * dw[None, :].astype(np.float64)).sum(1) + np.prod(1 - p, 1)          # :67-71
+    # through the tables: (P, S) per segment, chained per ray from the prefix of the samples before the volume
+    RR = sph * sph
+    ps = np.full((t["smax"][0] * RR, 2), np.nan)
+    for q, kl, line, _ in t["segs"].astype(np.int64):
+        k0, L = kl & 255, kl >> 8
+        Ts, Ss = 1.0, 0.0
+        for k in range(k0, k0 + L):
+            Ss += Ts * p[q, k] * float(dw[k])
+            Ts *= 1 - p[q, k]
+        ps[line] = (Ts, Ss)
+    got = np.empty(RR)
+    for q in range(RR):
+        Tq, Sq = t["ray_pre"][q]
+        for s in range(t["ray_nseg"][q]):
+            P, Sg = ps[s * RR + q]
+            Sq += Tq * Sg
+            Tq *= P
+        got[q] = Sq + Tq
+    assert np.abs(got - want).max() < 1e-12
