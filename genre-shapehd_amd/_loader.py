@@ -14,7 +14,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgenre_hip.so")
+# (GENRE_HIP_LIB: an A/B variant of the library, tools/build_variants.sh -- measurement only; the default is the in-tree build)
+LIB_PATH = os.environ.get("GENRE_HIP_LIB") or os.path.join(_HERE, "csrc", "libgenre_hip.so")
 ABI_VERSION = 5
 _MAX_DIMS = 5
 _F32, _I32 = 0, 1

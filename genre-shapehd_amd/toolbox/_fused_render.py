@@ -189,16 +189,18 @@ def seg_tables_for(vox_shape, device, dirs64, depth_weight):
     from . import _seg_tables
     small = vox_shape[0] * vox_shape[1] < SMALL_BATCH
     dw_hash, dw = _content_of(depth_weight)
-    key = ("seg", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], dw_hash, str(device), small)
+    key = ("seg", tuple(vox_shape[2:]), dirs64.shape[0], depth_weight.shape[0], dw_hash, str(device), small)   # (split, max_seg follow `small`)
     t = _TABLES.get(key)
     if t is None:
         d64 = dirs64.cpu().numpy()
         split = _seg_tables.SPLIT_SMALL if small else _seg_tables.SPLIT
+        max_seg = _seg_tables.MAX_SEG_SMALL if small else _seg_tables.MAX_SEG
 
         def build():
-            return _seg_tables.build_seg_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, split=split)
+            return _seg_tables.build_seg_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, max_seg=max_seg,
+                                                split=split)
         build.__module__ = _seg_tables.__name__
-        np_t = _disk_cached("seg", (tuple(vox_shape[2:]), split, _seg_tables.MAX_SEG, _seg_tables.BRICK, "r6"), [d64, dw], build)
+        np_t = _disk_cached("seg", (tuple(vox_shape[2:]), split, max_seg, _seg_tables.BRICK, "r6b"), [d64, dw], build)
         t = {"smax": int(np_t["smax"][0])}
         for k, v in np_t.items():
             if k == "smax":

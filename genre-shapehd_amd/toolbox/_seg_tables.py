@@ -15,7 +15,7 @@ operation sequence of the reference's `grid` buffer (spherical_proj.py:50-56) an
 Formats (int32 unless noted; see include/genre_hip.h, "segment renderer"):
   segs      [nseg,4]   (ray q, first sample k0 | length L << 8, scratch line, brick); grouped by row, inside a row sorted
                         by (L descending, q, k0): the 64 segments a wave marches together have (nearly) one length
-  seg_rows  [rows,4]   (brick, seg begin, seg end, 0): one workgroup each, heaviest first; bricks with more than `split`
+  seg_rows  [rows,4]   (brick, seg begin, seg end, bx | by << 10 | bz << 20): one workgroup each, heaviest first; bricks with more than `split`
                         segments are cut into several rows
   ray_nseg  [RR]       segments of every ray; segment number s (in sample order) of ray q owns scratch line s*RR + q, so that
                         the per-ray pass (lane = ray) reads 256 contiguous bytes per wave and step
@@ -23,12 +23,15 @@ Formats (int32 unless noted; see include/genre_hip.h, "segment renderer"):
   kin       [RR]       first in-volume sample of every ray
   smax      [1]        scratch lines per ray (= max(ray_nseg)): the scratch holds smax*RR (P, S) pairs per image
 """
+import os
+
 import numpy as np
 
 BRICK = 16                      # must match kBrick of csrc/sph_render.hip / sph_render_seg.hip
 MAX_SEG = 16                    # samples per segment at most (a run of n is cut into ceil(n / MAX_SEG) equal parts)
-SPLIT = 1024                    # segments per row at most ...
-SPLIT_SMALL = 256               # ... when fewer than SMALL_BATCH images have to fill 256 CUs
+MAX_SEG_SMALL = int(os.environ.get("GENRE_SEG_MAXSEG_SMALL", "16"))     # ... for batches of fewer than SMALL_BATCH images (A/B switch)
+SPLIT = int(os.environ.get("GENRE_SEG_SPLIT", "1024"))                  # segments per row at most ...
+SPLIT_SMALL = int(os.environ.get("GENRE_SEG_SPLIT_SMALL", "256"))       # ... when fewer than SMALL_BATCH images have to fill 256 CUs
 FIXED_COST = 6                  # weight of a row beyond its march steps (tile staging), in 64-segment march steps
 LO = np.float32(1e-5)           # spherical_proj.py:66
 
@@ -55,7 +58,7 @@ def sample_cells(X, Y, Z, dirs64, z_res):
 def build_seg_tables(X, Y, Z, dirs64, z_res, depth_weight, max_seg=MAX_SEG, split=SPLIT):
     R = dirs64.shape[0]
     RR = R * R
-    assert z_res <= 256 and RR < (1 << 24) and 1 <= max_seg <= 255
+    assert z_res <= 256 and RR < (1 << 24) and 1 <= max_seg <= 255 and max(X, Y, Z) <= 1023 * BRICK
     dw = np.asarray(depth_weight, np.float32).reshape(-1)
     assert dw.shape[0] == z_res
     cells, inside = sample_cells(X, Y, Z, dirs64, z_res)
@@ -112,7 +115,8 @@ def build_seg_tables(X, Y, Z, dirs64, z_res, depth_weight, max_seg=MAX_SEG, spli
         for r0 in (range(b0, b1, size) if cnt else [b0]):
             r1 = min(r0 + size, b1) if cnt else b0
             steps = int(lens[r0:r1:64].sum())                               # a wave marches its longest (= first) segment
-            rows.append((bid, r0, r1, 0, steps + FIXED_COST))
+            bxyz = (bid // (nby * nbz)) | ((bid // nbz) % nby) << 10 | (bid % nbz) << 20      # (the kernel divides nothing)
+            rows.append((bid, r0, r1, bxyz, steps + FIXED_COST))
     rows.sort(key=lambda r: -r[4])
     seg_rows = np.asarray([r[:4] for r in rows], np.int32).reshape(-1, 4)
     return dict(segs=segs, seg_rows=seg_rows, ray_nseg=ray_nseg, ray_pre=ray_pre, kin=kin,

@@ -323,14 +323,14 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  * but nothing per SAMPLE goes through memory: a lane marches one SEGMENT -- a run of consecutive samples of one ray whose base
  * voxel lies in one 16^3-voxel brick -- through the brick's tile in LDS and leaves the pair (prod(1-p), sum T p w); a per-ray
  * pass chains the pairs.  Tables (genre-shapehd_amd/toolbox/_seg_tables.py: build_seg_tables):
- *   seg_rows  int32 [rows,4]    (brick, seg begin, seg end, 0): one workgroup each; every brick in >= 1 row (an empty row stages
+ *   seg_rows  int32 [rows,4]    (brick, seg begin, seg end, bx | by << 10 | bz << 20): one workgroup each; every brick in >= 1 row (an empty row stages
  *                               its tile for the live words only)
  *   segs      int32 [nseg,4]    (ray, k0 | L << 8, scratch line, brick); inside a row sorted by L descending -- the first of every
  *                               64 consecutive segments is the longest
  *   ray_nseg  int32 [R*R]       segments per ray; segment s (sample order) of ray q owns scratch line s*R*R + q
  *   ray_pre   float64 [R*R,2] viewed as fp32 [R*R,4]: (transmittance, partial sum) of the samples before the volume
  *   ps_scratch fp32 [N*NC * smax*R*R * 2], 8-byte aligned, smax = max(ray_nseg): receives the pairs
- * Occupancy hint (both or neither): occ int32 [N*NC, ceil(X/cx), ceil(Y/cy), ceil(Z/cz)] with occ_cell = cx*10000 + cy*100 + cz --
+ * Occupancy hint (both or neither): occ int32 [N*NC, ceil(X/cx), ceil(Y/cy), ceil(Z/cz)] with occ_cell = cx*10000 + cy*100 + cz (powers of two) --
  *   word 0 <=> every voxel of that cx x cy x cz cell of that image holds the producer's fill value c (what
  *   genre_back_projection_forward_const writes for dense volumes: genre_cam_cell()) -- and ps_empty fp32 [nseg,2], table order:
  *   the pairs of every segment on the CONSTANT volume vox == c (this op's own ps_scratch on such a volume).  A tile none of whose

@@ -42,7 +42,8 @@ def test_segments_partition_the_in_volume_samples(res, sph, zr, max_seg, split):
     rows = t["seg_rows"]
     assert set(rows[:, 0].tolist()) == set(range(nb ** 3))
     covered = np.zeros(len(segs), int)
-    for b, beg, end, _ in rows:
+    for b, beg, end, packed in rows:
+        assert packed == (b // (nb * nb)) | ((b // nb) % nb) << 10 | (b % nb) << 20      # the kernel divides nothing
         covered[beg:end] += 1
         assert (brick[beg:end] == b).all() and end - beg <= -(-split // 64) * 64
         assert (np.diff(L[beg:end]) <= 0).all()

@@ -9,7 +9,7 @@ FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divid
 make -s
 mkdir -p ../../tools/variants
 OBJS=""
-for o in api cam_bp calc_prob nnd nnd_host glue sph_render sph_render_bm; do
+for o in api cam_bp calc_prob nnd nnd_host glue sph_render sph_render_seg sph_render_bm; do
   [ "$o.hip" = "$SRC" ] || OBJS="$OBJS $o.o"
 done
 for spec in "$@"; do
