@@ -1,5 +1,18 @@
 // cam_bp.hip -- depth-map / spherical-map  ->  voxel TDF back-projection for gfx950.
 //
+// DISPATCH of the camera / spherical FORWARD (forward_impl; which one a by-value call takes: genre_cam_forward_plan):
+//   entry point                                   output layout                                   kernels
+//   any camera entry (tensor or by-value camera)  dense NCXYZ, float4-aligned z rows, <= 65535    cam_brick_kernel<BYVAL, PIXELSCREEN>: ONE launch, LDS bricks,
+//                                                 images (the reference's tensors)                deterministic; optional per-cell occupancy words (by value)
+//   genre_back_projection_forward_const           anything else (image-minor volumes of the       fill1/fill2_vec4_kernel + cam_leader_kernel<H>: no atomics,
+//   (camera by value, voxels project to <= 4 px)  batch-minor renderer, odd res)                  bit-identical to the serial reference; optional brick words,
+//                                                                                                 optional sparse cnt
+//   tensor cameras                                anything else                                   fill2 + scatter_tile_kernel<false> + normalise_tile_kernel<false>
+//   spherical back-projection (K5)                any                                             fill2 + scatter_tile_kernel<true> + normalise_tile_kernel<true>
+//   GENRE_CAMBP_MODE=scatter | gather | brick     (read once per process; tests pin each)         scatter: the three launches for dense volumes too;
+//                                                                                                 gather: cam_gather_kernel (serial-order sums, opt-in)
+// BACKWARD / mask: cam_backward_kernel (K4), surface_mask_kernel (K3), sph_backward_kernel (K6): one implementation each.
+//
 // Replaces toolbox/cam_bp/cam_bp/src/back_projection_kernel.cu of the reference
 // (kernels K1-K6, wrappers :629-963).  Not a translation: the reference's
 // pipeline per forward is  zero(cnt) + zero(tdf) + add 1/res (Python)  ->
@@ -944,49 +957,60 @@ __device__ __forceinline__ double wave_sum(double v)
 // (256 per image at batch 32) made this kernel 85 us of atomic queueing around 3 us of work.
 constexpr int kBwdUnroll = 4;
 
-__global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 depth, View2 fl, View2 camdist,
-                                                               View5 cnt, View5 gin, View4 gdepth,
-                                                               View2 gcam, View2 gfl, float gscale)
+// Round 6: pixels whose depth cannot reach the grid's near plane (background: two thirds of a GenRe depth map) skip the arithmetic,
+// and the pixel -> (row, column) split is a float multiply + correction (divmod_px), not an integer division: 34.8 -> 28.5 us at
+// batch 32, back to back, either layout.  (1024-thread workgroups that take their pixels in ONE pass instead of four: 30.0 us --
+// the kernel is bound by its correctly rounded divisions and square roots at two waves per SIMD, not by the passes; the random
+// 4-byte gathers do not show either: the image-minor and the NCXYZ volume, a random and an all-zero gradient time the same.)
+template <int NT>
+__global__ __launch_bounds__(NT) void cam_backward_kernel(Dims D, View4 depth, View2 fl, View2 camdist,
+                                                           View5 cnt, View5 gin, View4 gdepth,
+                                                           View2 gcam, View2 gfl, float gscale)
 {
-    __shared__ double red[2][kBlock / 64];
-    const int img = blockIdx.y;
-    const int n = img / D.NC, c = img % D.NC;
+    __shared__ double red[2][NT / 64];
+    const int n = blockIdx.y, c = blockIdx.z;
     const int npix = D.H * D.W;
+    const float inv_w = 1.0f / (float)D.W;
     double acc_fl = 0.0, acc_cd = 0.0;
     const float f = fl.p[n * fl.s0 + c * fl.s1];
     const float cam_dist = camdist.p[n * camdist.s0 + c * camdist.s1];
+    // a point lands in the grid only if its depth along the optical axis, d cos(theta) <= d, reaches the near plane cam_dist - 1/2
+    // (a hair below it; cameras inside the cube: no screen)
+    const float d_screen = cam_dist > 0.5f ? (cam_dist - 0.5f) * (1.0f - 1e-5f) : -1.0f;
     const float *dimg = depth.p + n * depth.s0 + c * depth.s1;
     float *gdimg = gdepth.p + n * gdepth.s0 + c * gdepth.s1;
     const float *cimg = cnt.p + n * cnt.s0 + c * cnt.s1;
     const float *gimg = gin.p + n * gin.s0 + c * gin.s1;
-    for (int p0 = blockIdx.x * (kBlock * kBwdUnroll) + threadIdx.x; p0 < npix;
-         p0 += gridDim.x * (kBlock * kBwdUnroll)) {
+    for (int p0 = blockIdx.x * (NT * kBwdUnroll) + threadIdx.x; p0 < npix; p0 += gridDim.x * (NT * kBwdUnroll)) {
         float d_i[kBwdUnroll], gx[kBwdUnroll], gy[kBwdUnroll], gz[kBwdUnroll], u_h[kBwdUnroll], u_w[kBwdUnroll];
         float ptnum[kBwdUnroll], gd[kBwdUnroll];
-        int ix[kBwdUnroll], iy[kBwdUnroll], iz[kBwdUnroll];
+        int ix[kBwdUnroll], iy[kBwdUnroll], iz[kBwdUnroll], hh[kBwdUnroll], ww[kBwdUnroll];
         bool live[kBwdUnroll];
 #pragma unroll
         for (int u = 0; u < kBwdUnroll; u++) {
-            const int p = p0 + u * kBlock;
+            const int p = p0 + u * NT;
+            divmod_px(p < npix ? p : 0, D.W, inv_w, hh[u], ww[u]);
             d_i[u] = -1.0f;
-            if (p < npix) d_i[u] = dimg[(p / D.W) * depth.s2 + (p % D.W) * depth.s3];
+            if (p < npix) d_i[u] = dimg[hh[u] * depth.s2 + ww[u] * depth.s3];
         }
 #pragma unroll
         for (int u = 0; u < kBwdUnroll; u++) {
-            const int p = p0 + u * kBlock;
-            const int h = p / D.W, w = p % D.W;
-            live[u] = !(d_i[u] < 0.0f);                                 // :225
-            // camera model of :231-242 (same sequence as pixel_point<false>)
-            u_h[u] = (float)h - ((float)D.H - 1.0f) / 2.0f;
-            u_w[u] = (float)w - ((float)D.W - 1.0f) / 2.0f;
-            const float cos_theta = f / norm3(u_h[u], u_w[u], f);
-            const float d = d_i[u] * cos_theta;
-            gy[u] = -d * u_w[u] / f;
-            gz[u] = -d * u_h[u] / f;
-            gx[u] = d - cam_dist;
-            ix[u] = vox_index(gx[u], D.X); iy[u] = vox_index(gy[u], D.Y); iz[u] = vox_index(gz[u], D.Z);
-            live[u] = live[u] && in_grid(D, ix[u], iy[u], iz[u]);
+            const int h = hh[u], w = ww[u];
+            live[u] = d_i[u] >= d_screen && !(d_i[u] < 0.0f);           // :225 (and the screen: such a point is outside the grid)
+            ix[u] = iy[u] = iz[u] = 0;
             ptnum[u] = 1.0f; gd[u] = 0.0f;
+            if (live[u]) {
+                // camera model of :231-242 (same sequence as pixel_point<false>)
+                u_h[u] = (float)h - ((float)D.H - 1.0f) / 2.0f;
+                u_w[u] = (float)w - ((float)D.W - 1.0f) / 2.0f;
+                const float cos_theta = f / norm3(u_h[u], u_w[u], f);
+                const float d = d_i[u] * cos_theta;
+                gy[u] = -d * u_w[u] / f;
+                gz[u] = -d * u_h[u] / f;
+                gx[u] = d - cam_dist;
+                ix[u] = vox_index(gx[u], D.X); iy[u] = vox_index(gy[u], D.Y); iz[u] = vox_index(gz[u], D.Z);
+                live[u] = in_grid(D, ix[u], iy[u], iz[u]);
+            }
             if (live[u]) {
                 ptnum[u] = cimg[ix[u] * cnt.s2 + iy[u] * cnt.s3 + iz[u] * cnt.s4];
                 gd[u] = gimg[ix[u] * gin.s2 + iy[u] * gin.s3 + iz[u] * gin.s4];
@@ -994,7 +1018,7 @@ __global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 dept
         }
 #pragma unroll
         for (int u = 0; u < kBwdUnroll; u++) {
-            const int p = p0 + u * kBlock;
+            const int p = p0 + u * NT;
             float gd_out = 0.0f;
             if (live[u]) {
                 const float cx = centre_d(ix[u], D.X), cy = centre_d(iy[u], D.Y), cz = centre_d(iz[u], D.Z);
@@ -1006,7 +1030,7 @@ __global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 dept
                 const float qx = (gx[u] - cx) / Dn, qy = (gy[u] - cy) / Dn, qz = (gz[u] - cz) / Dn;
                 const float cos_cc = (rx * qx) + (ry * qy) + (rz * qz); // :448
                 float k = ptnum[u];
-                if (k < 1.0f) k = 1.0f;
+                if (!(k >= 1.0f)) k = 1.0f;                             // :452 max(cnt, 1); also a NaN (a sparse cnt is only defined where a point landed)
                 // gscale = 1, or -res when the incoming gradient is w.r.t. the shifted output 1 - res*tdf
                 const float g = gd[u] * gscale;
                 gd_out = -g * cos_cc / k;                               // :455
@@ -1017,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 dept
                 acc_fl += (double)((gfx + gfy + gfz) * g * d_i[u] / k);                             // :462
                 acc_cd += (double)(-qx * g / k);                                                    // :469
             }
-            if (p < npix) gdimg[(p / D.W) * gdepth.s2 + (p % D.W) * gdepth.s3] = gd_out;
+            if (p < npix) gdimg[hh[u] * gdepth.s2 + ww[u] * gdepth.s3] = gd_out;
         }
     }
     acc_fl = wave_sum(acc_fl);
@@ -1028,7 +1052,7 @@ __global__ __launch_bounds__(kBlock) void cam_backward_kernel(Dims D, View4 dept
     if (threadIdx.x == 0) {
         double a = 0.0, b = 0.0;
 #pragma unroll
-        for (int i = 0; i < kBlock / 64; i++) { a += red[0][i]; b += red[1][i]; }
+        for (int i = 0; i < NT / 64; i++) { a += red[0][i]; b += red[1][i]; }
         unsafeAtomicAdd(gfl.p + n * gfl.s0 + c * gfl.s1, (float)a);
         unsafeAtomicAdd(gcam.p + n * gcam.s0 + c * gcam.s1, (float)b);
     }
@@ -1390,7 +1414,8 @@ static int backward_impl(const char *op, const genre_tensor *depth, const genre_
     const int npix = D.H * D.W;
     if (npix == 0) return 1;
     GENRE_REQUIRE(imgs <= 65535, "%s: N*NC must be <= 65535", op);
-    int bx = ceil_div(npix, kBlock * kBwdUnroll);                       // ~512 workgroups in total (see kernel)
+    GENRE_REQUIRE(D.N <= 65535 && D.NC <= 65535, "%s: N and NC must be <= 65535", op);
+    int bx = ceil_div(npix, kBlock * kBwdUnroll);                       // ~512 workgroups in total (see the kernel)
     const int cap = imgs >= 512 ? 1 : 512 / imgs;
     if (bx > cap) bx = cap;
     float gscale = 1.0f;
@@ -1398,9 +1423,9 @@ static int backward_impl(const char *op, const genre_tensor *depth, const genre_
         GENRE_REQUIRE(D.X == D.Y && D.Y == D.Z, "%s: the fused shift needs a cubic grid", op);
         gscale = -(float)D.X;
     }
-    cam_backward_kernel<<<dim3(bx, imgs), kBlock, 0, st>>>(D, view4(depth), view2(fl), view2(camdist), view5(cnt),
-                                                          view5(grad_in), view4(grad_depth), view2(grad_camdist),
-                                                          view2(grad_fl), gscale);
+    cam_backward_kernel<kBlock><<<dim3(bx, D.N, D.NC), kBlock, 0, st>>>(D, view4(depth), view2(fl), view2(camdist), view5(cnt),
+                                                                        view5(grad_in), view4(grad_depth), view2(grad_camdist),
+                                                                        view2(grad_fl), gscale);
     GENRE_LAUNCH_CHECK("projection backward");
     return 1;
 }

@@ -663,11 +663,26 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                 const int oxe = (brick_e / (nby_e * nbz_e)) * kBrick, oye = ((brick_e / nbz_e) % nby_e) * kBrick,
                           oze = (brick_e % nbz_e) * kBrick;
                 float *gb = gvox.p + (img / D.NC) * gvox.s0 + (img % D.NC) * gvox.s1;
-                const int y = oye + (int)threadIdx.x / kBrick, z = oze + (int)threadIdx.x % kBrick;
-                if (y < D.Y && z < D.Z) {
+                // 16-byte streaming stores where the z rows allow it (dense volumes): the zeros are written once and read by another
+                // kernel much later; 268 MB at batch 32: 77 -> 5x us (4-byte plain stores before)
+                const bool v4 = gvox.s4 == 1 && ((gvox.s0 | gvox.s1 | gvox.s2 | gvox.s3) & 3) == 0 &&
+                                (reinterpret_cast<uintptr_t>(gvox.p) & 15) == 0 && oze + kBrick <= D.Z;
+                if (v4) {
+                    typedef float v4f_ __attribute__((ext_vector_type(4)));
+                    const int z4 = oze + ((int)threadIdx.x & 3) * 4, y = oye + (((int)threadIdx.x >> 2) & 15);
 #pragma unroll
-                    for (int i = 0; i < kBrick * kBrick * kBrick / kBlock; i++)
-                        if (oxe + i < D.X) gb[(oxe + i) * gvox.s2 + y * gvox.s3 + z * gvox.s4] = 0.f;
+                    for (int i = 0; i < kBrick * kBrick * kBrick / 4 / kBlock; i++) {
+                        const int x = oxe + ((int)threadIdx.x >> 6) + i * (kBlock / 64);
+                        if (x < D.X && y < D.Y)
+                            __builtin_nontemporal_store((v4f_){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f_ *>(gb + x * gvox.s2 + y * gvox.s3 + z4));
+                    }
+                } else {
+                    const int y = oye + (int)threadIdx.x / kBrick, z = oze + (int)threadIdx.x % kBrick;
+                    if (y < D.Y && z < D.Z) {
+#pragma unroll
+                        for (int i = 0; i < kBrick * kBrick * kBrick / kBlock; i++)
+                            if (oxe + i < D.X) gb[(oxe + i) * gvox.s2 + y * gvox.s3 + z * gvox.s4] = 0.f;
+                    }
                 }
             }
             return;

@@ -546,9 +546,13 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
     double *tile = lds_d;                                               // [kLinesB][32]
     int *recs = reinterpret_cast<int *>(lds_d + kLinesB * kImgs);       // [kWavesB][kMaxSeg * kRecL]
     unsigned *mlds = reinterpret_cast<unsigned *>(recs + kWavesB * kMaxSeg * kRecL);    // [kMaskThreads] clamp masks + summary words
+    // (the group word is requested beside the row, not behind it: on GenRe's own chain every group is dead, the launch is then
+    // 16 k workgroups that each wait for their first loads, write 32 KB of zeros and leave -- two per CU (LDS): the launch is
+    // bound by that turnover, i.e. by the dependent round trips in front of the stores)
+    const int g = blockIdx.y, n0 = g * kImgs;
+    const unsigned group_word = PS ? mask[(size_t)D.groups * D.X * D.Y * D.Z + g] : 1u;
     const int4 row = rows[blockIdx.x];
     if (row.w == 2) return;                                             // padding row of the XCD interleave
-    const int g = blockIdx.y, n0 = g * kImgs;
     int ox, oy, oz;
     brick_origin<PX, PY, PZ>(D, row.x, ox, oy, oz);
     if (PS) {
@@ -557,20 +561,21 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
         // its zeros and is done -- no entries, no scans, no atomics.  On GenRe's own chain (x50 of a saturated or empty
         // voxel) that is every brick; the group word behind the masks says so without reading them.
         static_assert(kMaskThreads <= kThreadsB, "one mask word per thread");
-        auto write_zeros = [&]() {                                       // this brick's voxels of all 32 images <- 0 (plain stores)
+        auto write_zeros = [&]() {                                       // this brick's voxels of all 32 images <- 0 (streaming stores)
             const bool v4 = (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
                             (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
             for (int q = threadIdx.x; q < PX * PY * PZ * (kImgs / 4); q += kThreadsB) {
                 const int line = q >> 3, n = n0 + (q & 7) * 4;
                 const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
                 if (x >= D.X || y >= D.Y || z >= D.Z) continue;
                 float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
-                if (v4 && n + 3 < D.N) *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v4 && n + 3 < D.N) __builtin_nontemporal_store((v4f_){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f_ *>(dst));
                 else
                     for (int c = 0; c < 4; c++) if (n + c < D.N) dst[c] = 0.f;
             }
         };
-        const bool group_live = mask[(size_t)D.groups * D.X * D.Y * D.Z + g] != 0u;
+        const bool group_live = group_word != 0u;
         if (!group_live) {          // nothing of this group passes the clamp: the zeros at once -- no tile to clear, no masks, no barrier
             if (row.w == 0) write_zeros();                              // (a shared brick: bm_zero_shared_kernel wrote its zeros)
             return;

@@ -1,0 +1,24 @@
+"""How profiles/pmc_targets.py orders the renderers' launches, shared by the three summarisers (summarize_rocpd.py --phases,
+pmc_traffic_table.py, pmc_sq_table.py): a kernel's dispatches, in launch order, fall into equal consecutive PHASES -- a leading
+remainder is set-up (the constants of an occupancy hint are built by rendering a constant volume once) and is dropped -- and are
+reported as "name@phase":
+  genre  GenRe's own volume as the step's layer hands it over (with its occupancy words): what the timed steps render
+  dense  the same volume without the words (segment forward only)
+  soft   a volume whose every sample passes the clamps: a gradient everywhere"""
+TWO = ("genre", "soft")
+PHASES = {
+    "seg_sample_kernel": ("genre", "dense", "soft"), "seg_combine_kernel": ("genre", "dense", "soft"),
+    "bm_sample_kernel": TWO, "bm_combine_fwd_kernel": TWO, "bm_combine_bwd_kernel": TWO, "bm_scatter_kernel": TWO,
+    "bm_zero_shared_kernel": TWO, "bm_zero_group_kernel": TWO, "render_sample_brick_group_kernel": TWO, "render_scan_bwd_kernel": TWO,
+    "render_bwd_brick_kernel": TWO, "zero_shared_bricks_kernel": TWO,
+}
+
+
+def split(name, vals):
+    """[(suffix, values)]: ("", vals) for an un-phased kernel, else one ("@phase", values) per phase"""
+    for key, phases in PHASES.items():
+        if key in name and len(vals) >= len(phases):
+            per = len(vals) // len(phases)
+            vals = vals[len(vals) - per * len(phases):]
+            return [("@" + ph, vals[i * per:(i + 1) * per]) for i, ph in enumerate(phases)]
+    return [("", vals)]

@@ -4,9 +4,13 @@ usage: python profiles/pmc_sq_table.py pass1_results.db [pass2_results.db ...] -
 Prints, for every kernel whose name contains one of the substrings, the average of every collected counter over its
 dispatches (whole device), and the wave-cycle split ACTIVE / WAIT_ANY / WAIT_INST_ANY in percent."""
 import collections
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import phases as _phases  # noqa: E402
 
 
 def read(db):
@@ -19,22 +23,13 @@ def read(db):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for name, cname, value in cur.execute(f"select kernel_name, counter_name, value from {view}{order}"):
         acc[name][cname].append(value)
-    # the renderers run in two phases in pmc_targets.py (GenRe's own volume, then the soft volume): split by dispatch order
+    # the renderers run in phases in pmc_targets.py (profiles/phases.py): split by dispatch order
     out = collections.defaultdict(dict)
     for name, counters in acc.items():
         for c, vals in counters.items():
-            if any(k in name for k in PHASED) and len(vals) >= 2:
-                half = len(vals) // 2
-                vals = vals[len(vals) - 2 * half:]                       # (odd count: the leading set-up dispatch is dropped)
-                out[name + "@genre"][c], out[name + "@soft"][c] = vals[:half], vals[half:]
-            else:
-                out[name][c] = vals
+            for tag, part in _phases.split(name, vals):
+                out[name + tag][c] = part
     return out
-
-
-PHASED = ("bm_sample_kernel", "bm_combine_fwd_kernel", "bm_combine_bwd_kernel", "bm_scatter_kernel", "bm_zero_shared_kernel",
-          "render_sample_brick_group_kernel", "render_scan_fwd_kernel", "render_scan_bwd_kernel", "render_bwd_brick_kernel",
-          "zero_shared_bricks_kernel")
 
 
 def short(name):

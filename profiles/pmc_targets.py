@@ -52,14 +52,23 @@ if TB is not None:
     out_p = torch.empty((B, 1, 160, 160), device=dev)
     gout_p = torch.randn_like(out_p)
     gvox_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
-# The two renderers are profiled in TWO PHASES (round 5): first on GenRe's own volume -- what the timed hot-path step renders;
-# the x50 clamp blocks every voxel there, the backward kernels write zeros (bench.py: kernels.render_fwd_bm / render_bwd_bm /
-# render_bwd_fused, and `roofline`) -- then on the SOFT volume (every sample passes the clamps: a gradient everywhere;
-# kernels.*_soft, `roofline_soft`).  pmc_traffic_table.py splits every renderer kernel's dispatches into the two halves
-# ("name@genre", "name@soft") by dispatch order.
+# The renderers are profiled in PHASES (profiles/phases.py): first on GenRe's own volume -- what the timed steps render, as the
+# step's layer hands it over, with its occupancy words; the x50 clamp blocks every voxel there, the backward kernels write zeros
+# (bench.py: kernels.render_fwd_fused / render_fwd_bm / render_bwd_*, and `roofline`) --, the segment forward once more on the
+# same volume WITHOUT the words (@dense), then on the SOFT volume (every sample passes the clamps: a gradient everywhere;
+# kernels.*_soft, `roofline_soft`).  The summarisers split every renderer kernel's dispatches by launch order.
 live = torch.empty((B * (1 + 512),), dtype=torch.int32, device=dev)
-proj_std = torch.empty_like(tdf)
-cam_bp_lib.back_projection_forward_shifted(d, cd, fl, proj_std, cnt)
+layer_std = G.Camera_back_projection_layer().to(dev)
+with torch.no_grad():
+    proj_std = layer_std(d)                  # dense NCXYZ, with the camera brick kernel's cell words
+S = _fused_render.seg_tables_for(proj_std.shape, dev, mod._dirs64, mod.depth_weight)
+ps_std = torch.empty((B * S["smax"] * 128 * 128 * 2,), device=dev)
+occ_std = _fused_render.occupancy_hint_std(proj_std, S, mod._dirs64, mod.depth_weight, 50.0, lib, with_grad=True)
+
+
+def seg_fwd(vol, hint):
+    lib.render_seg_forward(vol, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps_std, 50.0,
+                           live, *(occ_std if hint else (None, None, 0)))
 gsoft = torch.Generator(device="cpu").manual_seed(1)
 soft_std = ((torch.rand(tdf.shape, generator=gsoft) * 0.9 + 0.05) * 0.02).to(dev)
 soft_bm = None
@@ -67,21 +76,27 @@ if TB is not None:
     soft_bm = _fused_render.empty_batch_minor(proj_bm.shape, torch.float32, dev)
     soft_bm.copy_(soft_std)
 for _ in range(ITERS):
-    cam_bp_lib.back_projection_forward_shifted(d, cd, fl, tdf, cnt)
+    cam_bp_lib.back_projection_forward(d, cd, fl, tdf, cnt)              # (the call and the inputs of bench.py: kernels.cam_bp_fwd)
     calc_prob_lib.calc_prob_forward(p, s)
     calc_prob_lib.calc_prob_backward_fused(p, s, g, o)
     if TB is not None:
         cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True)   # image-minor volumes: fill + leader pass
+        tl_bm = _fused_render.new_brick_words(B, 128, dev)
         cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True,   # ... as the layer calls it in the step
-                                                 tile_live=_fused_render.new_brick_words(B, 128, dev), sparse_cnt=True)
-for vol_std, vol_bm in ((proj_std, proj_bm), (soft_std, soft_bm)):
+                                                 tile_live=tl_bm, sparse_cnt=True)
+for vol_std, vol_bm in ((proj_std, proj_bm), (None, None), (soft_std, soft_bm)):
+    if vol_std is None:                      # @dense: the segment forward on GenRe's volume without the occupancy words
+        for _ in range(ITERS):
+            seg_fwd(proj_std, False)
+        continue
     for _ in range(ITERS):
-        lib.render_spherical_forward(vol_std, dirs, mod.depth_weight, out, vbuf, T["fwd_table"], T["fwd_chunks"], T["kin"],
-                                     50.0, live)
+        seg_fwd(vol_std, vol_std is proj_std)
         lib.render_spherical_backward(vol_std, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"],
-                                      vbuf, T["kin"], 50.0, live)
+                                      vbuf, T["kin"], 50.0, live, T["fwd_table"], T["fwd_chunks"])
         if TB is not None:
-            words, ps_empty = (None, None) if vol_bm is soft_bm else _fused_render.occupancy_hint(proj_bm, TB, 50.0, lib)
+            if vol_bm is proj_bm:            # (the raw-ABI camera calls above dropped the layer's hint: same values, words of the last call)
+                _fused_render.attach_hint(proj_bm, tl_bm, 128)
+            words, ps_empty = (None, None) if vol_bm is soft_bm else _fused_render.occupancy_hint(proj_bm, TB, 50.0, lib, with_grad=True)
             lib.render_bm_forward(vol_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"], TB["ray_seg"],
                                   TB["ray_pre"], ps, stash, mask, 50.0, words, ps_empty)
             lib.render_bm_backward(gout_p, gvox_bm, TB["segs"], TB["ray_ptr"], TB["ray_seg"], TB["ray_pre"], TB["ent"],

@@ -21,11 +21,8 @@ WIDE_STREAMS = ("fill2_vec4_kernel", "stop_fwd_vec4_kernel", "stop_bwd_vec4_kern
 FETCH_FACTOR = 2
 
 
-# the renderers' kernels run in two phases in pmc_targets.py (GenRe's own volume, then the soft volume): the first half of a
-# kernel's dispatches becomes the row "name@genre", the second half "name@soft"
-PHASED = ("bm_sample_kernel", "bm_combine_fwd_kernel", "bm_combine_bwd_kernel", "bm_scatter_kernel", "bm_zero_shared_kernel",
-          "render_sample_brick_group_kernel", "render_scan_fwd_kernel", "render_scan_bwd_kernel", "render_bwd_brick_kernel",
-          "zero_shared_bricks_kernel")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import phases as _phases  # noqa: E402  (how pmc_targets.py orders the renderers' launches: name@genre / @dense / @soft rows)
 
 
 def per_kernel(db, counter):
@@ -41,12 +38,8 @@ def per_kernel(db, counter):
             acc[name].append(value)
     out = {}
     for name, vals in acc.items():
-        if any(k in name for k in PHASED) and len(vals) >= 2:
-            half = len(vals) // 2                 # (an odd count: the first dispatch is set-up -- the constants of the occupancy
-            vals = vals[len(vals) - 2 * half:]    #  hint are built by rendering a constant volume once -- and is dropped)
-            out[name + "@genre"], out[name + "@soft"] = vals[:half], vals[half:]
-        else:
-            out[name] = vals
+        for tag, part in _phases.split(name, vals):
+            out[name + tag] = part
     return out
 
 

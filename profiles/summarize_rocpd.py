@@ -6,12 +6,9 @@ import sqlite3
 import sys
 
 
-# the renderers' kernels run in two phases in profiles/pmc_targets.py (GenRe's own volume, then the soft volume): with --phases the
-# first half of a kernel's dispatches (by start time; a leading odd one is set-up and dropped) is reported as "name@genre", the
-# second as "name@soft" -- the rows bench.py's `roofline` (@genre) and `roofline_soft` (@soft) can be recomputed from
-PHASED = ("bm_sample_kernel", "bm_combine_fwd_kernel", "bm_combine_bwd_kernel", "bm_scatter_kernel", "bm_zero_shared_kernel",
-          "render_sample_brick_group_kernel", "render_scan_fwd_kernel", "render_scan_bwd_kernel", "render_bwd_brick_kernel",
-          "zero_shared_bricks_kernel")
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import phases as _phases  # noqa: E402  (how pmc_targets.py orders the renderers' launches: name@genre / @dense / @soft rows)
 
 
 def phase_rows(cur):
@@ -20,11 +17,7 @@ def phase_rows(cur):
         per.setdefault(name, []).append(((end - start) / 1e3, vg, sg, lds))
     rows = []
     for name, d in per.items():
-        parts = [("", d)]
-        if any(k in name for k in PHASED) and len(d) >= 2:
-            half = len(d) // 2
-            d = d[len(d) - 2 * half:]
-            parts = [("@genre ", d[:half]), ("@soft ", d[half:])]
+        parts = [(tag + " " if tag else "", dd) for tag, dd in _phases.split(name, d)]
         for tag, dd in parts:
             us = [x[0] for x in dd]
             rows.append((tag + name, len(us), sum(us), sum(us) / len(us), min(us), max(us), max(x[1] for x in dd),

@@ -21,6 +21,25 @@ def test_bench_spawns_its_own_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["value"] > 0
 
 
+def test_four_ranks_report_four_figures_and_disjoint_shards():
+    """the rank-count-dependent bookkeeping of the line beyond world size 2 -- N per-rank figures, the
+    max-over-ranks `value` no larger than the sum of them, contiguous disjoint shards of the job's N * batch items -- so that the
+    first real SCALE_*.json (rccl_ranks == N, N figures, scaling "weak") can be checked at a glance"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "1",
+                        "--batch", "7", "--stub"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["rccl_ranks"] == 4 and out["scaling"] == "weak"
+    hp = out["hot_path"]
+    assert len(hp["per_rank_shapes_per_s"]) == 4 and all(v > 0 for v in hp["per_rank_shapes_per_s"])
+    assert out["value"] <= sum(hp["per_rank_shapes_per_s"]) * (1 + 1e-9)          # whole job at the slowest rank's pace
+    assert abs(out["value"] - 4 * 7 * 5 / (out["ms_per_step"] * 5 / 1e3)) < 1e-6 * out["value"]
+    assert hp["shards"] == [[0, 7], [7, 14], [14, 21], [21, 28]]
+
+
 def _train_worker(rank, world, port, ret):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
