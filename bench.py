@@ -375,7 +375,7 @@ def kernel_table(G, dev, B):
                                          tiles_live_frac=tiles_live,
                                          kernels="bm_sample_kernel+bm_combine_fwd_kernel on GenRe's volume, %.0f %% of the tiles live "
                                                  "(occupancy words of the camera forward)" % (100 * tiles_live),
-                                         pmc=["bm_sample_kernel<true, true, 1024>@genre", "bm_combine_fwd_kernel@genre"],
+                                         pmc=["bm_sample_kernel<true, true, true, 1024>@genre", "bm_combine_fwd_kernel@genre"],
                                          src=("common.hpp", "sph_render_bm.hip"))
             rows["render_fwd_bm_nosave"] = dict(us=event_time_us(lambda: bm_fwd(False), iters, 5),
                                                 bytes=rows["render_fwd_bm"]["bytes"], kernels="the same without saved state (inference)")
@@ -412,7 +412,7 @@ def kernel_table(G, dev, B):
             rows["render_bwd_bm"]["kernels"] += " on GenRe's volume (clamp blocks every voxel: writes zeros)"
             rows["render_fwd_bm_soft"] = dict(us=event_time_us(bm_fwd_soft, iters, 5), bytes=B * BYTES_RENDER_FUSED,
                                               kernels="bm_sample_kernel+bm_combine_fwd_kernel (soft volume)",
-                                              pmc=["bm_sample_kernel<true, true, 1024>@soft", "bm_combine_fwd_kernel@soft"],
+                                              pmc=["bm_sample_kernel<true, true, false, 1024>@soft", "bm_combine_fwd_kernel@soft"],
                                               src=("common.hpp", "sph_render_bm.hip"))
             bm_fwd_soft()
             rows["render_bwd_bm_soft"] = dict(

@@ -663,8 +663,9 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                 const int oxe = (brick_e / (nby_e * nbz_e)) * kBrick, oye = ((brick_e / nbz_e) % nby_e) * kBrick,
                           oze = (brick_e % nbz_e) * kBrick;
                 float *gb = gvox.p + (img / D.NC) * gvox.s0 + (img % D.NC) * gvox.s1;
-                // 16-byte streaming stores where the z rows allow it (dense volumes): the zeros are written once and read by another
-                // kernel much later; 268 MB at batch 32: 77 -> 5x us (4-byte plain stores before)
+                // 16-byte stores where the z rows allow it (dense volumes).  PLAIN stores: a brick's z row is 64 bytes, half of a
+                // 128-byte line whose other half belongs to the next brick -- nontemporal stores (no merging in L2) measured
+                // 77 -> 96 us at batch 32
                 const bool v4 = gvox.s4 == 1 && ((gvox.s0 | gvox.s1 | gvox.s2 | gvox.s3) & 3) == 0 &&
                                 (reinterpret_cast<uintptr_t>(gvox.p) & 15) == 0 && oze + kBrick <= D.Z;
                 if (v4) {
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                     for (int i = 0; i < kBrick * kBrick * kBrick / 4 / kBlock; i++) {
                         const int x = oxe + ((int)threadIdx.x >> 6) + i * (kBlock / 64);
                         if (x < D.X && y < D.Y)
-                            __builtin_nontemporal_store((v4f_){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f_ *>(gb + x * gvox.s2 + y * gvox.s3 + z4));
+                            *reinterpret_cast<v4f_ *>(gb + x * gvox.s2 + y * gvox.s3 + z4) = (v4f_){0.f, 0.f, 0.f, 0.f};
                     }
                 } else {
                     const int y = oye + (int)threadIdx.x / kBrick, z = oze + (int)threadIdx.x % kBrick;

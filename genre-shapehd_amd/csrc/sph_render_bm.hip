@@ -57,7 +57,7 @@ constexpr int kRayRegs = 31;                             // segments of a ray th
 
 struct BmDims {
     int N, X, Y, Z, R, pad;
-    int nseg, groups, ZR;
+    int nseg, groups, ZR, nbricks;                       // nbricks: bricks of the forward's tiling (tile_live words per group)
     int64_t nslot;
     int64_t sx, sy, sz;                                  // element strides of vox (image stride == 1)
     int64_t gx, gy, gz;                                  // ... of grad_vox
@@ -80,17 +80,20 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A row's fourth word = flag (0 plain, 1 shared, 2 padding) | bx << 8 | by << 16 | bz << 24: the brick's coordinates come with the
+// row (toolbox/_bm_tables.py: _pack_coords) -- gfx950 has no integer divide, taking a brick id apart cost every workgroup three
+// ~40-instruction divisions in front of its first load
+__device__ __forceinline__ int row_flag(const int4 &row) { return row.w & 255; }
 template <int BX = kBX, int BY = kBY, int BZ = kBZ>
-__device__ __forceinline__ void brick_origin(const BmDims &D, int brick, int &ox, int &oy, int &oz)
+__device__ __forceinline__ void brick_origin(const int4 &row, int &ox, int &oy, int &oz)
 {
-    const int nby = (D.Y + BY - 1) / BY, nbz = (D.Z + BZ - 1) / BZ;
-    ox = (brick / (nby * nbz)) * BX; oy = ((brick / nbz) % nby) * BY; oz = (brick % nbz) * BZ;
+    ox = ((row.w >> 8) & 255) * BX; oy = ((row.w >> 16) & 255) * BY; oz = ((row.w >> 24) & 255) * BZ;
 }
 
 // ---- forward: brick sampler ---------------------------------------------------------------------------
 // grid = (rows, groups).  ps [group][segment][2][32] <- (P, S); stash [group][slot][32] <- clamped sample, negated
 // where the clamp does not pass the gradient; mask [group][voxel] <- bit i: image i passes the pre_scale clamp.
-template <bool PS, bool SAVE, int NT>
+template <bool PS, bool SAVE, bool HINT, int NT>
 __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__restrict__ vox,
                                                              const int4 *__restrict__ segs, const int *__restrict__ rec_f,
                                                              const int4 *__restrict__ rows, float *__restrict__ ps,
@@ -102,10 +105,39 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     float *tile = lds_f;                                               // [kLinesF][32]
     int *recs = reinterpret_cast<int *>(lds_f + kLinesF * kImgs);      // [(NT / 64)][64 lanes x 16 bytes]
     const int4 row = rows[blockIdx.x];
-    if (row.w == 2) return;                                            // padding row of the XCD interleave
+    if (row_flag(row) == 2) return;                                    // padding row of the XCD interleave
     const int g = blockIdx.y, n0 = g * kImgs;
     int ox, oy, oz;
-    brick_origin(D, row.x, ox, oy, oz);
+    brick_origin(row, ox, oy, oz);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    constexpr int NW = NT / 64;
+    // EVERYTHING THE ROW ALONE DETERMINES IS REQUESTED AT ONCE (round 6): the occupancy word of the tile, the constants of this
+    // wave's first segment (what a dead tile copies) and the headers of its first two segments (what a live tile marches) -- the
+    // workgroup's life is a chain of dependent round trips (row -> word -> headers / constants -> records, tile -> march), ~1.2 us
+    // each, and a launch is that chain times (workgroups / resident workgroups: two per CU); one link less for either kind of
+    // tile.  All of them unconditional (indices clamped into the row; HINT is a template parameter): a load that is only
+    // conditionally outstanding would cost the march loop its exact waits (below).
+    int s = row.y + wave;
+    const bool has_seg = s < row.z;
+    const int s_last = has_seg ? s + ((row.z - 1 - s) / NW) * NW : max(min(s, row.z - 1), 0);   // this wave's last segment: indices are clamped to it
+    int word = 1;
+    float4 pe0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HINT) {
+        word = tile_live[(size_t)g * D.nbricks + row.x];
+        // (through a VECTOR register: as a scalar load the four words of the constants keep four more SGPRs live across the
+        // kernel -- 84 instead of 80 -- and at 81-96 SGPRs gfx950 admits 7 waves per SIMD, not 8: ONE 16-wave workgroup per CU
+        // instead of two; measured 134 -> 167 us)
+        int pe_idx = has_seg ? s : s_last;
+        asm volatile("" : "+v"(pe_idx));
+        pe0 = ps_empty[pe_idx];
+    }
+    int4 sg = segs[has_seg ? s : s_last];
+    int4 sg1 = segs[has_seg ? min(s + NW, s_last) : s_last], rq;
+    if (HINT) {
+        // (the two headers wait in VECTOR registers while the occupancy word is decided: eight scalar registers less across the
+        // dead path -- the kernel must stay at <= 80 SGPRs, or gfx950 admits one 16-wave workgroup per CU instead of two)
+        asm volatile("" : "+v"(sg.x), "+v"(sg.y), "+v"(sg.z), "+v"(sg.w), "+v"(sg1.x), "+v"(sg1.y), "+v"(sg1.z), "+v"(sg1.w));
+    }
     // WHAT THE PRODUCER KNOWS TO BE EMPTY IS NOT READ (round 5).  The volumes this renderer sees are surfaces: a depth map
     // back-projected into 128^3 voxels leaves ~0.5 % of them occupied, and over a group of 32 images 61 % of the tiles (brick +
     // high halo) hold nothing but the producer's fill value.  tile_live [groups][bricks] (written by the camera forward's leader
@@ -113,44 +145,27 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     // every segment is a constant of the geometry: ps_empty [segment] = (P, S, the segment's scratch line), the sampler's own
     // output on the constant volume (built once per geometry by the caller: bit-identical to what the march below computes).
     // A dead workgroup copies the constants to its segments' scratch lines, clears its brick's clamp masks and is done: no
-    // tile loads (268 MB per group, mostly fill values), no records, no march.  (The whole dead path sits HERE, in front of
-    // every load of the live path and with its own loads inside it: a load that is only conditionally outstanding when the
-    // march loop is entered costs that loop its exact waits -- measured: vmcnt(1) -> vmcnt(0), +55 us.)
-    if (tile_live != nullptr) {
-        const int nb = ((D.X + kBX - 1) / kBX) * ((D.Y + kBY - 1) / kBY) * ((D.Z + kBZ - 1) / kBZ);
-        if (tile_live[(size_t)g * nb + row.x] == 0) {
-            if (PS && SAVE) {
-                for (int e = threadIdx.x; e < kBX * kBY * kBZ; e += NT) {
-                    const int x = ox + e / (kBY * kBZ), y = oy + (e / kBZ) % kBY, z = oz + e % kBZ;
-                    if (x < D.X && y < D.Y && z < D.Z) mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] = 0u;
-                }
+    // tile loads (268 MB per group, mostly fill values), no records, no march.
+    if (HINT && word == 0) {
+        if (PS && SAVE) {
+            for (int e = threadIdx.x; e < kBX * kBY * kBZ; e += NT) {
+                const int x = ox + e / (kBY * kBZ), y = oy + (e / kBZ) % kBY, z = oz + e % kBZ;
+                if (x < D.X && y < D.Y && z < D.Z) mask[(size_t)g * D.X * D.Y * D.Z + ((size_t)x * D.Y + y) * D.Z + z] = 0u;
             }
-            const int ln = threadIdx.x & 63;
-            for (int sd = row.y + (int)(threadIdx.x >> 6); sd < row.z; sd += NT / 64) {
-                const float4 pe = ps_empty[sd];
-                ps[(size_t)(g * D.nseg + __float_as_int(pe.z)) * 2 * kImgs + ln] = ln < kImgs ? pe.x : pe.y;
-            }
-            return;
         }
+        float4 pe = pe0;
+        for (int sd = s; sd < row.z; sd += NW) {
+            const int nxt = sd + NW;
+            const float4 pn = ps_empty[min(nxt, s_last)];               // (the next one is in flight while this one is stored)
+            ps[(size_t)(g * D.nseg + __float_as_int(pe.z)) * 2 * kImgs + lane] = lane < kImgs ? pe.x : pe.y;
+            pe = pn;
+        }
+        return;
     }
-    // THE FIRST SEGMENT'S HEADER AND RECORDS ARE REQUESTED BEFORE THE TILE (round 5).  A wave marches ~1.2 segments of a brick
-    // on average (315 k segments over 16 384 bricks x 16 waves), so the software pipeline of the march loop below rarely gets
-    // past its prologue, and that prologue -- header (segs) -> records (rec_f), two dependent round trips -- used to START
-    // behind the barrier that ends the tile staging: row -> tile -> barrier -> header -> records -> march, five exposed
-    // latencies per workgroup.  Issued here, in front of the tile loads (the records first, so that the ONE wait the tile
-    // values need also covers them and every later wait stays exact -- the in-order counter again), the chain is
-    // row -> header -> max(records, tile) -> barrier -> march.
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    constexpr int NW = NT / 64;
-    int s = row.y + wave;
-    const bool has_seg = s < row.z;
-    const int s_last = has_seg ? s + ((row.z - 1 - s) / NW) * NW : max(min(s, row.z - 1), 0);   // this wave's last segment: indices are clamped to it
-    int4 sg = make_int4(0, 0, 0, 0), sg1 = sg, rq = sg;
-    if (D.nseg > 0) {
-        sg = segs[has_seg ? s : s_last];
-        sg1 = segs[has_seg ? min(s + NW, s_last) : s_last];
-        rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)__builtin_amdgcn_readfirstlane(sg.w) * kRec)[lane];   // lane's 16 bytes of the records
-    }
+    // THE FIRST SEGMENT'S RECORDS ARE REQUESTED BEFORE THE TILE (round 5).  A wave marches ~1.2 segments of a brick on average
+    // (315 k segments over 16 384 bricks x 16 waves), so the software pipeline of the march loop below rarely gets past its
+    // prologue; the records first, so that the ONE wait the tile values need also covers them and every later wait stays exact.
+    rq = reinterpret_cast<const int4 *>(rec_f + (int64_t)__builtin_amdgcn_readfirstlane(sg.w) * kRec)[lane];   // lane's 16 bytes of the records
     const bool vec = (D.N & 3) == 0 && (D.sx & 3) == 0 && (D.sy & 3) == 0 && (D.sz & 3) == 0;
     // Stage the tile: thread t + 512 j takes 16 bytes (4 images) of voxel line (t + 512 j) / 8.  ALL loads of a thread are
     // issued before the first one is used -- one exposed HBM round trip per tile instead of seven.
@@ -486,9 +501,9 @@ template <int PX, int PY, int PZ>
 __global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, float *__restrict__ gvox)
 {
     const int4 row = rows[blockIdx.x];
-    if (row.w != 1) return;
+    if (row_flag(row) != 1) return;
     int ox, oy, oz;
-    brick_origin<PX, PY, PZ>(D, row.x, ox, oy, oz);
+    brick_origin<PX, PY, PZ>(row, ox, oy, oz);
     const int n0 = blockIdx.y * kImgs;
     for (int e = threadIdx.x; e < PX * PY * PZ * kImgs; e += kThreads) {
         const int line = e >> 5, n = n0 + (e & 31);
@@ -552,9 +567,10 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
     const int g = blockIdx.y, n0 = g * kImgs;
     const unsigned group_word = PS ? mask[(size_t)D.groups * D.X * D.Y * D.Z + g] : 1u;
     const int4 row = rows[blockIdx.x];
-    if (row.w == 2) return;                                             // padding row of the XCD interleave
+    if (row_flag(row) == 2) return;                                     // padding row of the XCD interleave
+    const bool shared_row = row_flag(row) == 1;
     int ox, oy, oz;
-    brick_origin<PX, PY, PZ>(D, row.x, ox, oy, oz);
+    brick_origin<PX, PY, PZ>(row, ox, oy, oz);
     if (PS) {
         // The clamp adjoint decides first.  A brick none of whose voxels passes clamp(x * pre_scale, lo, hi) in any of the 32
         // images has an identically zero gradient whatever the samples say (the flush multiplies by the mask): it writes
@@ -577,7 +593,7 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
         };
         const bool group_live = group_word != 0u;
         if (!group_live) {          // nothing of this group passes the clamp: the zeros at once -- no tile to clear, no masks, no barrier
-            if (row.w == 0) write_zeros();                              // (a shared brick: bm_zero_shared_kernel wrote its zeros)
+            if (!shared_row) write_zeros();                             // (a shared brick: bm_zero_shared_kernel wrote its zeros)
             return;
         }
         unsigned m = 0u;
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
             brick_live |= w.x | w.y | w.z | w.w;
         }
         if (!brick_live) {
-            if (row.w == 0) write_zeros();                              // (a shared brick: bm_zero_shared_kernel wrote its zeros)
+            if (!shared_row) write_zeros();                             // (a shared brick: bm_zero_shared_kernel wrote its zeros)
             return;
         }
     } else {
@@ -749,7 +765,7 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
     __syncthreads();
     // Flush: every voxel of the brick exactly once.  Four images per thread (two 16-byte LDS reads, one 16-byte store) when
     // the layout allows; rows that share their brick with other rows add atomically onto pre-zeroed voxels.
-    const bool vec4 = row.w == 0 && (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
+    const bool vec4 = !shared_row && (D.N & 3) == 0 && (D.gx & 3) == 0 && (D.gy & 3) == 0 && (D.gz & 3) == 0 &&
                       (reinterpret_cast<uintptr_t>(gvox) & 15) == 0;
     if (vec4) {
         for (int q = threadIdx.x; q < kLinesB * (kImgs / 4); q += kThreadsB) {
@@ -779,7 +795,7 @@ __global__ __launch_bounds__(kThreadsB, (PX == 4 ? (kThreadsB <= 768 ? 6 : GENRE
             float val = (float)tile[e2];
             if (PS) val = ((mlds[line] >> (e2 & 31)) & 1u) ? val * D.pre_scale : 0.f;  // adjoint of clamp(x * pre_scale, lo, hi)
             float *dst = gvox + x * D.gx + y * D.gy + z * D.gz + n;
-            if (row.w == 0) *dst = val;
+            if (!shared_row) *dst = val;
             else if (val != 0.f) unsafeAtomicAdd(dst, val);
         }
     }
@@ -876,7 +892,9 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
                       "constant volume", op);
         live_p = (const int *)tile_live->data;
         empty_p = (const float4 *)ps_empty->data;
+        D.nbricks = (int)(tile_live->size[1] * tile_live->size[2] * tile_live->size[3]);
     }
+    GENRE_REQUIRE(D.nseg >= 1, "%s: the segment table is empty", op);
     hipStream_t st = (hipStream_t)stream;
     if (save && pre_scale != 0.0f) {          // the groups' "some voxel passes the clamp" words behind the masks (set by the sampler)
         GENRE_REQUIRE(hipMemsetAsync((unsigned *)mask->data + (int64_t)D.groups * D.X * D.Y * D.Z, 0, (size_t)D.groups * 4, st) == hipSuccess,
@@ -887,16 +905,16 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
     constexpr int nt = kBY == 4 ? 512 : 1024;
     const size_t lds = (size_t)kLinesF * kImgs * 4 + (size_t)(nt / 64) * 64 * 16 + (size_t)(nt / 64) * 4;   // tile, records, wave flags
     const dim3 grid((unsigned)fwd_rows->size[0], (unsigned)D.groups);
-#define GENRE_BM_SAMPLE_NT(PSV, SV, NTV)                                                                                  \
+#define GENRE_BM_SAMPLE_NT(PSV, SV, HV, NTV)                                                                              \
     do {                                                                                                                  \
         static std::atomic<uint64_t> done_{0};                                                                            \
-        if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_sample_kernel<PSV, SV, NTV>), lds, done_)) return 0;      \
-        bm_sample_kernel<PSV, SV, NTV><<<grid, NTV, lds, st>>>(                                                           \
+        if (!reserve_lds(op, reinterpret_cast<const void *>(&bm_sample_kernel<PSV, SV, HV, NTV>), lds, done_)) return 0;  \
+        bm_sample_kernel<PSV, SV, HV, NTV><<<grid, NTV, lds, st>>>(                                                       \
             D, (const float *)vox->data, (const int4 *)segs->data, (const int *)rec_f->data, (const int4 *)fwd_rows->data, \
             (float *)ps_scratch->data, save ? (float *)p_stash->data : nullptr,                                           \
             (save && pre_scale != 0.0f) ? (unsigned *)mask->data : nullptr, live_p, empty_p);                             \
     } while (0)
-#define GENRE_BM_SAMPLE(PSV, SV) GENRE_BM_SAMPLE_NT(PSV, SV, nt)
+#define GENRE_BM_SAMPLE(PSV, SV) do { if (live_p) GENRE_BM_SAMPLE_NT(PSV, SV, true, nt); else GENRE_BM_SAMPLE_NT(PSV, SV, false, nt); } while (0)
     if (pre_scale != 0.0f) { if (save) GENRE_BM_SAMPLE(true, true); else GENRE_BM_SAMPLE(true, false); }
     else { if (save) GENRE_BM_SAMPLE(false, true); else GENRE_BM_SAMPLE(false, false); }
 #undef GENRE_BM_SAMPLE

@@ -24,7 +24,8 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
                               issue a FIXED number of loads per segment (every lane of a wave loads 16 bytes of records =
                               21.3 records from the segment's first; all 16 sample slots of a segment are fetched) so
                               that their waits on the in-order load counter can be exact; the excess is never used
-  fwd_rows  int32 [rows,4]   (brick, seg begin, seg end, flag); flag 2 = padding row (skipped); order: see _xcd_order
+  fwd_rows  int32 [rows,4]   (brick, seg begin, seg end, flag | bx << 8 | by << 16 | bz << 24); flag 2 = padding row (skipped);
+                              (bx, by, bz) = the brick's coordinates in bricks, so that the kernels divide nothing; order: see _xcd_order
   ray_ptr   int32 [RR+1], ray_seg int32 [nseg]   the segments of every ray in sample order
   ray_pre   float64 [RR,2]   (P0, S0) of the samples before the ray enters the volume (p = 1e-5 each)
   ent       int32 [E,4]      backward listing: (the segment's scratch line = ray-order position, slot of its first sample,
@@ -33,7 +34,7 @@ Formats (all little-endian 32-bit words unless noted) -- see include/genre_hip.h
   rec_b     int32 [SB,12]    (tile byte offset in the brick's own fp64 tile -- may point outside it for corners the
                               brick does not own --, ownership bits (corner c, z half h) -> bit c + 4h, 0, 0, 8 weights);
                               SB = listed samples + REC_PAD zero records (same reason as SLOT_PAD)
-  bwd_rows  int32 [rows,4]   (pull brick, ent begin, ent end, shared); shared = 1: the brick is split
+  bwd_rows  int32 [rows,4]   (pull brick, ent begin, ent end, shared | bx << 8 | by << 16 | bz << 24); shared = 1: the brick is split
                               over several rows, which add their tiles atomically onto pre-zeroed voxels.  The backward's
                               ("pull") bricks are PULL = 4x8x8 voxels like the forward's; 8x8x8 (a segment then touches fewer bricks,
                               each of which re-reads its saved samples, but only one workgroup fits a CU) measured slower
@@ -158,7 +159,7 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     sb = np.searchsorted(seg_brick_f, np.arange(nb), side="left")
     se = np.searchsorted(seg_brick_f, np.arange(nb), side="right")
     cum = np.concatenate(([0], np.cumsum(segs[:, 2].astype(np.int64))))
-    fwd_rows = _split_rows(sb, se, cum, split_f, 0)
+    fwd_rows = _pack_coords(_split_rows(sb, se, cum, split_f, 0), nbr)
 
     # ---- backward listing: every PULL brick lists the samples that touch one of its voxels ----
     assert tuple(pull) in ((4, 8, 8), (8, 8, 8))
@@ -222,11 +223,27 @@ def build_bm_tables(X, Y, Z, dirs64, z_res, depth_weight, split_f=SPLIT_F, split
     eb = np.searchsorted(ent_brick, np.arange(pnb), side="left")
     ee = np.searchsorted(ent_brick, np.arange(pnb), side="right")
     cumb = np.concatenate(([0], np.cumsum((i_last + 1 - i_first).astype(np.int64))))
-    bwd_rows = _split_rows(eb, ee, cumb, split_b, 1)
+    bwd_rows = _pack_coords(_split_rows(eb, ee, cumb, split_b, 1), pnbr)
 
     out = dict(segs=segs, rec_f=rec_f, fwd_rows=fwd_rows, ray_ptr=ray_ptr, ray_seg=ray_seg, ray_pre=ray_pre,
                ent=ent, rec_b=rec_b, bwd_rows=bwd_rows, kin=kin, pull=np.asarray(pull, np.int32))
     return out
+
+
+def _pack_coords(rows, nbr):
+    """flag | bx << 8 | by << 16 | bz << 24 in column 3: the brick's coordinates (gfx950 has no integer divide: ~40 instructions
+    each, three per workgroup to take a brick id apart)"""
+    assert max(nbr) <= 255
+    b = rows[:, 0].astype(np.int64)
+    bx, by, bz = b // (nbr[1] * nbr[2]), (b // nbr[2]) % nbr[1], b % nbr[2]
+    rows = rows.copy()
+    rows[:, 3] = (rows[:, 3].astype(np.int64) | (bx << 8) | (by << 16) | (bz << 24)).astype(np.int32)
+    return rows
+
+
+def row_flag(w):
+    """the flag of a row's fourth word (0 plain, 1 shared, SKIP padding)"""
+    return int(w) & 255
 
 
 def _split_rows(begin, end, cum, split, shared_mode):

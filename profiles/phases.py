@@ -8,7 +8,7 @@ reported as "name@phase":
 TWO = ("genre", "soft")
 PHASES = {
     "seg_sample_kernel": ("genre", "dense", "soft"), "seg_combine_kernel": ("genre", "dense", "soft"),
-    "bm_sample_kernel": TWO, "bm_combine_fwd_kernel": TWO, "bm_combine_bwd_kernel": TWO, "bm_scatter_kernel": TWO,
+    "bm_combine_fwd_kernel": TWO, "bm_combine_bwd_kernel": TWO, "bm_scatter_kernel": TWO,
     "bm_zero_shared_kernel": TWO, "bm_zero_group_kernel": TWO, "render_sample_brick_group_kernel": TWO, "render_scan_bwd_kernel": TWO,
     "render_bwd_brick_kernel": TWO, "zero_shared_bricks_kernel": TWO,
 }
@@ -16,6 +16,11 @@ PHASES = {
 
 def split(name, vals):
     """[(suffix, values)]: ("", vals) for an un-phased kernel, else one ("@phase", values) per phase"""
+    if "bm_sample_kernel<" in name:          # its HINT template argument names the phase: <PS, SAVE, HINT, NT>
+        args = name.split("bm_sample_kernel<")[1].split(">")[0].replace(" ", "").split(",")
+        if args[:2] == ["true", "true"]:
+            return [("@genre" if args[2] == "true" else "@soft", vals)]
+        return [("", vals)]
     for key, phases in PHASES.items():
         if key in name and len(vals) >= len(phases):
             per = len(vals) // len(phases)

@@ -23,7 +23,7 @@ def forward(mod, t, vox, pre_scale=0.0, lo=np.float32(1e-5), hi=np.float32(1 - 1
     mask = np.zeros(vox.shape, bool)
     corner = np.array([(c & 1) * TY * TZ + ((c >> 1) & 1) * TZ + (c >> 2) for c in range(8)])
     for brick, s0, s1, flag in t["fwd_rows"]:
-        if flag == mod.SKIP:
+        if mod.row_flag(flag) == mod.SKIP:
             continue
         ox, oy, oz = (brick // (nby * nbz)) * BX, ((brick // nbz) % nby) * BY, (brick % nbz) * BZ
         tile = np.zeros((TX, TY, TZ), np.float32)
@@ -84,6 +84,7 @@ def backward(mod, t, shape, PS, stash, mask, g, dw, pre_scale=0.0):
     corner = np.array([(c & 1) * BY * BZ + ((c >> 1) & 1) * BZ + (c >> 2) for c in range(8)])
     acc_shared = {}
     for brick, e0, e1, shared in t["bwd_rows"]:
+        shared = mod.row_flag(shared)
         if shared == mod.SKIP:
             continue
         tile = np.zeros(BX * BY * BZ)

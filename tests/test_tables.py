@@ -103,7 +103,7 @@ def test_bm_listing_names_every_touching_sample_once_per_brick(res, sph, zr, pul
             expect.setdefault((b_, q_ * zr + k_), set()).add(c)
     got = {}
     for b_, e0, e1, shared in t["bwd_rows"]:
-        if shared == B.SKIP:
+        if B.row_flag(shared) == B.SKIP:
             continue
         for s_, slot0_, pk, rs in t["ent"][e0:e1]:
             _, k0, L, slot0 = segs[t["ray_seg"][s_]]                     # s_: the segment's scratch line (ray order)
