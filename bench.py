@@ -277,9 +277,9 @@ def kernel_table(G, dev, B):
             tiles_live_std = float((t8 > 0).float().mean())
 
         def seg_fwd(vol, hint=True, lv=live):
-            render_lib.render_seg_forward(vol, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"],
+            render_lib.render_seg_forward(vol, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"],
                                           ps_std, 50.0, lv, *((occ, pe_std, cell) if hint else (None, None, 0)))
-        seg_pmc = ["seg_sample_kernel<true, false>", "seg_combine_kernel<256>"]
+        seg_pmc = ["seg_sample_kernel<true, false, true>", "seg_combine_kernel<256>"]       # (pmc_targets.py: with saved samples)
         rows["render_fwd_fused"] = dict(us=event_time_us(lambda: seg_fwd(proj), iters, 5), bytes=B * BYTES_RENDER_FUSED,
                                         bytes_needed=int(B * (tiles_live_std * 128 ** 3 * 4 + 128 * 128 * 4)),
                                         tiles_live_frac=tiles_live_std,
@@ -288,19 +288,32 @@ def kernel_table(G, dev, B):
                                         pmc=[k + "@genre" for k in seg_pmc], src=("common.hpp", "render_common.hpp", "sph_render_seg.hip"))
         rows["render_fwd_fused_dense"] = dict(us=event_time_us(lambda: seg_fwd(proj, False), iters, 5), bytes=B * BYTES_RENDER_FUSED,
                                               kernels="the same volume WITHOUT the occupancy words: every tile is read",
-                                              pmc=[k + "@dense" for k in seg_pmc], src=("common.hpp", "render_common.hpp", "sph_render_seg.hip"))
-        bwd_pmc = ["render_sample_brick_group_kernel<2, 512>", "render_scan_bwd_kernel", "zero_shared_bricks_kernel",
-                   "render_bwd_brick_kernel"]                                                  # + the phase of profiles/pmc_targets.py
-        bwd_src = ("common.hpp", "render_common.hpp", "wave_scan.hpp", "sph_render.hip")
+                                              pmc=["seg_sample_kernel<true, false, false>@dense", "seg_combine_kernel<256>@dense"],
+                                              src=("common.hpp", "render_common.hpp", "sph_render_seg.hip"))
+        bwd_pmc = ["seg_combine_bwd_kernel<256>", "seg_dp_kernel", "zero_shared_bricks_kernel", "render_bwd_brick_kernel"]
+        bwd_src = ("common.hpp", "render_common.hpp", "wave_scan.hpp", "sph_render.hip", "sph_render_seg.hip")
+        tr_std = torch.empty_like(ps_std)
+        bslot = _fused_render.bwd_slots_for(proj.shape, dev, mod._dirs64, mod.depth_weight)
+        vseg = torch.empty((B * S["segs"].shape[0] * 16,), device=dev)             # saved sample values: one 64-byte slot per segment
+        dpseg = torch.empty((B * S["segs"].shape[0] * 16 + max(4, B),), device=dev)  # dL/dp in the same layout + max|dL/dp| per image
+
+        def seg_fwd_grad(vol, hint=True):
+            # the forward as autograd runs it when a gradient is wanted: + the raw sample values of the tiles a gradient can
+            # come back through (GenRe's volume: none)
+            render_lib.render_seg_forward(vol, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"],
+                                          ps_std, 50.0, live, *((occ, pe_std, cell) if hint else (None, None, 0)), vseg)
 
         def std_bwd(vol, lv):
-            # (the segment forward saves nothing: the backward recomputes the raw sample values of the live images first)
-            render_lib.render_spherical_backward(vol, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"],
-                                                 T["bwd_chunks"], vbuf, T["kin"], 50.0, lv, T["fwd_table"], T["fwd_chunks"])
+            # segment form of the dL/dp phase (per-ray chains, dL/dp per segment), then the brick-owned accumulation
+            render_lib.render_spherical_backward(vol, dirs, mod.depth_weight, gout, gvox, dpseg, T["bwd_table"],
+                                                 T["bwd_chunks"], vseg, None, 50.0, lv, S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"],
+                                                 ps_std, tr_std, bslot)
         # GenRe's own volume: the clamp blocks every voxel, the group writes grad_vox = 0 (billed with the bytes it moves) ...
-        seg_fwd(proj)
+        rows["render_fwd_fused_grad"] = dict(us=event_time_us(lambda: seg_fwd_grad(proj), iters, 5), bytes=B * BYTES_RENDER_FUSED,
+                                             kernels="the same with a gradient wanted (GenRe's volume: no tile's samples are saved)")
+        seg_fwd_grad(proj)
         rows["render_bwd_fused"] = dict(us=event_time_us(lambda: std_bwd(proj, live), iters, 5), bytes=B * 128 ** 3 * 4,
-                                        kernels="(resample: returns at once)+render_scan_bwd_kernel+zero_shared_bricks_kernel+"
+                                        kernels="seg_combine_bwd_kernel+seg_dp_kernel (return at once)+zero_shared_bricks_kernel+"
                                                 "render_bwd_brick_kernel on GenRe's volume (clamp blocks every voxel: writes zeros)",
                                         pmc=[k + "@genre" for k in bwd_pmc], src=bwd_src)
         # ... and the same kernels where they do work: the soft volume (every sample passes the clamps)
@@ -309,12 +322,14 @@ def kernel_table(G, dev, B):
         rows["render_fwd_fused_soft"] = dict(us=event_time_us(lambda: seg_fwd(soft, False), iters, 5), bytes=B * BYTES_RENDER_FUSED,
                                              kernels="seg_sample_kernel+seg_combine_kernel (soft volume)",
                                              pmc=[k + "@soft" for k in seg_pmc], src=("common.hpp", "render_common.hpp", "sph_render_seg.hip"))
-        seg_fwd(soft, False)
+        rows["render_fwd_fused_soft_grad"] = dict(us=event_time_us(lambda: seg_fwd_grad(soft, False), iters, 5),
+                                                  bytes=B * BYTES_RENDER_FUSED,
+                                                  kernels="the same with a gradient wanted: + 4 B per sample of saved values")
+        seg_fwd_grad(soft, False)
         rows["render_bwd_fused_soft"] = dict(us=event_time_us(lambda: std_bwd(soft, live), iters, 5),
                                              bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                                             kernels="render_sample_brick_group_kernel (recomputes v)+render_scan_bwd_kernel+"
-                                                     "zero_shared_bricks_kernel+render_bwd_brick_kernel on the soft volume "
-                                                     "(gradient everywhere)",
+                                             kernels="seg_combine_bwd_kernel+seg_dp_kernel+zero_shared_bricks_kernel+"
+                                                     "render_bwd_brick_kernel on the soft volume (gradient everywhere)",
                                              pmc=[k + "@soft" for k in bwd_pmc], src=bwd_src)
         del soft
         seg_fwd(proj)

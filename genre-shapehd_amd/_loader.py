@@ -52,8 +52,8 @@ def _load():
                         ("genre_spherical_back_proj_backward_shifted", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
-                        ("genre_render_spherical_forward", 9), ("genre_render_spherical_backward", 13),
-                        ("genre_render_seg_forward", 12),
+                        ("genre_render_spherical_forward", 9), ("genre_render_spherical_backward", 18),
+                        ("genre_render_seg_forward", 14),
                         ("genre_render_bm_forward", 13), ("genre_render_bm_backward", 14),
                         ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4),
                         ("genre_nnd_forward_host", 6), ("genre_nnd_backward_host", 8)):
@@ -239,23 +239,26 @@ class _RenderLib:
     @staticmethod
     def render_spherical_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
                                   dp_scratch=None, brick_table=None, chunk_list=None, v_scratch=None, kin=None,
-                                  pre_scale=0.0, live=None, fwd_table=None, fwd_chunks=None):
+                                  pre_scale=0.0, live=None, segs=None, ray_nseg=None, ray_pre_as_f32=None, line_w=None,
+                                  ps_scratch=None, tr_scratch=None, chunk_slot=None):
         """dp_scratch/brick_table/chunk_list given: brick-owned backward (no global atomics), re-using the
         forward's v_scratch when it is passed too; without: global-atomic scatter fallback.  live: the forward's pass words --
-        what the pre_scale clamp blocks is written as zeros without being computed.  fwd_table + fwd_chunks: v_scratch is
-        scratch space, the raw sample values are recomputed from vox first (the segment forward saves nothing)"""
+        what the pre_scale clamp blocks is written as zeros without being computed.  segs ... tr_scratch: the segment form of
+        the dL/dp phase, for a forward by render_seg_forward (its tables, (P, S) pairs and saved sample values)"""
         return _call("genre_render_spherical_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                     dp_scratch, brick_table, chunk_list, v_scratch, kin, live, fwd_table, fwd_chunks,
-                     scalars=(C.c_float(pre_scale),), out=(4, 5, 8))
+                     dp_scratch, brick_table, chunk_list, v_scratch, kin, live, segs, ray_nseg, ray_pre_as_f32, line_w,
+                     ps_scratch, tr_scratch, chunk_slot, scalars=(C.c_float(pre_scale),), out=(4, 5, 16))
 
     @staticmethod
-    def render_seg_forward(vox, dirs64_as_f32, depth_weight, out, seg_rows, segs, ray_nseg, ray_pre_as_f32, ps_scratch,
-                           pre_scale=0.0, live=None, occ=None, ps_empty=None, occ_cell=0):
+    def render_seg_forward(vox, dirs64_as_f32, depth_weight, out, seg_rows, segs, ray_nseg, ray_pre_as_f32, line_w, ps_scratch,
+                           pre_scale=0.0, live=None, occ=None, ps_empty=None, occ_cell=0, v_scratch=None):
         """segment renderer, standard layout (csrc/sph_render_seg.hip; tables: toolbox/_seg_tables.py): one (P, S) pair per
         segment instead of one value per sample.  occ + ps_empty + occ_cell: the producer's occupancy words -- tiles known to
-        hold only the fill value are not read"""
+        hold only the fill value are not read.  v_scratch: a backward will follow -- the raw sample values of the tiles a gradient
+        can come back through are saved too"""
         return _call("genre_render_seg_forward", vox, dirs64_as_f32, depth_weight, out, seg_rows, segs, ray_nseg,
-                     ray_pre_as_f32, ps_scratch, live, occ, ps_empty, scalars=(C.c_float(pre_scale), C.c_int(occ_cell)), out=(3, 8, 9))
+                     ray_pre_as_f32, line_w, ps_scratch, live, occ, ps_empty, v_scratch,
+                     scalars=(C.c_float(pre_scale), C.c_int(occ_cell)), out=(3, 9, 10, 13))
 
 
     @staticmethod

@@ -37,6 +37,7 @@
 //    (pre_scale); its adjoint mask is one bit per voxel and image, written by the forward (the brick that owns the
 //    voxel), read by the backward's flush -- the volume itself is not read again.
 #include "common.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 namespace genre {
@@ -44,6 +45,16 @@ namespace {
 
 #ifndef GENRE_BM_BY
 #define GENRE_BM_BY 8                                    // 4: half bricks, 512-thread workgroups, four per CU (A/B: tools/build_variants.sh)
+#endif
+// Per-workgroup timeline of bm_sample_kernel (variant build -DGENRE_BM_TIMELINE, tools/bm_timeline.py; never in the shipped library)
+#ifdef GENRE_BM_TIMELINE
+#define GENRE_BTL_PARAM , unsigned long long *tlbuf_
+#define GENRE_BTL_ARG , tl_buf
+#define GENRE_BTL(i) do { if (tlbuf_ && threadIdx.x == 0) tlbuf_[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GENRE_BTL_PARAM
+#define GENRE_BTL_ARG
+#define GENRE_BTL(i) do {} while (0)
 #endif
 constexpr int kBX = 4, kBY = GENRE_BM_BY, kBZ = 8;       // brick (must match toolbox/_bm_tables.py: genre_bm_brick())
 constexpr int kTX = kBX + 1, kTY = kBY + 1, kTZ = kBZ + 1;
@@ -99,12 +110,13 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
                                                              const int4 *__restrict__ rows, float *__restrict__ ps,
                                                              float *__restrict__ stash, unsigned *__restrict__ mask,
                                                              const int *__restrict__ tile_live,
-                                                             const float4 *__restrict__ ps_empty)
+                                                             const float4 *__restrict__ ps_empty GENRE_BTL_PARAM)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     float *tile = lds_f;                                               // [kLinesF][32]
     int *recs = reinterpret_cast<int *>(lds_f + kLinesF * kImgs);      // [(NT / 64)][64 lanes x 16 bytes]
     const int4 row = rows[blockIdx.x];
+    GENRE_BTL(0);
     if (row_flag(row) == 2) return;                                    // padding row of the XCD interleave
     const int g = blockIdx.y, n0 = g * kImgs;
     int ox, oy, oz;
@@ -147,6 +159,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     // A dead workgroup copies the constants to its segments' scratch lines, clears its brick's clamp masks and is done: no
     // tile loads (268 MB per group, mostly fill values), no records, no march.
     if (HINT && word == 0) {
+        GENRE_BTL(1);
         if (PS && SAVE) {
             for (int e = threadIdx.x; e < kBX * kBY * kBZ; e += NT) {
                 const int x = ox + e / (kBY * kBZ), y = oy + (e / kBZ) % kBY, z = oz + e % kBZ;
@@ -160,8 +173,10 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
             ps[(size_t)(g * D.nseg + __float_as_int(pe.z)) * 2 * kImgs + lane] = lane < kImgs ? pe.x : pe.y;
             pe = pn;
         }
+        GENRE_BTL(7);
         return;
     }
+    GENRE_BTL(1);
     // THE FIRST SEGMENT'S RECORDS ARE REQUESTED BEFORE THE TILE (round 5).  A wave marches ~1.2 segments of a brick on average
     // (315 k segments over 16 384 bricks x 16 waves), so the software pipeline of the march loop below rarely gets past its
     // prologue; the records first, so that the ONE wait the tile values need also covers them and every later wait stays exact.
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
             }
         }
     }
+    GENRE_BTL(2);
     unsigned tile_bits = 0u;                                           // OR of every mask bit this thread staged (halo included)
 #pragma unroll
     for (int j = 0; j < kIter; j++) {
@@ -240,6 +256,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
         const unsigned long long hit = __ballot(tile_bits != 0u);
         if ((threadIdx.x & 63) == 0) wflags[threadIdx.x >> 6] = hit ? 1u : 0u;
     }
+    GENRE_BTL(3);
     __syncthreads();
     bool save_rt = SAVE;
     if (PS && SAVE) {
@@ -271,6 +288,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     //    issued after that load -- the saved samples of the segment just marched, a store round trip per segment and wave.
     //    A segment's saved samples (and its (P, S) pair) stay in registers and leave at the top of the NEXT segment, after
     //    the wait, so that at every wait the only operations outstanding were issued a whole march earlier.
+    GENRE_BTL(4);
     if (!has_seg) return;                                              // (header and records of the first segment: requested at the top)
     // the march, compiled twice where SAVE: with and without the stores of the saved samples (the choice is per workgroup and
     // made once, outside the loop: every wait inside stays exact)
@@ -332,6 +350,7 @@ __global__ __launch_bounds__(NT) void bm_sample_kernel(BmDims D, const float *__
     };
     if (SAVE && save_rt) march(std::true_type{});
     else march(std::false_type{});
+    GENRE_BTL(6);
 }
 
 // sph_pad (spherical_proj.py:21-28) as a fan-out of map pixel (i, j): see sph_render.hip: pad_span
@@ -905,6 +924,15 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
     constexpr int nt = kBY == 4 ? 512 : 1024;
     const size_t lds = (size_t)kLinesF * kImgs * 4 + (size_t)(nt / 64) * 64 * 16 + (size_t)(nt / 64) * 4;   // tile, records, wave flags
     const dim3 grid((unsigned)fwd_rows->size[0], (unsigned)D.groups);
+#ifdef GENRE_BM_TIMELINE
+    static unsigned long long *tl_buf = nullptr;
+    const size_t tl_n = (size_t)grid.x * grid.y * 8;
+    if (getenv("GENRE_BM_TIMELINE")) {
+        if (tl_buf) { (void)hipFree(tl_buf); tl_buf = nullptr; }
+        (void)hipMalloc(&tl_buf, tl_n * 8);
+        (void)hipMemsetAsync(tl_buf, 0, tl_n * 8, st);
+    }
+#endif
 #define GENRE_BM_SAMPLE_NT(PSV, SV, HV, NTV)                                                                              \
     do {                                                                                                                  \
         static std::atomic<uint64_t> done_{0};                                                                            \
@@ -912,7 +940,7 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
         bm_sample_kernel<PSV, SV, HV, NTV><<<grid, NTV, lds, st>>>(                                                       \
             D, (const float *)vox->data, (const int4 *)segs->data, (const int *)rec_f->data, (const int4 *)fwd_rows->data, \
             (float *)ps_scratch->data, save ? (float *)p_stash->data : nullptr,                                           \
-            (save && pre_scale != 0.0f) ? (unsigned *)mask->data : nullptr, live_p, empty_p);                             \
+            (save && pre_scale != 0.0f) ? (unsigned *)mask->data : nullptr, live_p, empty_p GENRE_BTL_ARG);               \
     } while (0)
 #define GENRE_BM_SAMPLE(PSV, SV) do { if (live_p) GENRE_BM_SAMPLE_NT(PSV, SV, true, nt); else GENRE_BM_SAMPLE_NT(PSV, SV, false, nt); } while (0)
     if (pre_scale != 0.0f) { if (save) GENRE_BM_SAMPLE(true, true); else GENRE_BM_SAMPLE(true, false); }
@@ -920,6 +948,16 @@ extern "C" int genre_render_bm_forward(const genre_tensor *vox, const genre_tens
 #undef GENRE_BM_SAMPLE
 #undef GENRE_BM_SAMPLE_NT
     GENRE_LAUNCH_CHECK("render_bm forward (bricks)");
+#ifdef GENRE_BM_TIMELINE
+    if (tl_buf && getenv("GENRE_BM_TIMELINE")) {            // dump: [grid.y][grid.x][8] stamps of the launch just made
+        (void)hipStreamSynchronize(st);
+        unsigned long long *h = (unsigned long long *)malloc(tl_n * 8);
+        (void)hipMemcpy(h, tl_buf, tl_n * 8, hipMemcpyDeviceToHost);
+        FILE *f = fopen(getenv("GENRE_BM_TIMELINE"), "wb");
+        if (f) { int hdr[4] = {(int)grid.x, (int)grid.y, 32, nt}; fwrite(hdr, 4, 4, f); fwrite(h, 8, tl_n, f); fclose(f); }
+        free(h);
+    }
+#endif
     bm_combine_fwd_kernel<<<dim3((unsigned)((D.R * D.R + 7) / 8), (unsigned)D.groups), 256, 0, st>>>(
         D, (const float *)ps_scratch->data, (const int *)ray_ptr->data, (const int *)ray_seg->data,
         (const double2 *)ray_pre->data, view4(out));

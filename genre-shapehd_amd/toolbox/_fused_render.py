@@ -4,10 +4,11 @@ grid_sample -> clamp -> CalcStopProb -> matmul -> prod -> add chain
 
 Forward : segment kernel (csrc/sph_render_seg.hip: 18^3 voxel tile staged in LDS with coalesced reads, one lane marches one
           segment of a ray through it, trilinear taps read from LDS) leaves one (P, S) pair per segment; a per-ray pass
-          chains them into the spherical map.  Nothing per sample goes through memory and nothing is saved for backward.
-Backward: the raw sample values v[ray, k] are recomputed from the volume (only for images in which some voxel passes the
-          pre_scale clamp); scan kernel v -> dL/dp[ray, k]; brick kernel accumulates the trilinear adjoint in
-          64-bit fixed-point LDS tiles and writes every voxel of grad_vox once (no global atomics).
+          chains them into the spherical map.  Nothing per sample goes through memory in a forward-only pass; when a
+          gradient is wanted the raw sample values of the tiles a gradient can come back through are saved too.
+Backward: per-ray chains over the (P, S) pairs, dL/dp[ray, k] per segment from the saved sample values; brick kernel
+          accumulates the trilinear adjoint in 64-bit fixed-point LDS tiles and writes every voxel of grad_vox once (no
+          global atomics).
 Which samples touch which brick depends only on the geometry; the lists are built once here
 with exactly the kernel's fp64/fp32 arithmetic and cached per geometry/device."""
 import numpy as np
@@ -200,7 +201,7 @@ def seg_tables_for(vox_shape, device, dirs64, depth_weight):
             return _seg_tables.build_seg_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, max_seg=max_seg,
                                                 split=split)
         build.__module__ = _seg_tables.__name__
-        np_t = _disk_cached("seg", (tuple(vox_shape[2:]), split, max_seg, _seg_tables.BRICK, "r6b"), [d64, dw], build)
+        np_t = _disk_cached("seg", (tuple(vox_shape[2:]), split, max_seg, _seg_tables.BRICK, "r6d"), [d64, dw], build)
         t = {"smax": int(np_t["smax"][0])}
         for k, v in np_t.items():
             if k == "smax":
@@ -211,6 +212,27 @@ def seg_tables_for(vox_shape, device, dirs64, depth_weight):
             t[k] = tv.to(device)
         _remember(key, t)
     return t
+
+
+def bwd_slots_for(vox_shape, device, dirs64, depth_weight):
+    """chunk_slot of the standard-layout backward's segment form: for every entry (ray, k) of the backward's sample list
+    (tables_for: bwd_chunks) the position of that sample in the per-segment slots of the saved values / of dL/dp -- segment
+    index in the segment tables' order * 16 + index inside the segment.  Built once per (geometry, table variant), cached"""
+    ts = seg_tables_for(vox_shape, device, dirs64, depth_weight)
+    if "bwd_slot" not in ts:
+        t = tables_for(vox_shape, device, dirs64, depth_weight.shape[0])
+        segs = ts["segs"].cpu().numpy().astype(np.int64)
+        z_res, rr = depth_weight.shape[0], dirs64.shape[0] * dirs64.shape[0]
+        slot_of = np.full((rr * z_res,), -1, np.int64)
+        q, k0, L = segs[:, 0], segs[:, 1] & 255, segs[:, 1] >> 8
+        for i in range(int(L.max())):
+            m = L > i
+            slot_of[q[m] * z_res + k0[m] + i] = np.nonzero(m)[0] * 16 + i
+        w = t["bwd_chunks"].cpu().numpy().view(np.uint32).astype(np.int64)
+        slots = slot_of[(w >> 8) * z_res + (w & 255)]
+        assert (slots >= 0).all(), "a listed sample lies in no segment"
+        ts["bwd_slot"] = torch.from_numpy(slots.astype(np.int32)).to(device)
+    return ts["bwd_slot"]
 
 
 def _bm_tables_module():
@@ -383,8 +405,12 @@ def occupancy_hint_std(vox, t, dirs64, depth_weight, pre_scale, lib, with_grad=F
         const = torch.full((1, 1, X, Y, Z), fill, dtype=torch.float32, device=vox.device)
         out = torch.empty((1, 1, res, res), dtype=torch.float32, device=vox.device)
         ps = torch.empty((t["smax"] * res * res * 2,), dtype=torch.float32, device=vox.device)
+        # (with a buffer for sample values: the variant whose products are rounded once per segment, as the backward wants them)
         lib.render_seg_forward(const, dirs64.view(torch.float32), depth_weight, out, t["seg_rows"], t["segs"], t["ray_nseg"],
-                               t["ray_pre"], ps, float(pre_scale))
+                               t["ray_pre"], t["line_w"], ps, float(pre_scale),
+                               live=(torch.empty((1 + (-(-X // 16)) * (-(-Y // 16)) * (-(-Z // 16)),), dtype=torch.int32,
+                                                 device=vox.device) if pre_scale else None),
+                               v_scratch=torch.empty((t["segs"].shape[0] * 16,), dtype=torch.float32, device=vox.device))
         t[key] = ps.view(-1, 2)[t["segs"][:, 2].long()].contiguous()            # [nseg, 2], table order
     return words, t[key], cell
 
@@ -448,9 +474,14 @@ class RenderSphericalFused(Function):
             ctx.live = torch.empty((imgs * (1 + nb),), dtype=torch.int32, device=vox.device)
         occ, ps_empty, cell = occupancy_hint_std(vox, t, dirs64, depth_weight, ctx.pre_scale, lib,
                                                  with_grad=bool(ctx.needs_input_grad[0]))
+        # a backward will follow: the raw sample values of the tiles a gradient can come back through (on GenRe's own chain:
+        # none) -- with the (P, S) pairs all the state the backward's segment form needs
+        v = (torch.empty((imgs * t["segs"].shape[0] * 16,), dtype=torch.float32, device=vox.device)
+             if ctx.needs_input_grad[0] else None)
         lib.render_seg_forward(vox, dirs64.view(torch.float32), depth_weight, out, t["seg_rows"], t["segs"], t["ray_nseg"],
-                               t["ray_pre"], ps, ctx.pre_scale, ctx.live, occ, ps_empty, cell)
-        ctx.save_for_backward(vox, dirs64, depth_weight)
+                               t["ray_pre"], t["line_w"], ps, ctx.pre_scale, ctx.live, occ, ps_empty, cell, v)
+        if v is not None:
+            ctx.save_for_backward(vox, dirs64, depth_weight, ps, v)
         return out
 
     @staticmethod
@@ -466,15 +497,17 @@ class RenderSphericalFused(Function):
                                    t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,
                                    ctx.pre_scale, t["pull_code"])
             return grad_vox, None, None, None, None
-        vox, dirs64, depth_weight = ctx.saved_tensors
+        vox, dirs64, depth_weight, ps, v = ctx.saved_tensors
         z_res = depth_weight.shape[0]
         t = tables_for(vox.shape, vox.device, dirs64, z_res)
+        ts = seg_tables_for(vox.shape, vox.device, dirs64, depth_weight)
         rays = vox.shape[0] * vox.shape[1] * dirs64.shape[0] * dirs64.shape[0]
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
-        # the raw sample values are recomputed from the volume here (fwd tables), for images with a live gradient only
-        v = torch.empty((rays * z_res,), dtype=torch.float32, device=vox.device)
-        scratch = torch.empty((rays * z_res + vox.shape[0] * vox.shape[1],), dtype=torch.float32, device=vox.device)
+        imgs = vox.shape[0] * vox.shape[1]
+        scratch = torch.empty((imgs * ts["segs"].shape[0] * 16 + imgs,), dtype=torch.float32, device=vox.device)
+        # segment form of the dL/dp phase (csrc/sph_render_seg.hip), then the brick-owned accumulation (csrc/sph_render.hip)
         lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,
-                                      scratch, t["bwd_table"], t["bwd_chunks"], v, t["kin"], ctx.pre_scale, ctx.live,
-                                      t["fwd_table"], t["fwd_chunks"])
+                                      scratch, t["bwd_table"], t["bwd_chunks"], v, None, ctx.pre_scale, ctx.live,
+                                      ts["segs"], ts["ray_nseg"], ts["ray_pre"], ts["line_w"], ps, torch.empty_like(ps),
+                                      bwd_slots_for(vox.shape, vox.device, dirs64, depth_weight))
         return grad_vox, None, None, None, None

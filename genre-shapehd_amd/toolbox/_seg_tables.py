@@ -13,7 +13,7 @@ operation sequence of the reference's `grid` buffer (spherical_proj.py:50-56) an
 (align_corners=True == PyTorch 0.4.1), the same sequence the kernel executes (csrc/sph_render.hip: sample_pos, locate).
 
 Formats (int32 unless noted; see include/genre_hip.h, "segment renderer"):
-  segs      [nseg,4]   (ray q, first sample k0 | length L << 8, scratch line, brick); grouped by row, inside a row sorted
+  segs      [nseg,4]   (ray q, first sample k0 | length L << 8, scratch line, bx | by << 10 | bz << 20 of its brick); grouped by row, inside a row sorted
                         by (L descending, q, k0): the 64 segments a wave marches together have (nearly) one length
   seg_rows  [rows,4]   (brick, seg begin, seg end, bx | by << 10 | bz << 20): one workgroup each, heaviest first; bricks with more than `split`
                         segments are cut into several rows
@@ -21,6 +21,7 @@ Formats (int32 unless noted; see include/genre_hip.h, "segment renderer"):
                         the per-ray pass (lane = ray) reads 256 contiguous bytes per wave and step
   ray_pre   float64 [RR,2]  (transmittance, partial sum) of the samples before the ray enters the volume (p = clamp(0) = 1e-5)
   kin       [RR]       first in-volume sample of every ray
+  line_w    float32 [smax*RR,2]  per scratch line: depth weight of its segment's first and of its last sample
   smax      [1]        scratch lines per ray (= max(ray_nseg)): the scratch holds smax*RR (P, S) pairs per image
 """
 import os
@@ -101,7 +102,9 @@ def build_seg_tables(X, Y, Z, dirs64, z_res, depth_weight, max_seg=MAX_SEG, spli
 
     # ---- rows: per brick, longest segments first; the 64 segments of a wave then share their march length ----
     order = np.lexsort((seg_k0, seg_q, -seg_len, seg_brick))
-    segs = np.stack([seg_q[order], seg_k0[order] | (seg_len[order] << 8), line[order], seg_brick[order]], 1).astype(np.int32)
+    sbr = seg_brick[order]
+    packed = (sbr // (nby * nbz)) | ((sbr // nbz) % nby) << 10 | (sbr % nbz) << 20              # (the kernels divide nothing)
+    segs = np.stack([seg_q[order], seg_k0[order] | (seg_len[order] << 8), line[order], packed], 1).astype(np.int32)
     sb = np.searchsorted(seg_brick[order], np.arange(nbx * nby * nbz), side="left")
     se = np.searchsorted(seg_brick[order], np.arange(nbx * nby * nbz), side="right")
     lens = seg_len[order]
@@ -119,5 +122,10 @@ def build_seg_tables(X, Y, Z, dirs64, z_res, depth_weight, max_seg=MAX_SEG, spli
             rows.append((bid, r0, r1, bxyz, steps + FIXED_COST))
     rows.sort(key=lambda r: -r[4])
     seg_rows = np.asarray([r[:4] for r in rows], np.int32).reshape(-1, 4)
-    return dict(segs=segs, seg_rows=seg_rows, ray_nseg=ray_nseg, ray_pre=ray_pre, kin=kin,
+    # per scratch line: the depth weights of its segment's first and last sample (the kernels keep a segment's partial sum and the
+    # chain's R relative to them: csrc/sph_render_seg.hip, seg_combine_kernel)
+    line_w = np.zeros((max(smax, 1) * RR, 2), np.float32)
+    line_w[line, 0] = dw[seg_k0]
+    line_w[line, 1] = dw[seg_k0 + seg_len - 1]
+    return dict(segs=segs, seg_rows=seg_rows, ray_nseg=ray_nseg, ray_pre=ray_pre, line_w=line_w, kin=kin,
                 smax=np.asarray([smax], np.int32))

@@ -304,9 +304,12 @@ int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *
  *    the samples are not recomputed from vox.
  *    live (optional; needs v_scratch + kin and pre_scale != 0): the forward's pass words, see above -- where the clamp
  *    blocks everything the adjoint is a select of zeros, so a non-finite upstream gradient does not reach a dead image.
- *    fwd_table + fwd_chunks (ABI 5; optional, with v_scratch + kin): the forward saved nothing (genre_render_seg_forward) --
- *    v_scratch is then plain scratch space and the raw sample values are recomputed from vox first (for the images whose live
- *    word is set, when live is given).
+ *    segs, ray_nseg, ray_pre, line_w, ps_scratch, tr_scratch, chunk_slot (ABI 5; all seven, with v_scratch): the SEGMENT form of the
+ *    dL/dp phase, for a forward by genre_render_seg_forward -- the tables of that op, the (P, S) pairs it left in ps_scratch, the
+ *    sample values it left in v_scratch (only in tiles a gradient can come back through), fp32 tr_scratch [>= numel(ps_scratch)]
+ *    (receives (g T in front, w_last - R behind) of every segment) and chunk_slot int32 [S]: for every chunk_list entry the position of
+ *    that sample in the per-segment slots, segment index (order of segs) * 16 + index inside the segment.  Per-ray chains, then
+ *    dL/dp per segment into dp_scratch (then fp32 [>= N*NC*nseg*16 + N*NC]); kin is not used.
  *  - those pointers NULL: global-atomic scatter fallback (grad_vox must be
  *    contiguous, 16-byte aligned, numel % 4 == 0). */
 int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
@@ -314,33 +317,44 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
                                     const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
                                     const genre_tensor *brick_table, const genre_tensor *chunk_list,
                                     const genre_tensor *v_scratch, const genre_tensor *kin,
-                                    const genre_tensor *live, const genre_tensor *fwd_table,
-                                    const genre_tensor *fwd_chunks, float pre_scale, void *stream);
+                                    const genre_tensor *live, const genre_tensor *segs,
+                                    const genre_tensor *ray_nseg, const genre_tensor *ray_pre,
+                                    const genre_tensor *line_w, const genre_tensor *ps_scratch,
+                                    const genre_tensor *tr_scratch, const genre_tensor *chunk_slot, float pre_scale,
+                                    void *stream);
 
 /* ---- segment renderer: the forward for the standard (NCXYZ) layout (ABI 5; csrc/sph_render_seg.hip) ----------------
  *
  * Same operator and arguments as genre_render_spherical_forward (vox, dirs, depth_weight, out, pre_scale, padded `out`, `live`),
  * but nothing per SAMPLE goes through memory: a lane marches one SEGMENT -- a run of consecutive samples of one ray whose base
- * voxel lies in one 16^3-voxel brick -- through the brick's tile in LDS and leaves the pair (prod(1-p), sum T p w); a per-ray
- * pass chains the pairs.  Tables (genre-shapehd_amd/toolbox/_seg_tables.py: build_seg_tables):
+ * voxel lies in one 16^3-voxel brick -- through the brick's tile in LDS and leaves the pair (P, S) = (prod(1-p),
+ * sum T p (w - w_first)), the sum relative to the depth weight of the segment's first sample; a per-ray pass chains the pairs in
+ * fp64 (sum T p w = S + w_first (1 - P)).  Tables (genre-shapehd_amd/toolbox/_seg_tables.py: build_seg_tables):
  *   seg_rows  int32 [rows,4]    (brick, seg begin, seg end, bx | by << 10 | bz << 20): one workgroup each; every brick in >= 1 row (an empty row stages
  *                               its tile for the live words only)
- *   segs      int32 [nseg,4]    (ray, k0 | L << 8, scratch line, brick); inside a row sorted by L descending -- the first of every
- *                               64 consecutive segments is the longest
+ *   segs      int32 [nseg,4]    (ray, k0 | L << 8, scratch line, bx | by << 10 | bz << 20 of its brick); inside a row sorted by L
+ *                               descending -- the first of every 64 consecutive segments is the longest
  *   ray_nseg  int32 [R*R]       segments per ray; segment s (sample order) of ray q owns scratch line s*R*R + q
  *   ray_pre   float64 [R*R,2] viewed as fp32 [R*R,4]: (transmittance, partial sum) of the samples before the volume
+ *   line_w    fp32 [smax*R*R,2] per scratch line: depth_weight of its segment's first and of its last sample
  *   ps_scratch fp32 [N*NC * smax*R*R * 2], 8-byte aligned, smax = max(ray_nseg): receives the pairs
  * Occupancy hint (both or neither): occ int32 [N*NC, ceil(X/cx), ceil(Y/cy), ceil(Z/cz)] with occ_cell = cx*10000 + cy*100 + cz (powers of two) --
  *   word 0 <=> every voxel of that cx x cy x cz cell of that image holds the producer's fill value c (what
  *   genre_back_projection_forward_const writes for dense volumes: genre_cam_cell()) -- and ps_empty fp32 [nseg,2], table order:
  *   the pairs of every segment on the CONSTANT volume vox == c (this op's own ps_scratch on such a volume).  A tile none of whose
  *   cells is occupied is not read: its segments get the constants.  The caller guarantees that vox still is what the producer
- *   wrote and, when it passes `live`, that c * pre_scale does not pass the clamp. */
+ *   wrote and, when it passes `live`, that c * pre_scale does not pass the clamp.
+ * v_scratch (optional; with pre_scale != 0 also pass `live`): fp32 [>= N*NC*nseg*16], 16-byte aligned, one 64-byte slot per image
+ *   and segment (table order) -- a backward will follow: receives the raw (un-clamped) values of the samples of every segment of
+ *   every tile some voxel of which passes the pre_scale clamp (every tile when pre_scale == 0): what
+ *   genre_render_spherical_backward's segment form reads.  ps_scratch is the other half of the saved state.  (`live` then
+ *   carries two bits per brick: bit 0 a voxel of the brick passes, bit 1 a voxel of its tile does = its values were saved.) */
 int genre_render_seg_forward(const genre_tensor *vox, const genre_tensor *dirs, const genre_tensor *depth_weight,
                              const genre_tensor *out, const genre_tensor *seg_rows, const genre_tensor *segs,
-                             const genre_tensor *ray_nseg, const genre_tensor *ray_pre, const genre_tensor *ps_scratch,
-                             const genre_tensor *live, const genre_tensor *occ, const genre_tensor *ps_empty,
-                             float pre_scale, int occ_cell, void *stream);
+                             const genre_tensor *ray_nseg, const genre_tensor *ray_pre, const genre_tensor *line_w,
+                             const genre_tensor *ps_scratch, const genre_tensor *live, const genre_tensor *occ,
+                             const genre_tensor *ps_empty,
+                             const genre_tensor *v_scratch, float pre_scale, int occ_cell, void *stream);
 
 /* ---- batch-minor tile renderer (extension; csrc/sph_render_bm.hip) ------------------------------
  *

@@ -7,9 +7,9 @@ reported as "name@phase":
   soft   a volume whose every sample passes the clamps: a gradient everywhere"""
 TWO = ("genre", "soft")
 PHASES = {
-    "seg_sample_kernel": ("genre", "dense", "soft"), "seg_combine_kernel": ("genre", "dense", "soft"),
+    "seg_combine_kernel": ("genre", "dense", "soft"),
     "bm_combine_fwd_kernel": TWO, "bm_combine_bwd_kernel": TWO, "bm_scatter_kernel": TWO,
-    "bm_zero_shared_kernel": TWO, "bm_zero_group_kernel": TWO, "render_sample_brick_group_kernel": TWO, "render_scan_bwd_kernel": TWO,
+    "bm_zero_shared_kernel": TWO, "seg_combine_bwd_kernel": TWO, "seg_dp_kernel": TWO,
     "render_bwd_brick_kernel": TWO, "zero_shared_bricks_kernel": TWO,
 }
 
@@ -21,6 +21,13 @@ def split(name, vals):
         if args[:2] == ["true", "true"]:
             return [("@genre" if args[2] == "true" else "@soft", vals)]
         return [("", vals)]
+    if "seg_sample_kernel<" in name:         # <VEC, SPEC, SAVE_V>: pmc_targets.py saves sample values in the genre and soft phases
+        args = name.split("seg_sample_kernel<")[1].split(">")[0].replace(" ", "").split(",")
+        if args[2] == "true":
+            per = len(vals) // 2
+            vals = vals[len(vals) - 2 * per:]
+            return [("@genre", vals[:per]), ("@soft", vals[per:])]
+        return [("@dense", vals[1:] if len(vals) > 1 else vals)]        # (the first: the constant volume of the occupancy hint)
     for key, phases in PHASES.items():
         if key in name and len(vals) >= len(phases):
             per = len(vals) // len(phases)

@@ -66,9 +66,15 @@ ps_std = torch.empty((B * S["smax"] * 128 * 128 * 2,), device=dev)
 occ_std = _fused_render.occupancy_hint_std(proj_std, S, mod._dirs64, mod.depth_weight, 50.0, lib, with_grad=True)
 
 
-def seg_fwd(vol, hint):
-    lib.render_seg_forward(vol, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps_std, 50.0,
-                           live, *(occ_std if hint else (None, None, 0)))
+tr_std = torch.empty_like(ps_std)
+vseg = torch.empty((B * S["segs"].shape[0] * 16,), device=dev)
+dpseg = torch.empty((B * S["segs"].shape[0] * 16 + max(4, B),), device=dev)
+bslot = _fused_render.bwd_slots_for(proj_std.shape, dev, mod._dirs64, mod.depth_weight)
+
+
+def seg_fwd(vol, hint, save=True):
+    lib.render_seg_forward(vol, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps_std, 50.0,
+                           live, *(occ_std if hint else (None, None, 0)), vseg if save else None)
 gsoft = torch.Generator(device="cpu").manual_seed(1)
 soft_std = ((torch.rand(tdf.shape, generator=gsoft) * 0.9 + 0.05) * 0.02).to(dev)
 soft_bm = None
@@ -87,12 +93,12 @@ for _ in range(ITERS):
 for vol_std, vol_bm in ((proj_std, proj_bm), (None, None), (soft_std, soft_bm)):
     if vol_std is None:                      # @dense: the segment forward on GenRe's volume without the occupancy words
         for _ in range(ITERS):
-            seg_fwd(proj_std, False)
+            seg_fwd(proj_std, False, save=False)
         continue
     for _ in range(ITERS):
         seg_fwd(vol_std, vol_std is proj_std)
-        lib.render_spherical_backward(vol_std, dirs, mod.depth_weight, gout, gvox, scratch, T["bwd_table"], T["bwd_chunks"],
-                                      vbuf, T["kin"], 50.0, live, T["fwd_table"], T["fwd_chunks"])
+        lib.render_spherical_backward(vol_std, dirs, mod.depth_weight, gout, gvox, dpseg, T["bwd_table"], T["bwd_chunks"],
+                                      vseg, None, 50.0, live, S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps_std, tr_std, bslot)
         if TB is not None:
             if vol_bm is proj_bm:            # (the raw-ABI camera calls above dropped the layer's hint: same values, words of the last call)
                 _fused_render.attach_hint(proj_bm, tl_bm, 128)

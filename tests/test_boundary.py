@@ -138,22 +138,26 @@ def test_validation_errors_do_not_launch(genre):
     odd = desc((1, 1, 126, 126, 126))
     assert lib.genre_cam_forward_plan(C.byref(odd), C.byref(odd), 2.2, 418.3) == 2       # rows not float4-aligned
     # ... and the segment forward's arguments: the occupancy pair, its cell grid, the scratch size
-    lib.genre_render_seg_forward.argtypes = [C.c_void_p] * 12 + [C.c_float, C.c_int, C.c_void_p]
+    lib.genre_render_seg_forward.argtypes = [C.c_void_p] * 14 + [C.c_float, C.c_int, C.c_void_p]
     srow, sseg, rn = desc((1, 4), 1), desc((10, 4), 1), desc((64,), 1)
-    sargs = [C.byref(a) for a in (v16, dirs, dw, desc((1, 1, 8, 8)), srow, sseg, rn, desc((64, 4)))]
-    rc = lib.genre_render_seg_forward(*sargs, C.byref(desc((100,))), None, None, None, 0.0, 0, None)
+    sargs = [C.byref(a) for a in (v16, dirs, dw, desc((1, 1, 8, 8)), srow, sseg, rn, desc((64, 4)), desc((3 * 64, 2)))]
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(desc((100,))), None, None, None, None, 0.0, 0, None)
     assert rc == 0 and b"ps_scratch" in lib.genre_last_error()                          # not a multiple of 2 * R*R
     pss = desc((3 * 64 * 2,))
-    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, C.byref(desc((1, 2, 2, 1), 1)), None, 0.0, 80832, None)
+    rc = lib.genre_render_seg_forward(*sargs[:-1], C.byref(desc((2 * 64, 2))), C.byref(pss), None, None, None, None, 0.0, 0, None)
+    assert rc == 0 and b"line_w" in lib.genre_last_error()                              # one pair per scratch line
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, C.byref(desc((1, 2, 2, 1), 1)), None, None, 0.0, 80832, None)
     assert rc == 0 and b"come together" in lib.genre_last_error()
-    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, C.byref(desc((1, 2, 2, 2), 1)), C.byref(desc((10, 2))),
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, C.byref(desc((1, 2, 2, 2), 1)), C.byref(desc((10, 2))), None,
                                       0.0, 80832, None)
     assert rc == 0 and b"occ must be" in lib.genre_last_error()                         # 16^3 voxels in 8x8x32 cells: [1,2,2,1]
-    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, C.byref(desc((1, 2, 2, 1), 1)), C.byref(desc((9, 2))),
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, C.byref(desc((1, 2, 2, 1), 1)), C.byref(desc((9, 2))), None,
                                       0.0, 80832, None)
     assert rc == 0 and b"ps_empty" in lib.genre_last_error()
-    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), C.byref(desc((1,), 1)), None, None, 50.0, 0, None)
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), C.byref(desc((1,), 1)), None, None, None, 50.0, 0, None)
     assert rc == 0 and b"live" in lib.genre_last_error()
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, None, None, C.byref(desc((10 * 16,))), 50.0, 0, None)
+    assert rc == 0 and b"v_scratch with pre_scale" in lib.genre_last_error()            # saved samples need the live words
     # empty problems succeed without launching anything
     e = desc((0, 1, 8, 8))
     ev = desc((0, 1, 4, 4, 4))

@@ -263,9 +263,14 @@ def test_standard_layout_backward_skips_what_the_clamp_blocks(genre, dev):
     assert torch.equal(lv[:, 0] != 0, passes.any(-1)) and lv[:, 0].tolist() == [0, 1, 1, 0, 1]
     assert (~passes[1]).sum().item() >= 2 * 2 * 5                       # image 1 has dead bricks (its saturated block)
     # ... and through autograd (RenderSphericalFused allocates the words when a gradient is wanted)
+    # (round 6: autograd runs the segment forward and the segment form of the dL/dp phase, csrc/sph_render_seg.hip -- fp32 scans
+    # per segment chained in fp64 instead of fp64 scans per ray: the same gradient to 1e-5 of its scale, the same zeros)
     x = vox.clone().requires_grad_(True)
     mod(x, pre_scale=50.0, pad=16).backward(g)
-    assert torch.equal(x.grad, grads[0])
+    assert (x.grad - grads[0]).abs().max().item() <= 1e-5 * max(1.0, grads[0].abs().max().item())
+    assert torch.count_nonzero(x.grad[[0, 3]]).item() == 0                # what the clamp blocks: exact zeros, not small numbers
+    dead = ~passes.view(n, 8, 8, 8)[:, :, None, :, None, :, None].expand(n, 8, 16, 8, 16, 8, 16).reshape(n, 1, 128, 128, 128).to(dev)
+    assert torch.count_nonzero(x.grad[dead]).item() == 0                  # ... brick by brick
 
 
 @pytest.mark.parametrize("n", [32, 19, 40])

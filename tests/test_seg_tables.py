@@ -20,11 +20,12 @@ def test_segments_partition_the_in_volume_samples(res, sph, zr, max_seg, split):
     RR = sph * sph
     assert np.array_equal(inside, np.arange(zr)[None, :] >= t["kin"][:, None])
     segs = t["segs"].astype(np.int64)
-    q, k0, L, line, brick = segs[:, 0], segs[:, 1] & 255, segs[:, 1] >> 8, segs[:, 2], segs[:, 3]
+    q, k0, L, line = segs[:, 0], segs[:, 1] & 255, segs[:, 1] >> 8, segs[:, 2]
+    nb = -(-res // S.BRICK)
+    brick = ((segs[:, 3] & 1023) * nb + ((segs[:, 3] >> 10) & 1023)) * nb + (segs[:, 3] >> 20)      # column 3: bx | by << 10 | bz << 20
     assert (L >= 1).all() and (L <= max_seg).all()
     # every in-volume sample in exactly one segment; all samples of a segment have their (clamped) base corner in its brick
     seen = np.zeros((RR, zr), int)
-    nb = -(-res // S.BRICK)
     for i in range(len(segs)):
         ks = np.arange(k0[i], k0[i] + L[i])
         seen[q[i], ks] += 1
@@ -38,6 +39,10 @@ def test_segments_partition_the_in_volume_samples(res, sph, zr, max_seg, split):
     s_in_ray = np.concatenate([np.arange(n) for n in t["ray_nseg"]])
     assert np.array_equal(line[order], s_in_ray * RR + q[order])
     assert t["smax"][0] == t["ray_nseg"].max()
+    # per scratch line: the depth weights of its segment's first and last sample
+    dwn = mod.depth_weight.numpy()
+    assert t["line_w"].shape == (t["smax"][0] * RR, 2)
+    assert np.array_equal(t["line_w"][line, 0], dwn[k0]) and np.array_equal(t["line_w"][line, 1], dwn[k0 + L - 1])
     # rows: every brick in at least one, every segment in exactly one, lengths non-increasing (lane 0 of a wave is the longest)
     rows = t["seg_rows"]
     assert set(rows[:, 0].tolist()) == set(range(nb ** 3))
@@ -64,22 +69,33 @@ def test_segment_algebra_reproduces_the_ray_integral():
     p = torch.clamp(p, 1e-5, 1 - 1e-5)[0, 0].reshape(sph * sph, zr).double().numpy()
     T = np.cumprod(np.concatenate([np.ones((sph * sph, 1)), 1 - p[:, :-1]], 1), 1)      # transmittance before sample k
     want = (T * p * dw[None, :].astype(np.float64)).sum(1) + np.prod(1 - p, 1)          # :67-71
-    # through the tables: (P, S) per segment, chained per ray from the prefix of the samples before the volume
+    # through the tables, as the kernels do it: (P, S) per segment with S relative to the depth weight of the segment's first
+    # sample (line_w), chained per ray from the prefix of the samples before the volume
     RR = sph * sph
     ps = np.full((t["smax"][0] * RR, 2), np.nan)
     for q, kl, line, _ in t["segs"].astype(np.int64):
         k0, L = kl & 255, kl >> 8
         Ts, Ss = 1.0, 0.0
         for k in range(k0, k0 + L):
-            Ss += Ts * p[q, k] * float(dw[k])
+            Ss += Ts * p[q, k] * (float(dw[k]) - float(dw[k0]))
             Ts *= 1 - p[q, k]
         ps[line] = (Ts, Ss)
     got = np.empty(RR)
+    R_front = np.empty(RR)
     for q in range(RR):
         Tq, Sq = t["ray_pre"][q]
-        for s in range(t["ray_nseg"][q]):
+        n = t["ray_nseg"][q]
+        for s in range(n):
             P, Sg = ps[s * RR + q]
-            Sq += Tq * Sg
+            Sq += Tq * (Sg + float(t["line_w"][s * RR + q, 0]) * (1 - P))
             Tq *= P
         got[q] = Sq + Tq
+        R = 1.0                                                          # the backward's chain: R in front of every segment
+        for s in range(n - 1, -1, -1):
+            P, Sg = ps[s * RR + q]
+            wf = float(t["line_w"][s * RR + q, 0])
+            R = wf + Sg + P * (R - wf)
+        R_front[q] = R
     assert np.abs(got - want).max() < 1e-12
+    # R in front of the first in-volume sample = (the ray's value - what the samples before the volume contribute) / T there
+    assert np.abs(R_front - (want - t["ray_pre"][:, 1]) / t["ray_pre"][:, 0]).max() < 1e-10

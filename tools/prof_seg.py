@@ -27,10 +27,10 @@ for B in [int(w) for w in which]:
         soft = (torch.rand(proj.shape, device=dev) * 0.9 + 0.05) * 0.02
 
         def hint():
-            lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps, 50.0, None, occ, pe, cell)
+            lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, 50.0, None, occ, pe, cell)
 
         def dense():
-            lib.render_seg_forward(soft, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps, 50.0)
+            lib.render_seg_forward(soft, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, 50.0)
 
         def chain():
             mod(layer(d), pre_scale=50.0, pad=16)

@@ -30,10 +30,10 @@ path = "/tmp/seg_tl.bin"
 for name, args in (("hint", (occ, pe, cell)), ("dense", (None, None, 0))):
     os.environ.pop("GENRE_SEG_TIMELINE", None)
     for _ in range(5):
-        lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps, 50.0, None, *args)
+        lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, 50.0, None, *args)
     torch.cuda.synchronize()
     os.environ["GENRE_SEG_TIMELINE"] = path
-    lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps, 50.0, None, *args)
+    lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, 50.0, None, *args)
     torch.cuda.synchronize()
     raw = np.fromfile(path, dtype=np.uint8)
     gx, gy, g_, nt = np.frombuffer(raw[:16], np.int32)

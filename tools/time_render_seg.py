@@ -64,10 +64,10 @@ for B in (1, 8, 32):
     r["old_genre"] = tm(lambda: lib.render_spherical_forward(proj, dirs, mod.depth_weight, out, v, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0, live))
     r["old_soft"] = tm(lambda: lib.render_spherical_forward(soft, dirs, mod.depth_weight, out, v, T["fwd_table"], T["fwd_chunks"], T["kin"], 50.0, live))
     for cfg in (("default", None),):
-        r["seg_genre_hint"] = tm(lambda: lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps, 50.0, live, occ, pe, cell))
-        r["seg_genre_hint_nolive"] = tm(lambda: lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps, 50.0, None, occ, pe, cell))
-        r["seg_genre_dense"] = tm(lambda: lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps, 50.0, live))
-        r["seg_soft"] = tm(lambda: lib.render_seg_forward(soft, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], ps, 50.0, live))
+        r["seg_genre_hint"] = tm(lambda: lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, 50.0, live, occ, pe, cell))
+        r["seg_genre_hint_nolive"] = tm(lambda: lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, 50.0, None, occ, pe, cell))
+        r["seg_genre_dense"] = tm(lambda: lib.render_seg_forward(proj, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, 50.0, live))
+        r["seg_soft"] = tm(lambda: lib.render_seg_forward(soft, dirs, mod.depth_weight, out, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, 50.0, live))
     r["tiles_occupied_cells_frac"] = float((occ != 0).float().mean()) if occ is not None else None
     r["cfg"] = os.environ.get("GENRE_SEG_CFG", "default")
     res["batch%d" % B] = r
