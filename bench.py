@@ -290,12 +290,11 @@ def kernel_table(G, dev, B):
                                               kernels="the same volume WITHOUT the occupancy words: every tile is read",
                                               pmc=["seg_sample_kernel<true, false, false>@dense", "seg_combine_kernel<256>@dense"],
                                               src=("common.hpp", "render_common.hpp", "sph_render_seg.hip"))
-        bwd_pmc = ["seg_combine_bwd_kernel<256>", "seg_dp_kernel", "zero_shared_bricks_kernel", "render_bwd_brick_kernel"]
-        bwd_src = ("common.hpp", "render_common.hpp", "wave_scan.hpp", "sph_render.hip", "sph_render_seg.hip")
-        tr_std = torch.empty_like(ps_std)
-        bslot = _fused_render.bwd_slots_for(proj.shape, dev, mod._dirs64, mod.depth_weight)
+        bwd_pmc = ["seg_combine_bwd_kernel<256>", "seg_scatter_kernel"]
+        bwd_src = ("common.hpp", "render_common.hpp", "sph_render_seg.hip")
+        tr_std = _fused_render.seg_tr_scratch(ps_std, proj, mod._dirs64)
+        halo_std = _fused_render.seg_halo_scratch(S, proj)
         vseg = torch.empty((B * S["segs"].shape[0] * 16,), device=dev)             # saved sample values: one 64-byte slot per segment
-        dpseg = torch.empty((B * S["segs"].shape[0] * 16 + max(4, B),), device=dev)  # dL/dp in the same layout + max|dL/dp| per image
 
         def seg_fwd_grad(vol, hint=True):
             # the forward as autograd runs it when a gradient is wanted: + the raw sample values of the tiles a gradient can
@@ -304,17 +303,16 @@ def kernel_table(G, dev, B):
                                           ps_std, 50.0, live, *((occ, pe_std, cell) if hint else (None, None, 0)), vseg)
 
         def std_bwd(vol, lv):
-            # segment form of the dL/dp phase (per-ray chains, dL/dp per segment), then the brick-owned accumulation
-            render_lib.render_spherical_backward(vol, dirs, mod.depth_weight, gout, gvox, dpseg, T["bwd_table"],
-                                                 T["bwd_chunks"], vseg, None, 50.0, lv, S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"],
-                                                 ps_std, tr_std, bslot)
+            # per-ray chains, then one pass over the segments (dL/dp from the saved values, scattered into the bricks' tiles)
+            render_lib.render_seg_backward(vol, dirs, mod.depth_weight, gout, gvox, S["bwd_rows"], S["segs"], S["ray_nseg"],
+                                           S["ray_pre"], S["line_w"], ps_std, tr_std, vseg, halo_std, 50.0, lv)
         # GenRe's own volume: the clamp blocks every voxel, the group writes grad_vox = 0 (billed with the bytes it moves) ...
         rows["render_fwd_fused_grad"] = dict(us=event_time_us(lambda: seg_fwd_grad(proj), iters, 5), bytes=B * BYTES_RENDER_FUSED,
                                              kernels="the same with a gradient wanted (GenRe's volume: no tile's samples are saved)")
         seg_fwd_grad(proj)
         rows["render_bwd_fused"] = dict(us=event_time_us(lambda: std_bwd(proj, live), iters, 5), bytes=B * 128 ** 3 * 4,
-                                        kernels="seg_combine_bwd_kernel+seg_dp_kernel (return at once)+zero_shared_bricks_kernel+"
-                                                "render_bwd_brick_kernel on GenRe's volume (clamp blocks every voxel: writes zeros)",
+                                        kernels="memset + seg_combine_bwd_kernel + seg_scatter_kernel (both return at once) on GenRe's "
+                                                "volume (the clamp blocks every voxel: grad_vox = 0)",
                                         pmc=[k + "@genre" for k in bwd_pmc], src=bwd_src)
         # ... and the same kernels where they do work: the soft volume (every sample passes the clamps)
         gs = torch.Generator(device="cpu").manual_seed(1)
@@ -328,8 +326,8 @@ def kernel_table(G, dev, B):
         seg_fwd_grad(soft, False)
         rows["render_bwd_fused_soft"] = dict(us=event_time_us(lambda: std_bwd(soft, live), iters, 5),
                                              bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                                             kernels="seg_combine_bwd_kernel+seg_dp_kernel+zero_shared_bricks_kernel+"
-                                                     "render_bwd_brick_kernel on the soft volume (gradient everywhere)",
+                                             kernels="memset + seg_combine_bwd_kernel + seg_scatter_kernel on the soft volume "
+                                                     "(gradient everywhere)",
                                              pmc=[k + "@soft" for k in bwd_pmc], src=bwd_src)
         del soft
         seg_fwd(proj)

@@ -40,7 +40,7 @@ def _load():
         raise ImportError("libgenre_hip.so ABI %d != expected %d -- rebuild" % (lib.genre_abi_version(), ABI_VERSION))
     T, V = C.POINTER(GenreTensor), C.c_void_p
     scalars = {"genre_render_spherical_forward": [C.c_float], "genre_render_spherical_backward": [C.c_float],
-               "genre_render_seg_forward": [C.c_float, C.c_int],
+               "genre_render_seg_forward": [C.c_float, C.c_int], "genre_render_seg_backward": [C.c_float],
                "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float, C.c_int],
                "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float],
                "genre_back_projection_forward_const": [C.c_float, C.c_float, C.c_int]}
@@ -52,7 +52,8 @@ def _load():
                         ("genre_spherical_back_proj_backward_shifted", 5), ("genre_calc_prob_forward", 2),
                         ("genre_calc_prob_backward", 3), ("genre_calc_prob_backward_fused", 4),
                         ("genre_nnd_forward", 6), ("genre_nnd_backward", 8),
-                        ("genre_render_spherical_forward", 9), ("genre_render_spherical_backward", 18),
+                        ("genre_render_spherical_forward", 9), ("genre_render_spherical_backward", 11),
+                        ("genre_render_seg_backward", 15),
                         ("genre_render_seg_forward", 14),
                         ("genre_render_bm_forward", 13), ("genre_render_bm_backward", 14),
                         ("genre_abs_depth_forward", 4), ("genre_abs_depth_backward", 4),
@@ -239,15 +240,12 @@ class _RenderLib:
     @staticmethod
     def render_spherical_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
                                   dp_scratch=None, brick_table=None, chunk_list=None, v_scratch=None, kin=None,
-                                  pre_scale=0.0, live=None, segs=None, ray_nseg=None, ray_pre_as_f32=None, line_w=None,
-                                  ps_scratch=None, tr_scratch=None, chunk_slot=None):
+                                  pre_scale=0.0, live=None):
         """dp_scratch/brick_table/chunk_list given: brick-owned backward (no global atomics), re-using the
         forward's v_scratch when it is passed too; without: global-atomic scatter fallback.  live: the forward's pass words --
-        what the pre_scale clamp blocks is written as zeros without being computed.  segs ... tr_scratch: the segment form of
-        the dL/dp phase, for a forward by render_seg_forward (its tables, (P, S) pairs and saved sample values)"""
+        what the pre_scale clamp blocks is written as zeros without being computed"""
         return _call("genre_render_spherical_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox,
-                     dp_scratch, brick_table, chunk_list, v_scratch, kin, live, segs, ray_nseg, ray_pre_as_f32, line_w,
-                     ps_scratch, tr_scratch, chunk_slot, scalars=(C.c_float(pre_scale),), out=(4, 5, 16))
+                     dp_scratch, brick_table, chunk_list, v_scratch, kin, live, scalars=(C.c_float(pre_scale),), out=(4, 5))
 
     @staticmethod
     def render_seg_forward(vox, dirs64_as_f32, depth_weight, out, seg_rows, segs, ray_nseg, ray_pre_as_f32, line_w, ps_scratch,
@@ -259,6 +257,15 @@ class _RenderLib:
         return _call("genre_render_seg_forward", vox, dirs64_as_f32, depth_weight, out, seg_rows, segs, ray_nseg,
                      ray_pre_as_f32, line_w, ps_scratch, live, occ, ps_empty, v_scratch,
                      scalars=(C.c_float(pre_scale), C.c_int(occ_cell)), out=(3, 9, 10, 13))
+
+    @staticmethod
+    def render_seg_backward(vox, dirs64_as_f32, depth_weight, grad_out, grad_vox, bwd_rows, segs, ray_nseg, ray_pre_as_f32,
+                            line_w, ps_scratch, tr_scratch, v_scratch, halo_scratch, pre_scale=0.0, live=None):
+        """the backward of render_seg_forward from the state it left (ps_scratch, v_scratch, live): per-ray chains, then one
+        pass over the segments that scatters dL/dp times the trilinear weights into the bricks' tiles"""
+        return _call("genre_render_seg_backward", vox, dirs64_as_f32, depth_weight, grad_out, grad_vox, bwd_rows, segs,
+                     ray_nseg, ray_pre_as_f32, line_w, ps_scratch, tr_scratch, v_scratch, halo_scratch, live,
+                     scalars=(C.c_float(pre_scale),), out=(4, 11, 13))
 
 
     @staticmethod

@@ -9,13 +9,6 @@
 
 namespace genre {
 
-// csrc/sph_render_seg.hip: the dL/dp phase of the standard-layout backward in segment form (per-ray chains + per-segment scans),
-// called by genre_render_spherical_backward (csrc/sph_render.hip) in front of its brick kernel
-int seg_backward_dlp(const char *op, const genre_tensor *vox, const genre_tensor *dirs, const genre_tensor *depth_weight,
-                     const genre_tensor *grad_out, const genre_tensor *segs, const genre_tensor *ray_nseg,
-                     const genre_tensor *ray_pre, const genre_tensor *line_w, const genre_tensor *ps_scratch,
-                     const genre_tensor *tr_scratch, const genre_tensor *v_scratch, float *dp, unsigned *dpmax, const int *live, float pre_scale, hipStream_t st);
-
 namespace {
 
 constexpr int kBrick = 16;                       // brick edge (voxels)

@@ -627,8 +627,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
                                                                    const int *__restrict__ brick_table,
                                                                    const int *__restrict__ chunk_list,
                                                                    const unsigned *__restrict__ dpmax_bits, View5 vox,
-                                                                   View5 gvox, const int *__restrict__ live,
-                                                                   const int *__restrict__ chunk_slot, int64_t dp_img_stride)
+                                                                   View5 gvox, const int *__restrict__ live)
 {
     __shared__ unsigned long long tile[kBrick * kBrick * kBrick];
     // XCD-aware order: workgroups go to the 8 XCDs round-robin by linear id; when the image count allows it, all rows
@@ -696,20 +695,18 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
     const int ox = bx * kBrick, oy = by * kBrick, oz = bz * kBrick;
     for (int t = threadIdx.x; t < kBrick * kBrick * kBrick; t += kBlock) tile[t] = 0ull;
     __syncthreads();
-    // dL/dp of this image: [ray][k] (per-sample forward), or one 16-float slot per segment named by chunk_slot (segment form)
-    const float *__restrict__ dpi = dpbuf + (int64_t)img * dp_img_stride;
+    const float *__restrict__ dpi = dpbuf + (int64_t)img * D.R * D.R * D.ZR;
     // One lane per listed sample, eight samples per thread in flight (4: +15 us, 16: +100 us): list words first
     // (coalesced), then the dependent dL/dp loads of all of them (64-byte runs: entries are sorted by ray, then
     // sample), then the work.
     constexpr int kInFlight = 8;
     for (int e0 = begin + threadIdx.x; e0 < end; e0 += kInFlight * kBlock) {
-        unsigned ent[kInFlight], slot[kInFlight];
+        unsigned ent[kInFlight];
         float dp[kInFlight];
 #pragma unroll
         for (int u = 0; u < kInFlight; u++) {
             const int e = e0 + u * kBlock;
             ent[u] = e < end ? (unsigned)chunk_list[e] : 0xffffffffu;
-            slot[u] = (chunk_slot != nullptr && e < end) ? (unsigned)chunk_slot[e] : 0u;
         }
         double d2[kInFlight][3];
 #pragma unroll
@@ -717,7 +714,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_brick_kernel(RenderDims D, 
             const bool ok = ent[u] != 0xffffffffu;
             const int q = ok ? (int)(ent[u] >> 8) : 0;
             // one image's samples fit 32 bits (R*R < 2^24, ZR <= 256): unsigned index from the image's base
-            dp[u] = ok ? dpi[chunk_slot != nullptr ? slot[u] : (unsigned)q * (unsigned)D.ZR + (ent[u] & 255u)] : 0.f;
+            dp[u] = ok ? dpi[(unsigned)q * (unsigned)D.ZR + (ent[u] & 255u)] : 0.f;
             d2[u][0] = dirs[q * 3 + 0]; d2[u][1] = dirs[q * 3 + 1]; d2[u][2] = dirs[q * 3 + 2];
         }
 #pragma unroll
@@ -945,17 +942,13 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
                                                const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
                                                const genre_tensor *brick_table, const genre_tensor *chunk_list,
                                                const genre_tensor *v_scratch, const genre_tensor *kin,
-                                               const genre_tensor *live, const genre_tensor *segs,
-                                               const genre_tensor *ray_nseg, const genre_tensor *ray_pre,
-                                               const genre_tensor *line_w, const genre_tensor *ps_scratch,
-                                               const genre_tensor *tr_scratch, const genre_tensor *chunk_slot, float pre_scale,
-                                               void *stream)
+                                               const genre_tensor *live, float pre_scale, void *stream)
 {
     const char *op = "render_spherical_backward";
     RenderDims D{};
     if (!check_render(op, vox, dirs, depth_weight, grad_out, D)) return 0;
     D.pre_scale = pre_scale;
-    GENRE_REQUIRE(pre_scale == 0.0f || (brick_table && chunk_list && dp_scratch && v_scratch && (kin || segs)),
+    GENRE_REQUIRE(pre_scale == 0.0f || (brick_table && chunk_list && dp_scratch && v_scratch && kin),
                   "%s: pre_scale needs the brick path with the forward's v_scratch", op);
     GENRE_REQUIRE(is_f32(grad_vox, 5) && same_shape(grad_vox, vox), "%s: grad_vox must have the shape of vox", op);
     GENRE_REQUIRE(D.ZR <= 256, "%s: fused backward supports z_res <= 256", op);
@@ -968,33 +961,18 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
         if (!check_tables(op, D, brick_table, chunk_list, rows)) return 0;
         const int nb = ((D.X + kBrick - 1) / kBrick) * ((D.Y + kBrick - 1) / kBrick) * ((D.Z + kBrick - 1) / kBrick);
         const int imgs = D.N * D.NC;
-        // dL/dp per image: [ray][k], or -- segment form -- one 16-float slot per segment (chunk_slot names every listed sample's)
-        GENRE_REQUIRE((segs != nullptr) == (chunk_slot != nullptr), "%s: segs and chunk_slot come together (segment form)", op);
-        if (chunk_slot != nullptr)
-            GENRE_REQUIRE(is_i32(chunk_slot, 1) && is_contiguous(chunk_slot) && chunk_slot->size[0] == chunk_list->size[0] &&
-                              is_i32(segs, 2) && segs->size[1] == 4,
-                          "%s: chunk_slot must be int32 [S], one slot index per chunk_list entry", op);
-        const int64_t dp_img = chunk_slot ? (int64_t)segs->size[0] * 16 : (int64_t)D.R * D.R * D.ZR;
-        GENRE_REQUIRE(is_f32(dp_scratch, 1) && is_contiguous(dp_scratch) && dp_scratch->size[0] >= imgs * dp_img + imgs &&
-                          aligned16(dp_scratch->data) && dp_img < ((int64_t)1 << 31),
-                      "%s: dp_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= N*NC * (R*R*ZR, or nseg*16 in the "
-                      "segment form) + N*NC elements", op);
-        unsigned *dpmax = (unsigned *)dp_scratch->data + imgs * dp_img;     // per-image max|dL/dp| behind the samples
+        GENRE_REQUIRE(is_f32(dp_scratch, 1) && is_contiguous(dp_scratch) && dp_scratch->size[0] >= rays * D.ZR + imgs &&
+                          aligned16(dp_scratch->data),
+                      "%s: dp_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= rays*ZR + N*NC elements", op);
+        unsigned *dpmax = (unsigned *)dp_scratch->data + rays * D.ZR;       // per-image max|dL/dp| behind the samples
         const int *live_p = nullptr;                                        // the forward's clamp pass words (pre_scale only)
-        if (live != nullptr && pre_scale != 0.0f && v_scratch && (kin || segs)) {
+        if (live != nullptr && pre_scale != 0.0f && v_scratch && kin) {
             GENRE_REQUIRE(is_i32(live, 1) && is_contiguous(live) && live->size[0] >= (int64_t)imgs * (nb + 1),
                           "%s: live must be the forward's int32 [N*NC*(1 + bricks)] buffer", op);
             live_p = (const int *)live->data;
         }
         if (hipMemsetAsync(dpmax, 0, (size_t)imgs * 4, st) != hipSuccess) return fail("%s: hipMemsetAsync failed", op);
-        if (rays > 0 && segs != nullptr) {
-            // SEGMENT FORM (round 6; the forward was genre_render_seg_forward): per-ray chains over the forward's (P, S) pairs, then
-            // dL/dp per segment from the sample values the forward saved where a gradient can come back (csrc/sph_render_seg.hip)
-            GENRE_REQUIRE(v_scratch && ray_nseg && ray_pre && line_w && ps_scratch && tr_scratch,
-                          "%s: the segment form needs v_scratch, ray_nseg, ray_pre, line_w, ps_scratch and tr_scratch", op);
-            if (!seg_backward_dlp(op, vox, dirs, depth_weight, grad_out, segs, ray_nseg, ray_pre, line_w, ps_scratch, tr_scratch, v_scratch,
-                                  (float *)dp_scratch->data, dpmax, live_p, pre_scale, st)) return 0;
-        } else if (rays > 0 && v_scratch && kin) {          // the per-sample forward left the raw value of EVERY sample: scan only
+        if (rays > 0 && v_scratch && kin) {          // the per-sample forward left the raw value of EVERY sample: scan only
             GENRE_REQUIRE((D.ZR & 3) == 0, "%s: brick path needs ZR %% 4 == 0", op);
             GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && v_scratch->size[0] >= rays * D.ZR &&
                               aligned16(v_scratch->data),
@@ -1022,8 +1000,7 @@ extern "C" int genre_render_spherical_backward(const genre_tensor *vox, const ge
         // the dL/dp gathers and the LDS atomics, not by the shared geometry arithmetic)
         render_bwd_brick_kernel<<<dim3(rows, D.N * D.NC), kBlock, 0, st>>>(
             D, (const double *)dirs->data, (const float *)dp_scratch->data, (const int *)brick_table->data,
-            (const int *)chunk_list->data, dpmax, view5(vox), view5(grad_vox), live_p,
-            chunk_slot ? (const int *)chunk_slot->data : nullptr, dp_img);
+            (const int *)chunk_list->data, dpmax, view5(vox), view5(grad_vox), live_p);
         GENRE_LAUNCH_CHECK("render_spherical backward (bricks)");
         return 1;
     }

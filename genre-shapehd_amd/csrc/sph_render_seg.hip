@@ -22,8 +22,8 @@
 //    is occupied is not read: on the constant tile every segment's (P, S) is a constant of the geometry (`ps_empty`, this
 //    kernel's own output on the constant volume, built once per geometry by the caller -- bit-identical to what the march
 //    would compute), which the workgroup copies to its segments' lines.
-//  * What the backward needs is NOT saved: genre_render_spherical_backward recomputes the raw sample values from the volume
-//    (images in which no voxel passes the pre_scale clamp -- every image of GenRe's own chain -- are skipped there: `live` words).
+//  * With a gradient wanted (v_scratch) the raw sample values are saved too, one 64-byte slot per segment, in the tiles a gradient
+//    can come back through (none on GenRe's own chain: `live` words); genre_render_seg_backward (below) needs nothing else.
 //
 // What the kernel is bound by (per-workgroup timelines, tools/seg_timeline.py; profiles/r06_ab_experiments.txt): a workgroup lives
 // 9-13 us -- kernel arguments 0.9, occupancy words 1.4, segment entries 1.0, tile + directions 1.6 (each one dependent memory
@@ -64,7 +64,7 @@ constexpr int kSegSlot = 16;                                             // samp
 // occupancy words have answered -- one dependent round trip (1.4 us of a batch-1 forward) less for a live tile; a dead tile's
 // loads are wasted, which is what the words are there to avoid when bandwidth matters (large batches: SPEC off).
 // SAVE_V (a gradient is wanted): the raw value of every sample of a tile through which a gradient CAN come back -- some voxel of the
-// tile passes the pre_scale clamp, or there is no pre_scale -- is also written to v[ray][k], for seg_dp_kernel.  On GenRe's own
+// tile passes the pre_scale clamp, or there is no pre_scale -- is also saved (one 64-byte slot per segment), for seg_scatter_kernel.  On GenRe's own
 // chain no tile qualifies and nothing is written.
 template <bool VEC, bool SPEC, bool SAVE_V>
 __global__ __launch_bounds__(kNT) void seg_sample_kernel(RenderDims D, View5 vox, const double *__restrict__ dirs,
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kNT) void seg_sample_kernel(RenderDims D, View5 vox
     bool save_v = SAVE_V;                                                // (workgroup-uniform)
     if (live != nullptr) {
         // bit 0: a voxel of the BRICK passes (what render_bwd_brick_kernel skips by); bit 1: a voxel of the TILE passes = this
-        // workgroup saves its samples' values (what seg_dp_kernel skips by: exactly the tiles whose values exist).
+        // workgroup saves its samples' values (what seg_scatter_kernel skips by: exactly the tiles whose values exist).
         // (__syncthreads_or returns a predicate, not the bitwise OR: one call per bit)
         const int own_any = __syncthreads_or(passes & 1) ? 1 : 0;
         const int tile_any = (SAVE_V && __syncthreads_or(passes & 2)) ? 2 : 0;
@@ -393,10 +393,10 @@ void launch_seg_sample(const RenderDims &D, const genre_tensor *vox, const genre
 //   dL/dp_k = g T_k (w_k - R_{k+1}),   R_k = p_k w_k + (1 - p_k) R_{k+1},   R behind the ray's last sample = 1      (no division, no
 // cancellation: the form of csrc/sph_render_bm.hip).  T_k = transmittance in front of sample k, g = dL/d(map value of the ray).
 // seg_combine_bwd_kernel (lane = ray) chains the forward's (P, S) pairs once forwards (g T in front of every segment) and once
-// backwards (R behind every segment's end: R in front of a segment = S + P R behind it) in fp64; seg_dp_kernel (lane = segment)
-// re-runs the segment's two short scans from the saved sample values and writes dL/dp[ray][k] for render_bwd_brick_kernel
-// (csrc/sph_render.hip), plus each image's max |dL/dp| for its fixed-point scale.  Replaces round 5's render_scan_bwd_kernel (a
-// wave per ray over ALL samples, fp64 DPP scans) and needs the sample values only where a gradient can come back.
+// backwards (R behind every segment's end) in fp64; seg_scatter_kernel (lane = segment) re-runs the segment's two short scans from
+// the saved sample values and scatters dL/dp times the trilinear weights into its brick's tile.  Replaces round 5's
+// render_scan_bwd_kernel + render_bwd_brick_kernel (a wave per ray over ALL samples, dL/dp[ray][k] through memory, a lane per
+// (sample, brick it touches)) for forwards by genre_render_seg_forward; needs the sample values only where a gradient can come back.
 constexpr int kMaxRaySegs = 32;
 
 template <int NT>
@@ -404,13 +404,15 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
                                                               const int *__restrict__ ray_nseg,
                                                               const double2 *__restrict__ ray_pre, int lines, View4 gout,
                                                               float2 *__restrict__ tr, const int *__restrict__ live, int nbricks,
-                                                              const float2 *__restrict__ line_w)
+                                                              const float2 *__restrict__ line_w, unsigned *__restrict__ bmax)
 {
+    __shared__ unsigned red[NT / 64];
     const int rr = D.R * D.R;
-    const int q = blockIdx.x * NT + threadIdx.x, img = blockIdx.y * D.NC + blockIdx.z;
+    const int img = blockIdx.y * D.NC + blockIdx.z;
     if (live != nullptr && live[(int64_t)img * (nbricks + 1)] == 0) return;      // no voxel of this image passes the clamp: nothing reads tr
-    if (q >= rr) return;
-    const int n = min(ray_nseg[q], kMaxRaySegs);
+    const bool ray = (int)(blockIdx.x * NT + threadIdx.x) < rr;
+    const int q = min((int)(blockIdx.x * NT + threadIdx.x), rr - 1);              // (lanes beyond the last ray repeat it, store nothing)
+    const int n = ray ? min(ray_nseg[q], kMaxRaySegs) : 0;
     const float2 *__restrict__ b = ps + (size_t)img * lines + q;
     float2 *__restrict__ t = tr + (size_t)img * lines + q;
     float2 v[kMaxRaySegs], lw[kMaxRaySegs];                              // (P, S), (first, last depth weight) of the ray's segments
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
         gT[u] = (float)(g * T);
         if (u < n) T *= (double)v[u].x;
     }
-    // R in fp64; what leaves is the DIFFERENCE seg_dp_kernel starts from, w_last - R behind the segment (rounded to fp32 relative
+    // R in fp64; what leaves is the DIFFERENCE seg_scatter_kernel starts from, w_last - R behind the segment (rounded to fp32 relative
     // to itself, not to a depth).  In front of a segment: R = w_first + S + P (R behind - w_first)  (seg_combine_kernel: S is relative)
     double R = 1.0;                                                      // behind the last sample: prod(1-p) * 1  (:69-71)
 #pragma unroll
@@ -451,151 +453,355 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
             R = (double)lw[u].x + (double)v[u].y + (double)v[u].x * (R - (double)lw[u].x);
         }
     }
-}
-
-__device__ __forceinline__ void publish_max_bits(unsigned wmax, int lane, unsigned *dpmax_bits)
-{
-    // a wave's max |dL/dp| as a bit pattern (non-negative floats order like their bits; Inf / NaN sort above every finite value, so a
-    // non-finite gradient survives: csrc/sph_render.hip: publish_max)
+    // this block's max |g T| in front of a ray's first segment (T only falls along a ray), as a bit pattern -- non-negative floats
+    // order like their bits, Inf / NaN sort above every finite value, so a non-finite gradient survives --: seg_scatter_kernel
+    // derives its image's fixed-point scale from the blocks' maxima (no atomics, nothing to clear)
+    unsigned m = n > 0 ? (__float_as_uint(gT[0]) & 0x7fffffffu) : 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o, 64));
-    if (lane == 0 && wmax > 0u &&
-        wmax > __hip_atomic_load(dpmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dpmax_bits, wmax);
-}
-
-constexpr int kDpSeg = kSegSlot;
-
-__global__ __launch_bounds__(kNT) void seg_dp_kernel(RenderDims D, const int4 *__restrict__ segs, int nseg,
-                                                      const float2 *__restrict__ tr, int lines, const float *__restrict__ vbuf,
-                                                      const float *__restrict__ dw, float *__restrict__ dpbuf,
-                                                      unsigned *__restrict__ dpmax_bits, const int *__restrict__ live, int nbricks)
-{
-    __shared__ float dw_s[kMaxZR];
-    const int img = blockIdx.y * D.NC + blockIdx.z, lane = threadIdx.x & 63;
-    const int *lv = live ? live + (int64_t)img * (nbricks + 1) : nullptr;
-    if (lv != nullptr && lv[0] == 0) return;                             // no voxel of this image passes the clamp: grad_vox = 0
-    const int s = min((int)(blockIdx.x * kNT + threadIdx.x), nseg - 1);
-    const bool act = (int)(blockIdx.x * kNT + threadIdx.x) < nseg;
-    // Everything whose address is known now is requested now -- the table entry, the segment's saved values (one aligned 64-byte slot,
-    // found by the segment's index alone), the depth weights for LDS -- and only the two loads that need the entry (the brick's word,
-    // the segment's chain line) wait for it: two dependent round trips per wave instead of four (the kernel is bound by them: 113 000
-    // waves at batch 32).  Slots of tiles without saved values hold whatever the buffer held: read, never used (selects below).
-    const int4 e = segs[s];
-    float p[kDpSeg], w[kDpSeg], c[kDpSeg];
-    const float4 *slot = reinterpret_cast<const float4 *>(vbuf + ((size_t)img * nseg + (unsigned)s) * kSegSlot);
-#pragma unroll
-    for (int j = 0; j < kDpSeg / 4; j++) {
-        const float4 t4 = slot[j];
-        p[4 * j] = t4.x; p[4 * j + 1] = t4.y; p[4 * j + 2] = t4.z; p[4 * j + 3] = t4.w;
-    }
-    for (int i = threadIdx.x; i < kMaxZR; i += kNT) dw_s[i] = dw[min(i, D.ZR - 1)];
-    const int k0 = e.y & 255, L = min(e.y >> 8, kDpSeg);
-    // a gradient can come back through this segment's tile -- its brick and the voxels one step beyond the high faces -- only if
-    // one of the tile's voxels passes the pre_scale clamp: bit 1 of the brick's word, set by the very workgroup that then saved the
-    // tile's sample values.  Elsewhere no values exist and nobody's gradient depends on dL/dp (whatever render_bwd_brick_kernel
-    // accumulates from such samples lands on voxels the clamp blocks: a select)
-    bool tile_live = true;
-    const float2 st = tr[(size_t)img * lines + e.z];                       // (g T in front of the segment, w_last - R behind its end)
-    if (lv != nullptr) {
-        const int nby = (D.Y + kBrick - 1) >> 4, nbz = (D.Z + kBrick - 1) >> 4;
-        const int bx = e.w & 1023, by = (e.w >> 10) & 1023, bz = e.w >> 20;
-        tile_live = (lv[1 + (bx * nby + by) * nbz + bz] & 2) != 0;
-    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    unsigned wmax = 0u;
-    if (__ballot(act && tile_live) != 0ull) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < NT / 64; w++) m = max(m, red[w]);
+        bmax[(size_t)img * gridDim.x + blockIdx.x] = m;
+    }
+}
+
+// ---- backward: who writes what of grad_vox --------------------------------------------------------------------------------------
+// A row's workgroup (seg_scatter_kernel) accumulates the tile of its brick: the brick's 16^3 voxels, which it WRITES (plain
+// stores; every voxel of grad_vox is written by its brick's row, zeros where nothing comes back), and the 817 cells one step
+// beyond the high faces, voxels of other bricks, which it leaves in its halo record; seg_halo_kernel adds the records onto the
+// voxels behind the first kernel's stores.  Bricks whose segments are divided over several rows (bit 30 of the row's last column;
+// bit 31: the first of them) are zeroed by seg_zero_split_kernel first and added to with atomics by all their rows.
+constexpr int kHF = kBrick + 1;                                          // cells per tile edge that exist as voxels: locals 0 .. 16
+constexpr int kHaloX = 0;                                                // x face: local x = 16, [y 0..16][z 0..16]
+constexpr int kHaloY = kHF * kHF;                                        // y face: local y = 16, [x 0..15][z 0..16]
+constexpr int kHaloZ = kHaloY + kBrick * kHF;                            // z face: local z = 16, [x 0..15][y 0..15]
+constexpr int kHaloN = kHaloZ + kBrick * kBrick;                         // 817
+constexpr int kHaloRec = 832;                                            // floats per record
+
+struct RowBits { int bx0, by0, bz0; bool split, first; };
+__device__ __forceinline__ RowBits row_bits(const int4 &row)
+{
+    const unsigned w = (unsigned)row.w;
+    return {(int)(w & 1023u) * kBrick, (int)((w >> 10) & 1023u) * kBrick, (int)((w >> 20) & 1023u) * kBrick, ((w >> 30) & 1u) != 0,
+            (w >> 31) != 0};
+}
+
+// the row's tile holds nothing that comes back (or the row is empty): with live words, no voxel of the tile passes the pre_scale clamp
+__device__ __forceinline__ bool row_dead(const RenderDims &D, const int4 &row, const int *__restrict__ live, int img)
+{
+    if (row.y >= row.z) return true;                                     // a brick no sample is based in (the cube's corners)
+    if (live == nullptr) return false;
+    const int nbricks = ((D.X + kBrick - 1) >> 4) * ((D.Y + kBrick - 1) >> 4) * ((D.Z + kBrick - 1) >> 4);
+    const int *lv = live + (int64_t)img * (nbricks + 1);
+    return lv[0] == 0 || (lv[1 + row.x] & 2) == 0;
+}
+
+__device__ __forceinline__ void zero_brick(const RenderDims &D, const View5 &gvox, float *gb, const RowBits &b, int nthreads)
+{
+    // 16-byte stores where the z rows allow it.  PLAIN stores: a brick's z row is 64 bytes, half of a 128-byte line whose other
+    // half belongs to the next brick -- nontemporal stores (no merging in L2) measured slower (csrc/sph_render.hip)
+    const bool v4 = gvox.s4 == 1 && ((gvox.s2 | gvox.s3) & 3) == 0 && (reinterpret_cast<uintptr_t>(gb) & 15) == 0 && b.bz0 + kBrick <= D.Z;
+    for (int it = threadIdx.x; it < kBrick * kBrick * 4; it += nthreads) {
+        const int x = b.bx0 + (it >> 6), y = b.by0 + ((it >> 2) & 15), z = b.bz0 + (it & 3) * 4;
+        if (x >= D.X || y >= D.Y) continue;
+        float *dst = gb + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
+        if (v4) *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else
+            for (int c = 0; c < 4; c++)
+                if (z + c < D.Z) dst[c * gvox.s4] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(kNT) void seg_zero_split_kernel(RenderDims D, View5 gvox, const int4 *__restrict__ rows)
+{
+    const int4 row = rows[blockIdx.x];
+    const RowBits b = row_bits(row);
+    if (!b.first) return;
+    zero_brick(D, gvox, gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1, b, kNT);
+}
+
+// adds every live row's halo record onto the voxels it belongs to (other bricks' low faces): behind seg_scatter_kernel's stores
+__global__ __launch_bounds__(kNT) void seg_halo_kernel(RenderDims D, View5 gvox, const int4 *__restrict__ rows,
+                                                        const float *__restrict__ halo, const int *__restrict__ live)
+{
+    const int4 row = rows[blockIdx.x];
+    const int img = blockIdx.y * D.NC + blockIdx.z;
+    if (row_dead(D, row, live, img)) return;
+    const RowBits b = row_bits(row);
+    const float *rec = halo + ((size_t)img * gridDim.x + blockIdx.x) * kHaloRec;
+    float *gb = gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1;
+    float v[(kHaloN + kNT - 1) / kNT];
+#pragma unroll
+    for (int i = 0; i < (kHaloN + kNT - 1) / kNT; i++) v[i] = rec[min((int)threadIdx.x + i * kNT, kHaloN - 1)];
+#pragma unroll
+    for (int i = 0; i < (kHaloN + kNT - 1) / kNT; i++) {
+        const int idx = (int)threadIdx.x + i * kNT;
+        if (idx >= kHaloN || v[i] == 0.0f) continue;                      // (cells outside the volume were recorded as zeros)
+        int lx, ly, lz;
+        if (idx < kHaloY) { lx = kBrick; ly = (int)(((float)idx + 0.5f) * (1.0f / kHF)); lz = idx - ly * kHF; }
+        else if (idx < kHaloZ) { const int j = idx - kHaloY; lx = (int)(((float)j + 0.5f) * (1.0f / kHF)); ly = kBrick; lz = j - lx * kHF; }
+        else { const int j = idx - kHaloZ; lx = j >> 4; ly = j & 15; lz = kBrick; }
+        unsafeAtomicAdd(gb + (b.bx0 + lx) * gvox.s2 + (b.by0 + ly) * gvox.s3 + (b.bz0 + lz) * gvox.s4, v[i]);
+    }
+}
+
+// ---- backward, accumulation: lane = segment, the brick's tile as 64-bit fixed point in LDS -------------------------------------------
+// One workgroup per row of bwd_rows (a brick, or a piece of a heavy one), one image.  A lane takes one segment: the saved values of
+// its <= 16 samples (one 64-byte slot), (g T in front, w_last - R behind) from seg_combine_bwd_kernel; forwards g T_k, backwards
+//   dL/dp_k = g T_k d_k,   d_k = w_k - R_{k+1}:   d_{k-1} = (w_{k-1} - w_k) + (1 - p_k) d_k        (R_k = R_{k+1} + p_k d_k)
+// (the DIFFERENCE carried, not R: roundings relative to a fraction of the depth range), and per sample the position, cell and
+// ATen's eight trilinear weights exactly as the forward formed them, accumulated into the tile -- 18^3 cells: the brick, the
+// voxels one step beyond its high faces (a sample is listed under the brick of its base corner) and one plane in front of the low
+// faces (base corner -1: zero padding, never flushed): no ownership tests.  Every sample is visited ONCE (round 5's brick-owned
+// kernel listed a sample under every brick it touches, 1.37 visits, at one lane per visit with the position recomputed in fp64;
+// pulling whole segments would be 1.8) and nothing per sample goes through memory between the scan and the scatter.
+//   * The tile is 64-bit FIXED POINT: LDS integer atomics cost nothing next to the arithmetic here whatever the lanes' addresses
+//     (64 lanes adding to near-by, often identical cells), floating-point ones do -- measured on this kernel at batch 32:
+//     ds_add_u64 914 us (no atomics at all: 930), ds_add_f64 1564, ds_add_f32 2324.  Scale 2^(44-e) with 2^e above a BOUND of the
+//     image's |dL/dp|, max |g T| in front of a ray (seg_combine_bwd_kernel's per-block maxima) times the span of the depth
+//     weights and 1 (|w_k - R| cannot exceed it): a few bits of the 44 unused, no pass over the samples.  Sums of up to 2^17
+//     contributions stay below 2^63; integer sums do not depend on the order.  A non-finite bound: the image's gradient is NaN.
+//   * Consecutive samples of a ray are a quarter to half a voxel apart; the eight corner sums of a cell are formed in registers
+//     (fp32, a handful of terms) and go to the tile when the cell changes.
+//   * The next chunk's entry and slot are requested before the current chunk's arithmetic, its chain line and direction after.
+// The flush applies the adjoint of clamp(vox * pre_scale) -- a per-voxel select and scale, so it distributes over partial sums --
+// and adds the tile into grad_vox, which the host entry zeroes first: voxels only this workgroup can reach (inside the brick,
+// away from its low faces, brick not split over rows) with plain stores, the rest (its low faces, which the tiles of the bricks
+// in front reach too; the halo, = other bricks' low faces; split bricks) with fp32 atomics, skipping zeros.
+#ifndef GENRE_SCATTER_AB
+#define GENRE_SCATTER_AB 0
+#endif
+constexpr int kAT = kBrick + 2;                                          // tile edge: voxel locals -1 .. 16
+constexpr int kATn = kAT * kAT * kAT;
+constexpr int kNTs = 512;                                               // threads of seg_scatter_kernel: two workgroups (99 KB of LDS) per
+                                                                         // CU = four waves per SIMD, at <= 128 VGPRs
+
+__global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) void seg_scatter_kernel(RenderDims D, View5 vox, View5 gvox, const double *__restrict__ dirs,
+                                                           const float *__restrict__ dw, const int4 *__restrict__ rows,
+                                                           const int4 *__restrict__ segs, int nseg,
+                                                           const float2 *__restrict__ tr, int lines,
+                                                           const float *__restrict__ vbuf, const int *__restrict__ live,
+                                                           const unsigned *__restrict__ bmax, int nblk, float *__restrict__ halo)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    unsigned long long *tile = reinterpret_cast<unsigned long long *>(lds_d);   // [kATn]
+    float *dw_s = reinterpret_cast<float *>(lds_d + kATn);               // [kMaxZR]
+    __shared__ unsigned red_m[kNTs / 64];
+    __shared__ float red_lo[kNTs / 64], red_hi[kNTs / 64];
+    const int4 row = rows[blockIdx.x];
+    const int img = blockIdx.y * D.NC + blockIdx.z;
+    const RowBits rb = row_bits(row);
+    const bool split = rb.split;                                         // other rows accumulate into this brick too
+    const int bx0 = rb.bx0, by0 = rb.by0, bz0 = rb.bz0;
+    float *gb = gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1;
+    if (row_dead(D, row, live, img)) {                                   // nothing comes back: this brick's voxels are zeros
+        if (!split) zero_brick(D, gvox, gb, rb, kNTs);                   // (a split brick: seg_zero_split_kernel)
+        return;
+    }
+    const int ox = bx0 - 1, oy = by0 - 1, oz = bz0 - 1;                  // tile origin
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const size_t vimg = (size_t)img * nseg;
+    const float2 *__restrict__ trimg = tr + (size_t)img * lines;
+    // the first chunk's entry and slot (addresses known now), in flight across the set-up below
+    int c0 = row.y + wave * 64;
+    int sc = min(c0 + lane, row.z - 1);
+    int4 e = segs[sc];
+    float4 pv[kSegSlot / 4];
+    {
+        const float4 *slot = reinterpret_cast<const float4 *>(vbuf + (vimg + (unsigned)sc) * kSegSlot);
+#pragma unroll
+        for (int j = 0; j < kSegSlot / 4; j++) pv[j] = slot[j];
+    }
+    unsigned mb = 0u;
+    for (int i = threadIdx.x; i < nblk; i += kNTs) mb = max(mb, bmax[(size_t)img * nblk + i]);
+    float wlo = 1.0f, whi = 1.0f;                                        // (R behind a ray's last sample is 1)
+    for (int k = threadIdx.x; k < kMaxZR; k += kNTs) {
+        const int kk = min(k, D.ZR - 1);
+        const float w = dw[kk];
+        dw_s[k] = w;
+        wlo = fminf(wlo, w); whi = fmaxf(whi, w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
+        wlo = fminf(wlo, __shfl_xor(wlo, o, 64)); whi = fmaxf(whi, __shfl_xor(whi, o, 64));
+    }
+    if (lane == 0) { red_m[wave] = mb; red_lo[wave] = wlo; red_hi[wave] = whi; }
+    for (int i = threadIdx.x; i < kATn; i += kNTs) tile[i] = 0ull;
+    float2 st = trimg[e.z];                                               // (g T in front of the segment, w_last - R behind its end)
+    double d2x = dirs[e.x * 3 + 0], d2y = dirs[e.x * 3 + 1], d2z = dirs[e.x * 3 + 2];
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kNTs / 64; w++) { mb = max(mb, red_m[w]); wlo = fminf(wlo, red_lo[w]); whi = fmaxf(whi, red_hi[w]); }
+    const float bound = __uint_as_float(mb) * (whi - wlo);               // >= |dL/dp| of every sample of this image
+    const bool nonfinite = !(bound <= 3.0e38f);                          // an Inf / NaN upstream gradient (or depth weight)
+    int ex = 0;
+    (void)frexpf(nonfinite ? 1.0f : bound, &ex);                         // bound < 2^ex
+    const double scale = ldexp(1.0, 44 - ex), inv_scale = ldexp(1.0, ex - 44);
+
+    for (; c0 < row.z && !nonfinite; c0 += kNTs) {                       // (waves run on their own: no barrier in here)
+        const bool act = c0 + lane < row.z;
+        const int k0 = e.y & 255, L = act ? min(e.y >> 8, kSegSlot) : 0;
+        const double dx2 = d2x * 2, dy2 = d2y * 2, dz2 = d2z * 2;
+        float p[kSegSlot], gt[kSegSlot];
+#pragma unroll
+        for (int j = 0; j < kSegSlot / 4; j++) { p[4 * j] = pv[j].x; p[4 * j + 1] = pv[j].y; p[4 * j + 2] = pv[j].z; p[4 * j + 3] = pv[j].w; }
+        float Tg = st.x, d = st.y;
+        // the next chunk's entry and slot (the last chunk re-reads its own)
+        sc = min(c0 + kNTs + lane, row.z - 1);
+        e = segs[sc];
+        {
+            const float4 *slot = reinterpret_cast<const float4 *>(vbuf + (vimg + (unsigned)sc) * kSegSlot);
+#pragma unroll
+            for (int j = 0; j < kSegSlot / 4; j++) pv[j] = slot[j];
+        }
         unsigned pass = 0u;
+        float Tlo = 0.f;
 #pragma unroll
-        for (int i = 0; i < kDpSeg; i++) w[i] = dw_s[k0 + min(i, L - 1)];
-        // Both short scans in fp64 (the kernel waits for memory, not for its ALUs): forwards g T_k; backwards
-        // dL/dp_k = g T_k (w_k - R_{k+1}) with the DIFFERENCE d_k = w_k - R_{k+1} carried instead of R -- from R_k = R_{k+1} + p_k d_k
-        // follows d_{k-1} = (w_{k-1} - w_k) + (1 - p_k) d_k.  In fp32 with R carried, sixteen roundings of a number ~2 under
-        // differences ~0.3 showed as 2e-5 of the gradient's scale on sharp volumes (tests/test_gpu_render_genre.py asks for 1e-5)
-        double Tg = (double)st.x, gt[kDpSeg];
-#pragma unroll
-        for (int i = 0; i < kDpSeg; i++) {
+        for (int i = 0; i < kSegSlot; i++) {                              // forwards: g T_k, carried as T + Tlo (see the sampler)
             const float raw = p[i];
             p[i] = fminf(fmaxf(raw, D.lo), D.hi);                         // clamp(., 1e-5, 1 - 1e-5)  (spherical_proj.py:66)
-            pass |= (raw >= D.lo && raw <= D.hi) ? 1u << i : 0u;          // torch.clamp's backward mask
-            gt[i] = Tg;
-            if (i < L) Tg *= (double)(1.0f - p[i]);
-        }
-        double d = 0.0;
-#pragma unroll
-        for (int i = kDpSeg - 1; i >= 0; i--) {
-            c[i] = 0.f;
+            pass |= (raw >= D.lo && raw <= D.hi && i < L) ? 1u << i : 0u; // torch.clamp's backward mask
+            gt[i] = Tg + Tlo;
             if (i < L) {
-                double dn = (double)st.y;                                  // the segment's last sample: w - R behind it, from the fp64 chain
-                if (i + 1 < kDpSeg) {
-                    if (i + 1 < L) dn = fma((double)(1.0f - p[min(i + 1, kDpSeg - 1)]), d, (double)(w[i] - w[min(i + 1, kDpSeg - 1)]));
-                }
-                d = dn;
-                c[i] = (pass >> i & 1u) ? (float)(gt[i] * d) : 0.f;
-                if (act && tile_live) wmax = max(wmax, __float_as_uint(c[i]) & 0x7fffffffu);
+                const float f = 1.0f - p[i], t = Tg * f;
+                Tlo = __builtin_fmaf(Tlo, f, __builtin_fmaf(Tg, f, -t));
+                Tg = t;
             }
         }
-        if (act && tile_live) {       // one aligned 64-byte slot per segment, like the saved values (render_bwd_brick_kernel finds a
-                                      // listed sample's slot through chunk_slot): written [ray][k], 4 bytes at a time to 64 different
-                                      // rays per store instruction, the stores alone took 400 us at batch 32
-            float4 *dslot = reinterpret_cast<float4 *>(dpbuf + ((size_t)img * nseg + (unsigned)s) * kSegSlot);
+        // backwards: d_k, and dL/dp_k in the place of g T_k.  ALL of this chunk's LDS reads happen here, in front of its atomics: LDS
+        // operations complete in order, and a read behind a spill would wait for the spill's eight conflict-laden atomics
 #pragma unroll
-            for (int j = 0; j < kDpSeg / 4; j++)
-                dslot[j] = make_float4(4 * j < L ? c[4 * j] : 0.f, 4 * j + 1 < L ? c[4 * j + 1] : 0.f, 4 * j + 2 < L ? c[4 * j + 2] : 0.f,
-                                       4 * j + 3 < L ? c[4 * j + 3] : 0.f);
+        for (int i = kSegSlot - 1; i >= 0; i--) {
+            const int k = min(k0 + i, kMaxZR - 1);
+            if (i + 1 < kSegSlot) {
+                const float dn = __builtin_fmaf(1.0f - p[min(i + 1, kSegSlot - 1)], d, dw_s[k] - dw_s[min(k + 1, kMaxZR - 1)]);
+                d = i + 1 < L ? dn : d;
+            }
+            gt[i] = (pass >> i & 1u) ? gt[i] * d : 0.f;                   // (pass: inside the segment and through the clamp)
+        }
+        // the scatter: position, cell and weights of every sample as the forward formed them (spherical_proj.py:50-56; 1 - alpha_k
+        // in fp64 arithmetic here, not from a table in LDS: see above)
+        int cur = -1;                                                     // tile index of the cell whose sums are in acc[]
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0.f;
+        auto spill = [&]() {
+            unsigned long long *tp = tile + cur;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+#if GENRE_SCATTER_AB == 1                                                 // (A/B: no LDS atomics)
+                if (acc[j] == 12345.678f)
+#endif
+                // one fp64 fma with the power-of-two scale and 1.5 * 2^52: the rounded product is an integer in the mantissa
+                atomicAdd(tp + ((j & 1) ? kAT * kAT : 0) + ((j & 2) ? kAT : 0) + ((j & 4) ? 1 : 0),
+                          (unsigned long long)(__double_as_longlong(fma((double)acc[j], scale, 6755399441055744.0)) -
+                                               0x4338000000000000LL));    // ds_add_u64
+                acc[j] = 0.f;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < kSegSlot; i++) {
+            if (__ballot(i < L) == 0ull) break;                           // (a wave's segments are neighbours in length)
+            const int k = min(k0 + i, D.ZR - 1);
+            const double a = 1.0 - ((k == D.ZR - 1) ? 1.0 : (double)k * D.step);   // numpy.linspace(0,1,ZR)[k]  (render_common.hpp: sample_pos)
+            const float gx = (float)(dx2 * a), gy = (float)(dy2 * a), gz = (float)(dz2 * a);
+            Cell c;
+            locate(D, gx, gy, gz, c);
+            const int idx = ((c.x0 - ox) * kAT + (c.y0 - oy)) * kAT + (c.z0 - oz);
+            const float dp = gt[i];
+            const bool on = dp != 0.0f;                                   // (NaN != 0: a non-finite gradient goes through)
+#if GENRE_SCATTER_AB == 5                                                 // (A/B: one spill per segment)
+            if (on) cur = idx;
+#else
+            if (on && idx != cur) {
+                if (cur >= 0) spill();
+                cur = idx;
+            }
+#endif
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] += corner_w(c, j) * dp;    // ATen's weight (fp32, its product order) times dL/dp (0 off the segment)
+        }
+        if (cur >= 0) spill();
+        // what needs the next entry
+        st = trimg[e.z];
+        d2x = dirs[e.x * 3 + 0]; d2y = dirs[e.x * 3 + 1]; d2z = dirs[e.x * 3 + 2];
+    }
+    __syncthreads();
+#if GENRE_SCATTER_AB == 6                                                 // (A/B: no flush)
+    if (tile[threadIdx.x] != 0x123456789ull) return;
+#endif
+    // ---- flush: the tile's 17 x 17 z rows in four pieces of four cells (+ the cell at z = 16), through the adjoint of
+    // clamp(vox * pre_scale) -- a per-voxel select and scale, so it distributes over the partial sums of a voxel that several tiles
+    // reach.  The brick's own voxels go to grad_vox (16-byte stores when the rows allow it; atomics in a split brick), the cells
+    // beyond its high faces to the row's halo record (zeros for cells outside the volume) ----------------------------------------------
+    const float *vb = vox.p + blockIdx.y * vox.s0 + blockIdx.z * vox.s1;
+    float *rec = halo + ((size_t)img * gridDim.x + blockIdx.x) * kHaloRec;
+    const bool v4 = D.sz == 1 && ((D.sx | D.sy) & 3) == 0 && (reinterpret_cast<uintptr_t>(vb) & 15) == 0 && gvox.s4 == 1 &&
+                    ((gvox.s2 | gvox.s3) & 3) == 0 && (reinterpret_cast<uintptr_t>(gb) & 15) == 0 && bz0 + kBrick <= D.Z;
+    auto cell = [&](const unsigned long long raw, const float mv, const bool ok) {
+        float val = (float)((double)(long long)raw * inv_scale);
+        if (nonfinite) val = __uint_as_float(0x7fc00000u);                // the reference chain would return NaN here too
+        if (D.pre_scale != 0.0f) {                                        // adjoint of clamp(x * pre_scale, lo, hi): a select
+            const float t = mv * D.pre_scale;
+            val = (t >= D.lo && t <= D.hi) ? val * D.pre_scale : 0.0f;
+        }
+        return ok ? val : 0.0f;
+    };
+    for (int it = threadIdx.x; it < kHF * kHF * 4; it += kNTs) {
+        const int r = it >> 2, lz0 = (it & 3) * 4;
+        const int lx = (int)(((float)r + 0.5f) * (1.0f / kHF)), ly = r - lx * kHF;
+        const int x = bx0 + lx, y = by0 + ly, z = bz0 + lz0;
+        const bool in_xy = x < D.X && y < D.Y;
+        float mv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (D.pre_scale != 0.0f && in_xy) {
+            if (v4) {
+                const float4 t = *reinterpret_cast<const float4 *>(vb + x * D.sx + y * D.sy + z);
+                mv[0] = t.x; mv[1] = t.y; mv[2] = t.z; mv[3] = t.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) mv[c] = z + c < D.Z ? vb[x * D.sx + y * D.sy + (z + c) * D.sz] : 0.f;
+            }
+        }
+        const unsigned long long *tp = tile + ((lx + 1) * kAT + ly + 1) * kAT + lz0 + 1;
+        float val[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) val[c] = cell(tp[c], mv[c], in_xy && z + c < D.Z);
+        if (lx < kBrick && ly < kBrick) {                                 // the brick's own voxels
+            if (!in_xy) continue;
+            float *dst = gb + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
+            if (!split) {
+                if (v4) *reinterpret_cast<float4 *>(dst) = make_float4(val[0], val[1], val[2], val[3]);
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if (z + c < D.Z) dst[c * gvox.s4] = val[c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (val[c] != 0.0f) unsafeAtomicAdd(dst + c * gvox.s4, val[c]);
+            }
+        } else {                                                          // x face (local x = 16), else y face
+            float *h = rec + (lx == kBrick ? kHaloX + ly * kHF + lz0 : kHaloY + lx * kHF + lz0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) h[c] = val[c];
         }
     }
-    publish_max_bits(wmax, lane, dpmax_bits + img);
+    for (int r = threadIdx.x; r < kHF * kHF; r += kNTs) {                 // the cells at local z = 16
+        const int lx = (int)(((float)r + 0.5f) * (1.0f / kHF)), ly = r - lx * kHF;
+        const int x = bx0 + lx, y = by0 + ly, z = bz0 + kBrick;
+        const bool ok = x < D.X && y < D.Y && z < D.Z;
+        const float mv = (D.pre_scale != 0.0f && ok) ? vb[x * D.sx + y * D.sy + z * D.sz] : 0.f;
+        const float val = cell(tile[((lx + 1) * kAT + ly + 1) * kAT + kBrick + 1], mv, ok);
+        rec[lx == kBrick ? kHaloX + ly * kHF + kBrick : (ly == kBrick ? kHaloY + lx * kHF + kBrick : kHaloZ + lx * kBrick + ly)] = val;
+    }
 }
 
 }  // namespace
-
-// the dL/dp phase of genre_render_spherical_backward in segment form (called from csrc/sph_render.hip; arguments checked here)
-int seg_backward_dlp(const char *op, const genre_tensor *vox, const genre_tensor *dirs, const genre_tensor *depth_weight,
-                     const genre_tensor *grad_out, const genre_tensor *segs, const genre_tensor *ray_nseg,
-                     const genre_tensor *ray_pre, const genre_tensor *line_w, const genre_tensor *ps_scratch,
-                     const genre_tensor *tr_scratch,
-                     const genre_tensor *v_scratch, float *dp, unsigned *dpmax, const int *live, float pre_scale, hipStream_t st)
-{
-    RenderDims D{};
-    if (!check_render(op, vox, dirs, depth_weight, grad_out, D)) return 0;
-    D.pre_scale = pre_scale;
-    const int imgs = D.N * D.NC, rr = D.R * D.R;
-    const int nb = ((D.X + kBrick - 1) / kBrick) * ((D.Y + kBrick - 1) / kBrick) * ((D.Z + kBrick - 1) / kBrick);
-    GENRE_REQUIRE(D.ZR <= kMaxZR && D.N <= 65535 && D.NC <= 65535, "%s: needs ZR <= 256, N and NC <= 65535", op);
-    GENRE_REQUIRE(is_i32(segs, 2) && segs->size[1] == 4 && segs->size[0] >= 1 && is_contiguous(segs) && aligned16(segs->data),
-                  "%s: segs must be a contiguous, 16-byte aligned int32 [nseg >= 1, 4] tensor", op);
-    GENRE_REQUIRE(is_i32(ray_nseg, 1) && is_contiguous(ray_nseg) && ray_nseg->size[0] == rr, "%s: ray_nseg must be int32 [R*R]", op);
-    GENRE_REQUIRE(is_f32(ray_pre, 2) && is_contiguous(ray_pre) && ray_pre->size[0] == rr && ray_pre->size[1] == 4 &&
-                      aligned16(ray_pre->data), "%s: ray_pre must be the float64 [R*R, 2] prefix table viewed as fp32 [R*R, 4]", op);
-    GENRE_REQUIRE(line_w != nullptr && is_f32(line_w, 2) && is_contiguous(line_w) && line_w->size[1] == 2 &&
-                      ((uintptr_t)line_w->data & 7u) == 0 && line_w->size[0] * (int64_t)2 * imgs == ps_scratch->size[0],
-                  "%s: line_w must be fp32 [smax*R*R, 2], one pair per scratch line of an image", op);
-    GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ((uintptr_t)ps_scratch->data & 7u) == 0 &&
-                      ps_scratch->size[0] % ((int64_t)2 * imgs * rr) == 0 && ps_scratch->size[0] > 0 &&
-                      ps_scratch->size[0] / (2 * imgs) < ((int64_t)1 << 31) && ps_scratch->size[0] / ((int64_t)2 * imgs * rr) <= kMaxRaySegs,
-                  "%s: ps_scratch must be the forward's fp32 [N*NC * smax*R*R * 2] buffer (smax <= %d)", op, kMaxRaySegs);
-    GENRE_REQUIRE(is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && ((uintptr_t)tr_scratch->data & 7u) == 0 &&
-                      tr_scratch->size[0] >= ps_scratch->size[0], "%s: tr_scratch must hold as many floats as ps_scratch", op);
-    GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && aligned16(v_scratch->data) &&
-                      v_scratch->size[0] >= (int64_t)imgs * segs->size[0] * kSegSlot,
-                  "%s: v_scratch must be the forward's fp32 [N*NC*nseg*%d] buffer (one slot per segment)", op, kSegSlot);
-    const int lines = (int)(ps_scratch->size[0] / (2 * imgs));
-    const int nseg = (int)segs->size[0];
-    if (imgs * (int64_t)rr >= 65536 * 4)
-        seg_combine_bwd_kernel<256><<<dim3((rr + 255) / 256, D.N, D.NC), 256, 0, st>>>(
-            D, (const float2 *)ps_scratch->data, (const int *)ray_nseg->data, (const double2 *)ray_pre->data, lines,
-            view4(grad_out), (float2 *)tr_scratch->data, live, nb, (const float2 *)line_w->data);
-    else
-        seg_combine_bwd_kernel<64><<<dim3((rr + 63) / 64, D.N, D.NC), 64, 0, st>>>(
-            D, (const float2 *)ps_scratch->data, (const int *)ray_nseg->data, (const double2 *)ray_pre->data, lines,
-            view4(grad_out), (float2 *)tr_scratch->data, live, nb, (const float2 *)line_w->data);
-    GENRE_LAUNCH_CHECK("render_spherical backward (segment chains)");
-    seg_dp_kernel<<<dim3((nseg + kNT - 1) / kNT, D.N, D.NC), kNT, 0, st>>>(
-        D, (const int4 *)segs->data, nseg, (const float2 *)tr_scratch->data, lines, (const float *)v_scratch->data,
-        (const float *)depth_weight->data, dp, dpmax, live, nb);
-    GENRE_LAUNCH_CHECK("render_spherical backward (dL/dp per segment)");
-    return 1;
-}
 
 }  // namespace genre
 
@@ -694,5 +900,92 @@ extern "C" int genre_render_seg_forward(const genre_tensor *vox, const genre_ten
             D, (const float2 *)ps_scratch->data, (const int *)ray_nseg->data, (const double2 *)ray_pre->data, lines, view4(out),
             live_p, nb, (const float2 *)line_w->data);
     GENRE_LAUNCH_CHECK("render_seg forward (combine)");
+    return 1;
+}
+
+
+// The backward of genre_render_seg_forward (include/genre_hip.h): per-ray chains over the forward's (P, S) pairs, then one pass over
+// the segments -- dL/dp of every sample from the values the forward saved, scattered straight into the brick's tile
+extern "C" int genre_render_seg_backward(const genre_tensor *vox, const genre_tensor *dirs, const genre_tensor *depth_weight,
+                                         const genre_tensor *grad_out, const genre_tensor *grad_vox, const genre_tensor *bwd_rows,
+                                         const genre_tensor *segs, const genre_tensor *ray_nseg, const genre_tensor *ray_pre,
+                                         const genre_tensor *line_w, const genre_tensor *ps_scratch,
+                                         const genre_tensor *tr_scratch, const genre_tensor *v_scratch,
+                                         const genre_tensor *halo_scratch, const genre_tensor *live, float pre_scale,
+                                         void *stream)
+{
+    using namespace genre;
+    const char *op = "render_seg_backward";
+    RenderDims D{};
+    if (!check_render(op, vox, dirs, depth_weight, grad_out, D)) return 0;
+    D.pre_scale = pre_scale;
+    const int imgs = D.N * D.NC, rr = D.R * D.R;
+    hipStream_t st = (hipStream_t)stream;
+    GENRE_REQUIRE(is_f32(grad_vox, 5) && same_shape(grad_vox, vox) && is_contiguous(grad_vox),
+                  "%s: grad_vox must be a contiguous fp32 tensor of the shape of vox", op);
+    const int64_t nv = numel(grad_vox);
+    if (nv == 0) return 1;
+    if ((int64_t)imgs * rr == 0)                                         // no rays: the gradient of nothing
+        return hipMemsetAsync(grad_vox->data, 0, (size_t)nv * sizeof(float), st) == hipSuccess ? 1 : fail("%s: hipMemsetAsync failed", op);
+    const int nb = ((D.X + kBrick - 1) / kBrick) * ((D.Y + kBrick - 1) / kBrick) * ((D.Z + kBrick - 1) / kBrick);
+    GENRE_REQUIRE(D.ZR <= kMaxZR && (int64_t)rr < (1 << 24) && D.N <= 65535 && D.NC <= 65535,
+                  "%s: needs ZR <= 256, R*R < 2^24, N and NC <= 65535", op);
+    GENRE_REQUIRE(is_i32(bwd_rows, 2) && bwd_rows->size[1] == 4 && is_contiguous(bwd_rows) && bwd_rows->size[0] >= 1 &&
+                      bwd_rows->size[0] < (1 << 30) && aligned16(bwd_rows->data),
+                  "%s: bwd_rows must be a contiguous, 16-byte aligned int32 [rows >= 1, 4] tensor", op);
+    GENRE_REQUIRE(is_i32(segs, 2) && segs->size[1] == 4 && segs->size[0] >= 1 && is_contiguous(segs) && aligned16(segs->data),
+                  "%s: segs must be a contiguous, 16-byte aligned int32 [nseg >= 1, 4] tensor", op);
+    GENRE_REQUIRE(is_i32(ray_nseg, 1) && is_contiguous(ray_nseg) && ray_nseg->size[0] == rr, "%s: ray_nseg must be int32 [R*R]", op);
+    GENRE_REQUIRE(is_f32(ray_pre, 2) && is_contiguous(ray_pre) && ray_pre->size[0] == rr && ray_pre->size[1] == 4 &&
+                      aligned16(ray_pre->data), "%s: ray_pre must be the float64 [R*R, 2] prefix table viewed as fp32 [R*R, 4]", op);
+    GENRE_REQUIRE(is_f32(ps_scratch, 1) && is_contiguous(ps_scratch) && ((uintptr_t)ps_scratch->data & 7u) == 0 &&
+                      ps_scratch->size[0] % ((int64_t)2 * imgs * rr) == 0 && ps_scratch->size[0] > 0 &&
+                      ps_scratch->size[0] / (2 * imgs) < ((int64_t)1 << 31) && ps_scratch->size[0] / ((int64_t)2 * imgs * rr) <= kMaxRaySegs,
+                  "%s: ps_scratch must be the forward's fp32 [N*NC * smax*R*R * 2] buffer (smax <= %d)", op, kMaxRaySegs);
+    GENRE_REQUIRE(is_f32(line_w, 2) && is_contiguous(line_w) && line_w->size[1] == 2 && ((uintptr_t)line_w->data & 7u) == 0 &&
+                      line_w->size[0] * (int64_t)2 * imgs == ps_scratch->size[0],
+                  "%s: line_w must be fp32 [smax*R*R, 2], one pair per scratch line of an image", op);
+    GENRE_REQUIRE(is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && ((uintptr_t)tr_scratch->data & 7u) == 0,
+                  "%s: tr_scratch must be a contiguous, 8-byte aligned fp32 buffer", op);
+    GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && aligned16(v_scratch->data) &&
+                      v_scratch->size[0] >= (int64_t)imgs * segs->size[0] * kSegSlot,
+                  "%s: v_scratch must be the forward's fp32 [N*NC*nseg*%d] buffer (one slot per segment)", op, kSegSlot);
+    const int *live_p = nullptr;                                        // the forward's clamp pass words (pre_scale only)
+    if (pre_scale != 0.0f) {
+        GENRE_REQUIRE(is_i32(live, 1) && is_contiguous(live) && live->size[0] >= (int64_t)imgs * (nb + 1),
+                      "%s: with pre_scale, live must be the forward's int32 [N*NC*(1 + bricks)] buffer (it says which slots of "
+                      "v_scratch hold values)", op);
+        live_p = (const int *)live->data;
+    }
+    const int lines = (int)(ps_scratch->size[0] / (2 * imgs));
+    const bool big = imgs * (int64_t)rr >= 65536 * 4;
+    const int nblk = big ? (rr + 255) / 256 : (rr + 63) / 64;               // blocks of seg_combine_bwd_kernel per image
+    GENRE_REQUIRE(tr_scratch->size[0] >= ps_scratch->size[0] + (int64_t)imgs * nblk,
+                  "%s: tr_scratch must hold numel(ps_scratch) + N*NC * ceil(R*R / 64) floats", op);
+    unsigned *bmax = (unsigned *)tr_scratch->data + ps_scratch->size[0];   // per image and block: max |g T|, behind the lines
+    GENRE_REQUIRE(is_f32(halo_scratch, 1) && is_contiguous(halo_scratch) &&
+                      halo_scratch->size[0] >= (int64_t)imgs * bwd_rows->size[0] * kHaloRec,
+                  "%s: halo_scratch must be a contiguous fp32 buffer of >= N*NC * rows * %d elements", op, kHaloRec);
+    const dim3 rgrid((unsigned)bwd_rows->size[0], D.N, D.NC);
+    seg_zero_split_kernel<<<rgrid, kNT, 0, st>>>(D, view5(grad_vox), (const int4 *)bwd_rows->data);
+    GENRE_LAUNCH_CHECK("render_seg backward (zero split bricks)");
+    if (big)
+        seg_combine_bwd_kernel<256><<<dim3((rr + 255) / 256, D.N, D.NC), 256, 0, st>>>(
+            D, (const float2 *)ps_scratch->data, (const int *)ray_nseg->data, (const double2 *)ray_pre->data, lines,
+            view4(grad_out), (float2 *)tr_scratch->data, live_p, nb, (const float2 *)line_w->data, bmax);
+    else
+        seg_combine_bwd_kernel<64><<<dim3((rr + 63) / 64, D.N, D.NC), 64, 0, st>>>(
+            D, (const float2 *)ps_scratch->data, (const int *)ray_nseg->data, (const double2 *)ray_pre->data, lines,
+            view4(grad_out), (float2 *)tr_scratch->data, live_p, nb, (const float2 *)line_w->data, bmax);
+    GENRE_LAUNCH_CHECK("render_seg backward (segment chains)");
+    constexpr size_t lds = (size_t)kATn * sizeof(double) + kMaxZR * sizeof(float);
+    static_assert(lds <= 64 * 1024, "dynamic LDS beyond 64 KB needs reserve_lds");
+    seg_scatter_kernel<<<rgrid, kNTs, lds, st>>>(
+        D, view5(vox), view5(grad_vox), (const double *)dirs->data, (const float *)depth_weight->data,
+        (const int4 *)bwd_rows->data, (const int4 *)segs->data, (int)segs->size[0], (const float2 *)tr_scratch->data, lines,
+        (const float *)v_scratch->data, live_p, bmax, nblk, (float *)halo_scratch->data);
+    GENRE_LAUNCH_CHECK("render_seg backward (scatter)");
+    seg_halo_kernel<<<rgrid, kNT, 0, st>>>(D, view5(grad_vox), (const int4 *)bwd_rows->data, (const float *)halo_scratch->data, live_p);
+    GENRE_LAUNCH_CHECK("render_seg backward (halo records)");
     return 1;
 }

@@ -201,7 +201,7 @@ def seg_tables_for(vox_shape, device, dirs64, depth_weight):
             return _seg_tables.build_seg_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, max_seg=max_seg,
                                                 split=split)
         build.__module__ = _seg_tables.__name__
-        np_t = _disk_cached("seg", (tuple(vox_shape[2:]), split, max_seg, _seg_tables.BRICK, "r6d"), [d64, dw], build)
+        np_t = _disk_cached("seg", (tuple(vox_shape[2:]), split, max_seg, _seg_tables.BRICK, _seg_tables.BWD_SPLIT, "r6f"), [d64, dw], build)
         t = {"smax": int(np_t["smax"][0])}
         for k, v in np_t.items():
             if k == "smax":
@@ -214,25 +214,16 @@ def seg_tables_for(vox_shape, device, dirs64, depth_weight):
     return t
 
 
-def bwd_slots_for(vox_shape, device, dirs64, depth_weight):
-    """chunk_slot of the standard-layout backward's segment form: for every entry (ray, k) of the backward's sample list
-    (tables_for: bwd_chunks) the position of that sample in the per-segment slots of the saved values / of dL/dp -- segment
-    index in the segment tables' order * 16 + index inside the segment.  Built once per (geometry, table variant), cached"""
-    ts = seg_tables_for(vox_shape, device, dirs64, depth_weight)
-    if "bwd_slot" not in ts:
-        t = tables_for(vox_shape, device, dirs64, depth_weight.shape[0])
-        segs = ts["segs"].cpu().numpy().astype(np.int64)
-        z_res, rr = depth_weight.shape[0], dirs64.shape[0] * dirs64.shape[0]
-        slot_of = np.full((rr * z_res,), -1, np.int64)
-        q, k0, L = segs[:, 0], segs[:, 1] & 255, segs[:, 1] >> 8
-        for i in range(int(L.max())):
-            m = L > i
-            slot_of[q[m] * z_res + k0[m] + i] = np.nonzero(m)[0] * 16 + i
-        w = t["bwd_chunks"].cpu().numpy().view(np.uint32).astype(np.int64)
-        slots = slot_of[(w >> 8) * z_res + (w & 255)]
-        assert (slots >= 0).all(), "a listed sample lies in no segment"
-        ts["bwd_slot"] = torch.from_numpy(slots.astype(np.int32)).to(device)
-    return ts["bwd_slot"]
+def seg_tr_scratch(ps, vox, dirs64):
+    """tr_scratch of render_seg_backward: a (g T, w - R) pair per scratch line like ps, and behind them one word per image and
+    block of the per-ray kernel (at most ceil(R*R / 64): include/genre_hip.h)"""
+    imgs, rr = vox.shape[0] * vox.shape[1], dirs64.shape[0] * dirs64.shape[0]
+    return torch.empty((ps.numel() + imgs * (-(-rr // 64)),), dtype=torch.float32, device=ps.device)
+
+
+def seg_halo_scratch(ts, vox):
+    """halo_scratch of render_seg_backward: 832 floats per image and row of bwd_rows"""
+    return torch.empty((vox.shape[0] * vox.shape[1] * ts["bwd_rows"].shape[0] * 832,), dtype=torch.float32, device=vox.device)
 
 
 def _bm_tables_module():
@@ -498,16 +489,11 @@ class RenderSphericalFused(Function):
                                    ctx.pre_scale, t["pull_code"])
             return grad_vox, None, None, None, None
         vox, dirs64, depth_weight, ps, v = ctx.saved_tensors
-        z_res = depth_weight.shape[0]
-        t = tables_for(vox.shape, vox.device, dirs64, z_res)
         ts = seg_tables_for(vox.shape, vox.device, dirs64, depth_weight)
-        rays = vox.shape[0] * vox.shape[1] * dirs64.shape[0] * dirs64.shape[0]
         grad_vox = torch.empty(vox.shape, dtype=vox.dtype, device=vox.device)
-        imgs = vox.shape[0] * vox.shape[1]
-        scratch = torch.empty((imgs * ts["segs"].shape[0] * 16 + imgs,), dtype=torch.float32, device=vox.device)
-        # segment form of the dL/dp phase (csrc/sph_render_seg.hip), then the brick-owned accumulation (csrc/sph_render.hip)
-        lib.render_spherical_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox,
-                                      scratch, t["bwd_table"], t["bwd_chunks"], v, None, ctx.pre_scale, ctx.live,
-                                      ts["segs"], ts["ray_nseg"], ts["ray_pre"], ts["line_w"], ps, torch.empty_like(ps),
-                                      bwd_slots_for(vox.shape, vox.device, dirs64, depth_weight))
+        # per-ray chains over the (P, S) pairs, then one pass over the segments: dL/dp from the saved values, scattered into the
+        # bricks' tiles (csrc/sph_render_seg.hip)
+        lib.render_seg_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox, ts["bwd_rows"], ts["segs"],
+                                ts["ray_nseg"], ts["ray_pre"], ts["line_w"], ps, seg_tr_scratch(ps, vox, dirs64), v,
+                                seg_halo_scratch(ts, vox), ctx.pre_scale, ctx.live)
         return grad_vox, None, None, None, None

@@ -22,6 +22,8 @@ Formats (int32 unless noted; see include/genre_hip.h, "segment renderer"):
   ray_pre   float64 [RR,2]  (transmittance, partial sum) of the samples before the ray enters the volume (p = clamp(0) = 1e-5)
   kin       [RR]       first in-volume sample of every ray
   line_w    float32 [smax*RR,2]  per scratch line: depth weight of its segment's first and of its last sample
+  bwd_rows  [rows,4]   like seg_rows with pieces of <= bwd_split segments; bit 30 of the last column: the brick is split over several rows,
+                        bit 31: the first of them -- the workgroups of the backward (seg_scatter_kernel)
   smax      [1]        scratch lines per ray (= max(ray_nseg)): the scratch holds smax*RR (P, S) pairs per image
 """
 import os
@@ -33,6 +35,7 @@ MAX_SEG = 16                    # samples per segment at most (a run of n is cut
 MAX_SEG_SMALL = int(os.environ.get("GENRE_SEG_MAXSEG_SMALL", "16"))     # ... for batches of fewer than SMALL_BATCH images (A/B switch)
 SPLIT = int(os.environ.get("GENRE_SEG_SPLIT", "1024"))                  # segments per row at most ...
 SPLIT_SMALL = int(os.environ.get("GENRE_SEG_SPLIT_SMALL", "256"))       # ... when fewer than SMALL_BATCH images have to fill 256 CUs
+BWD_SPLIT = int(os.environ.get("GENRE_SEG_BWD_SPLIT", "4096"))          # segments per row of the backward at most
 FIXED_COST = 6                  # weight of a row beyond its march steps (tile staging), in 64-segment march steps
 LO = np.float32(1e-5)           # spherical_proj.py:66
 
@@ -56,9 +59,10 @@ def sample_cells(X, Y, Z, dirs64, z_res):
     return cells, inside
 
 
-def build_seg_tables(X, Y, Z, dirs64, z_res, depth_weight, max_seg=MAX_SEG, split=SPLIT):
+def build_seg_tables(X, Y, Z, dirs64, z_res, depth_weight, max_seg=MAX_SEG, split=SPLIT, bwd_split=None):
     R = dirs64.shape[0]
     RR = R * R
+    bwd_split = BWD_SPLIT if bwd_split is None else bwd_split
     assert z_res <= 256 and RR < (1 << 24) and 1 <= max_seg <= 255 and max(X, Y, Z) <= 1023 * BRICK
     dw = np.asarray(depth_weight, np.float32).reshape(-1)
     assert dw.shape[0] == z_res
@@ -108,24 +112,31 @@ def build_seg_tables(X, Y, Z, dirs64, z_res, depth_weight, max_seg=MAX_SEG, spli
     sb = np.searchsorted(seg_brick[order], np.arange(nbx * nby * nbz), side="left")
     se = np.searchsorted(seg_brick[order], np.arange(nbx * nby * nbz), side="right")
     lens = seg_len[order]
-    rows = []
-    for bid in range(nbx * nby * nbz):
-        b0, b1 = int(sb[bid]), int(se[bid])
-        cnt = b1 - b0
-        nparts = max(1, -(-cnt // split))
-        size = -(-cnt // nparts) if cnt else 0
-        size = -(-size // 64) * 64                                          # whole waves
-        for r0 in (range(b0, b1, size) if cnt else [b0]):
-            r1 = min(r0 + size, b1) if cnt else b0
-            steps = int(lens[r0:r1:64].sum())                               # a wave marches its longest (= first) segment
-            bxyz = (bid // (nby * nbz)) | ((bid // nbz) % nby) << 10 | (bid % nbz) << 20      # (the kernel divides nothing)
-            rows.append((bid, r0, r1, bxyz, steps + FIXED_COST))
-    rows.sort(key=lambda r: -r[4])
-    seg_rows = np.asarray([r[:4] for r in rows], np.int32).reshape(-1, 4)
+    def rows_for(split, flag_split):
+        rows = []
+        for bid in range(nbx * nby * nbz):
+            b0, b1 = int(sb[bid]), int(se[bid])
+            cnt = b1 - b0
+            nparts = max(1, -(-cnt // split))
+            size = -(-cnt // nparts) if cnt else 0
+            size = -(-size // 64) * 64                                      # whole waves
+            for r0 in (range(b0, b1, size) if cnt else [b0]):
+                r1 = min(r0 + size, b1) if cnt else b0
+                steps = int(lens[r0:r1:64].sum())                           # a wave marches its longest (= first) segment
+                bxyz = (bid // (nby * nbz)) | ((bid // nbz) % nby) << 10 | (bid % nbz) << 20  # (the kernel divides nothing)
+                if flag_split and nparts > 1:
+                    bxyz |= (1 << 30) | ((1 << 31) if r0 == b0 else 0)      # split brick; the first of its rows
+                rows.append((bid, r0, r1, bxyz, steps + FIXED_COST))
+        rows.sort(key=lambda r: -r[4])
+        return (np.asarray([r[:4] for r in rows], np.int64).reshape(-1, 4) & 0xffffffff).astype(np.uint32).view(np.int32)
+    seg_rows = rows_for(split, False)
+    # the backward's rows: the same segments, longer pieces (a workgroup of the backward carries a 46 KB accumulation tile that it
+    # flushes with atomics when its brick is split: fewer, longer rows), the split flag in bit 30
+    bwd_rows = rows_for(bwd_split, True)
     # per scratch line: the depth weights of its segment's first and last sample (the kernels keep a segment's partial sum and the
     # chain's R relative to them: csrc/sph_render_seg.hip, seg_combine_kernel)
     line_w = np.zeros((max(smax, 1) * RR, 2), np.float32)
     line_w[line, 0] = dw[seg_k0]
     line_w[line, 1] = dw[seg_k0 + seg_len - 1]
     return dict(segs=segs, seg_rows=seg_rows, ray_nseg=ray_nseg, ray_pre=ray_pre, line_w=line_w, kin=kin,
-                smax=np.asarray([smax], np.int32))
+                bwd_rows=bwd_rows, smax=np.asarray([smax], np.int32))

@@ -304,12 +304,6 @@ int genre_render_spherical_forward(const genre_tensor *vox, const genre_tensor *
  *    the samples are not recomputed from vox.
  *    live (optional; needs v_scratch + kin and pre_scale != 0): the forward's pass words, see above -- where the clamp
  *    blocks everything the adjoint is a select of zeros, so a non-finite upstream gradient does not reach a dead image.
- *    segs, ray_nseg, ray_pre, line_w, ps_scratch, tr_scratch, chunk_slot (ABI 5; all seven, with v_scratch): the SEGMENT form of the
- *    dL/dp phase, for a forward by genre_render_seg_forward -- the tables of that op, the (P, S) pairs it left in ps_scratch, the
- *    sample values it left in v_scratch (only in tiles a gradient can come back through), fp32 tr_scratch [>= numel(ps_scratch)]
- *    (receives (g T in front, w_last - R behind) of every segment) and chunk_slot int32 [S]: for every chunk_list entry the position of
- *    that sample in the per-segment slots, segment index (order of segs) * 16 + index inside the segment.  Per-ray chains, then
- *    dL/dp per segment into dp_scratch (then fp32 [>= N*NC*nseg*16 + N*NC]); kin is not used.
  *  - those pointers NULL: global-atomic scatter fallback (grad_vox must be
  *    contiguous, 16-byte aligned, numel % 4 == 0). */
 int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor *dirs,
@@ -317,11 +311,7 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
                                     const genre_tensor *grad_vox, const genre_tensor *dp_scratch,
                                     const genre_tensor *brick_table, const genre_tensor *chunk_list,
                                     const genre_tensor *v_scratch, const genre_tensor *kin,
-                                    const genre_tensor *live, const genre_tensor *segs,
-                                    const genre_tensor *ray_nseg, const genre_tensor *ray_pre,
-                                    const genre_tensor *line_w, const genre_tensor *ps_scratch,
-                                    const genre_tensor *tr_scratch, const genre_tensor *chunk_slot, float pre_scale,
-                                    void *stream);
+                                    const genre_tensor *live, float pre_scale, void *stream);
 
 /* ---- segment renderer: the forward for the standard (NCXYZ) layout (ABI 5; csrc/sph_render_seg.hip) ----------------
  *
@@ -347,7 +337,7 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  * v_scratch (optional; with pre_scale != 0 also pass `live`): fp32 [>= N*NC*nseg*16], 16-byte aligned, one 64-byte slot per image
  *   and segment (table order) -- a backward will follow: receives the raw (un-clamped) values of the samples of every segment of
  *   every tile some voxel of which passes the pre_scale clamp (every tile when pre_scale == 0): what
- *   genre_render_spherical_backward's segment form reads.  ps_scratch is the other half of the saved state.  (`live` then
+ *   genre_render_seg_backward reads.  ps_scratch is the other half of the saved state.  (`live` then
  *   carries two bits per brick: bit 0 a voxel of the brick passes, bit 1 a voxel of its tile does = its values were saved.) */
 int genre_render_seg_forward(const genre_tensor *vox, const genre_tensor *dirs, const genre_tensor *depth_weight,
                              const genre_tensor *out, const genre_tensor *seg_rows, const genre_tensor *segs,
@@ -355,6 +345,28 @@ int genre_render_seg_forward(const genre_tensor *vox, const genre_tensor *dirs, 
                              const genre_tensor *ps_scratch, const genre_tensor *live, const genre_tensor *occ,
                              const genre_tensor *ps_empty,
                              const genre_tensor *v_scratch, float pre_scale, int occ_cell, void *stream);
+
+/* The backward of genre_render_seg_forward (render_spherical.backward of spherical_proj.py:62-72, with the caller's clamp and
+ * sph_pad folded in as in the forward): grad_vox (contiguous, every voxel written) from grad_out and the state the forward left --
+ * ps_scratch (the pairs), v_scratch (the saved sample values), live (with pre_scale: which tiles' values exist) -- with the
+ * forward's tables plus
+ *   bwd_rows  int32 [rows,4]    (brick, seg begin, seg end, bx | by << 10 | bz << 20 | split << 30 | first << 31): one workgroup each,
+ *                               heaviest first; every brick in >= 1 row; split = the brick's segments are divided over several
+ *                               rows, first = the first of them (toolbox/_seg_tables.py)
+ *   halo_scratch fp32 [>= N*NC * rows * 832]: per image and row the sums of the 817 tile cells beyond the brick's high faces
+ *   tr_scratch fp32 [>= numel(ps_scratch) + N*NC * ceil(R*R / 64)], 8-byte aligned: receives (g T in front, w_last - R behind) of
+ *                               every segment and, behind them, per image the per-block maxima of |g T| (the fixed-point scale).
+ * Per-ray chains in fp64, then one pass over the segments: dL/dp of every sample and its trilinear adjoint into the brick's tile
+ * (64-bit fixed point in LDS, scaled per image), flushed through the clamp's adjoint: a brick's row writes the brick's voxels, the
+ * cells beyond the high faces go through halo_scratch and are added onto the neighbours' low faces behind those stores with fp32
+ * atomics, as are all rows of a split brick (the order of at most eight addends is not fixed: the last bit of a voxel on a
+ * brick's low face can differ between runs). */
+int genre_render_seg_backward(const genre_tensor *vox, const genre_tensor *dirs, const genre_tensor *depth_weight,
+                              const genre_tensor *grad_out, const genre_tensor *grad_vox, const genre_tensor *bwd_rows,
+                              const genre_tensor *segs, const genre_tensor *ray_nseg, const genre_tensor *ray_pre,
+                              const genre_tensor *line_w, const genre_tensor *ps_scratch, const genre_tensor *tr_scratch,
+                              const genre_tensor *v_scratch, const genre_tensor *halo_scratch, const genre_tensor *live,
+                              float pre_scale, void *stream);
 
 /* ---- batch-minor tile renderer (extension; csrc/sph_render_bm.hip) ------------------------------
  *

@@ -36,7 +36,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAI
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU -d "$OUT/pmc_s2" -o sq2 -- python "$ROOT/profiles/pmc_targets.py" "$B" > /dev/null 2> "$OUT/pmc_s2.err"
 S1=$(ls "$OUT"/pmc_s1/sq1_results.db "$OUT"/pmc_s1/*/sq1_results.db 2>/dev/null | head -1)
 S2=$(ls "$OUT"/pmc_s2/sq2_results.db "$OUT"/pmc_s2/*/sq2_results.db 2>/dev/null | head -1)
-python "$ROOT/profiles/pmc_sq_table.py" $S1 $S2 -- bm_scatter_kernel bm_sample_kernel bm_combine cam_brick seg_sample seg_combine render_sample_brick render_bwd_brick cam_backward > "$OUT/sq_counters.txt" 2>&1
+python "$ROOT/profiles/pmc_sq_table.py" $S1 $S2 -- bm_scatter_kernel bm_sample_kernel bm_combine cam_brick seg_sample seg_combine seg_scatter cam_backward > "$OUT/sq_counters.txt" 2>&1
 # the bench line of the same build reads the table just measured (roofline.traffic must not be null in a committed line)
 cp "$OUT/pmc_hbm_traffic.json" "$ROOT/profiles/${TAG}_pmc_hbm_traffic.json"
 cd "$ROOT" && T0=$(date +%s) && python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench.py wall time: $(( $(date +%s) - T0 )) s" >> "$OUT/bench.err"

@@ -9,7 +9,7 @@ TWO = ("genre", "soft")
 PHASES = {
     "seg_combine_kernel": ("genre", "dense", "soft"),
     "bm_combine_fwd_kernel": TWO, "bm_combine_bwd_kernel": TWO, "bm_scatter_kernel": TWO,
-    "bm_zero_shared_kernel": TWO, "seg_combine_bwd_kernel": TWO, "seg_dp_kernel": TWO,
+    "bm_zero_shared_kernel": TWO, "seg_combine_bwd_kernel": TWO, "seg_scatter_kernel": TWO,
     "render_bwd_brick_kernel": TWO, "zero_shared_bricks_kernel": TWO,
 }
 
@@ -27,7 +27,7 @@ def split(name, vals):
             per = len(vals) // 2
             vals = vals[len(vals) - 2 * per:]
             return [("@genre", vals[:per]), ("@soft", vals[per:])]
-        return [("@dense", vals[1:] if len(vals) > 1 else vals)]        # (the first: the constant volume of the occupancy hint)
+        return [("@dense", vals)]
     for key, phases in PHASES.items():
         if key in name and len(vals) >= len(phases):
             per = len(vals) // len(phases)

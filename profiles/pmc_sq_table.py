@@ -45,11 +45,14 @@ merged = collections.defaultdict(dict)
 for db in dbs:
     for k, counters in read(db).items():
         for c, vals in counters.items():
-            merged[k][c] = (sum(vals) / len(vals), len(vals))
+            if vals:
+                merged[k][c] = (sum(vals) / len(vals), len(vals))
 for k in sorted(merged, key=short):
     if not any(p in k for p in pats):
         continue
     c = merged[k]
+    if not c:
+        continue
     print("# %s   (%d dispatches)" % (short(k), max(n for _, n in c.values())))
     wc = c.get("SQ_WAVE_CYCLES", (0, 0))[0]
     for name in sorted(c):

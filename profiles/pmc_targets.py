@@ -66,10 +66,9 @@ ps_std = torch.empty((B * S["smax"] * 128 * 128 * 2,), device=dev)
 occ_std = _fused_render.occupancy_hint_std(proj_std, S, mod._dirs64, mod.depth_weight, 50.0, lib, with_grad=True)
 
 
-tr_std = torch.empty_like(ps_std)
+tr_std = _fused_render.seg_tr_scratch(ps_std, proj_std, mod._dirs64)
+halo_std = _fused_render.seg_halo_scratch(S, proj_std)
 vseg = torch.empty((B * S["segs"].shape[0] * 16,), device=dev)
-dpseg = torch.empty((B * S["segs"].shape[0] * 16 + max(4, B),), device=dev)
-bslot = _fused_render.bwd_slots_for(proj_std.shape, dev, mod._dirs64, mod.depth_weight)
 
 
 def seg_fwd(vol, hint, save=True):
@@ -97,8 +96,8 @@ for vol_std, vol_bm in ((proj_std, proj_bm), (None, None), (soft_std, soft_bm)):
         continue
     for _ in range(ITERS):
         seg_fwd(vol_std, vol_std is proj_std)
-        lib.render_spherical_backward(vol_std, dirs, mod.depth_weight, gout, gvox, dpseg, T["bwd_table"], T["bwd_chunks"],
-                                      vseg, None, 50.0, live, S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps_std, tr_std, bslot)
+        lib.render_seg_backward(vol_std, dirs, mod.depth_weight, gout, gvox, S["bwd_rows"], S["segs"], S["ray_nseg"], S["ray_pre"],
+                                S["line_w"], ps_std, tr_std, vseg, halo_std, 50.0, live)
         if TB is not None:
             if vol_bm is proj_bm:            # (the raw-ABI camera calls above dropped the layer's hint: same values, words of the last call)
                 _fused_render.attach_hint(proj_bm, tl_bm, 128)

@@ -15,7 +15,7 @@ from test_tables import brute_force
 def test_segments_partition_the_in_volume_samples(res, sph, zr, max_seg, split):
     mod = G.render_spherical(sph_res=sph, z_res=zr, fused=False)
     dirs = mod._dirs64.numpy()
-    t = S.build_seg_tables(res, res, res, dirs, zr, mod.depth_weight.numpy(), max_seg=max_seg, split=split)
+    t = S.build_seg_tables(res, res, res, dirs, zr, mod.depth_weight.numpy(), max_seg=max_seg, split=split, bwd_split=2 * split)
     cells, inside = brute_force(res, res, res, dirs, zr)
     RR = sph * sph
     assert np.array_equal(inside, np.arange(zr)[None, :] >= t["kin"][:, None])
@@ -52,6 +52,19 @@ def test_segments_partition_the_in_volume_samples(res, sph, zr, max_seg, split):
         covered[beg:end] += 1
         assert (brick[beg:end] == b).all() and end - beg <= -(-split // 64) * 64
         assert (np.diff(L[beg:end]) <= 0).all()
+    assert (covered == 1).all()
+    # the backward's rows: the same segments in longer pieces, bit 30 of the last column set on every row of a split brick
+    brows = t["bwd_rows"]
+    covered[:] = 0
+    per_brick = np.bincount(brows[:, 0], minlength=nb ** 3)
+    for b, beg, end, packed in brows:
+        packed = int(packed) & 0xffffffff
+        assert (packed & 0x3fffffff) == (b // (nb * nb)) | ((b // nb) % nb) << 10 | (b % nb) << 20
+        assert ((packed >> 30) & 1) == (per_brick[b] > 1)
+        first = bool(packed >> 31)
+        assert first == (per_brick[b] > 1 and beg == brows[brows[:, 0] == b][:, 1].min())      # exactly one first row per split brick
+        covered[beg:end] += 1
+        assert (brick[beg:end] == b).all()
     assert (covered == 1).all()
 
 

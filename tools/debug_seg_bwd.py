@@ -36,22 +36,9 @@ for scale in (0.0, 50.0):
     k = torch.arange(256, device=dev)
     inside = (k[None, :] >= kin[:, None]).repeat(n, 1)
     print('scale', scale, 'map diff', (out - out2).abs().max().item())
-    gv_new = torch.empty_like(vox); sc_new = torch.zeros((n * S["segs"].shape[0] * 16 + n,), device=dev); tr = torch.zeros_like(ps)
-    bslot = F.bwd_slots_for(vox.shape, dev, mod._dirs64, mod.depth_weight)
-    lib.render_spherical_backward(vox, dirs, mod.depth_weight, g, gv_new, sc_new, T["bwd_table"], T["bwd_chunks"], v_new, None, scale, live,
-                                  S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, tr, bslot)
+    gv_new = torch.empty_like(vox); tr = F.seg_tr_scratch(ps, vox, mod._dirs64)
+    lib.render_seg_backward(vox, dirs, mod.depth_weight, g, gv_new, S["bwd_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, tr, v_new, F.seg_halo_scratch(S, vox), scale, live)
     print("   grad diff max %.4g of %.4g" % ((gv_old - gv_new).abs().max().item(), gv_old.abs().max().item()))
-    w = T["bwd_chunks"].view(torch.int32).long() & 0xffffffff
-    qq, kk = w >> 8, w & 255
-    nseg = S["segs"].shape[0]
-    for im in range(n):
-        vo = v_old.view(n, -1)[im][qq * 256 + kk]; vn = v_new.view(n, -1)[im][bslot.long()]
-        do = sc_old[:rays * 256].view(n, -1)[im][qq * 256 + kk]; dn = sc_new[:n * nseg * 16].view(n, -1)[im][bslot.long()]
-        bad = (vo != vn)
-        print("   img", im, "saved values differ at", bad.sum().item(), "of", bad.numel(), "max", (vo - vn).abs().max().item(),
-              "| dL/dp diff max %.4g of %.4g" % ((do - dn).abs().max().item(), do.abs().max().item()))
-        i = (do - dn).abs().argmax().item()
-        print("      worst entry ray", qq[i].item(), "k", kk[i].item(), "old", do[i].item(), "new", dn[i].item(), "v", vo[i].item(), vn[i].item())
     if len(sys.argv) > 1 and sys.argv[1] == "sharp" and scale:
         from oracle.torch_oracle import RenderSphericalExact
         x = vox[:1].cpu().clone().requires_grad_(True)
@@ -69,13 +56,3 @@ for scale in (0.0, 50.0):
                   (ex[ix, iy, iz].item(), gv[0, 0, ix, iy, iz].item(), gv_old[0, 0, ix, iy, iz].item()), "value", vox[0, 0, ix, iy, iz].item() * scale)
             top = torch.topk(err.flatten(), 8)
             print("      top errors", [("%.2e" % v) for v in top.values.tolist()], [(j // 16384, (j // 128) % 128, j % 128) for j in top.indices.tolist()])
-        # the pole rays: per-sample dL/dp, old vs new
-        dirs_h = mod._dirs64.cpu().numpy().reshape(-1, 3)
-        for q in (5, 127 * 128 + 5):
-            sel = (qq == q).nonzero().flatten()
-            ks = kk[sel]; order = ks.argsort(); sel = sel[order]; ks = ks[order]
-            do = sc_old[:rays * 256].view(n, -1)[0][q * 256 + ks].double().cpu(); dn = sc_new[:n * nseg * 16].view(n, -1)[0][bslot.long()[sel]].double().cpu()
-            print("    ray", q, "dir", dirs_h[q], "listed samples", len(sel), "k range", ks.min().item(), ks.max().item())
-            rel = ((dn - do) / do.abs().clamp(min=1e-30))
-            print("      rel diff new-old by sample (first 40):", ["%.1e" % v for v in rel[:40].tolist()])
-            print("      old", ["%.6g" % v for v in do[:8].tolist()], "new", ["%.6g" % v for v in dn[:8].tolist()])
