@@ -399,7 +399,9 @@ void launch_seg_sample(const RenderDims &D, const genre_tensor *vox, const genre
 // (sample, brick it touches)) for forwards by genre_render_seg_forward; needs the sample values only where a gradient can come back.
 constexpr int kMaxRaySegs = 32;
 
-template <int NT>
+// (NB: lines requested together: 8 for large batches -- registers, occupancy --, all 32 for small ones, where a ray's dependent round
+// trips are the kernel's duration)
+template <int NT, int NB>
 __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const float2 *__restrict__ ps,
                                                               const int *__restrict__ ray_nseg,
                                                               const double2 *__restrict__ ray_pre, int lines, View4 gout,
@@ -415,12 +417,6 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
     const int n = ray ? min(ray_nseg[q], kMaxRaySegs) : 0;
     const float2 *__restrict__ b = ps + (size_t)img * lines + q;
     float2 *__restrict__ t = tr + (size_t)img * lines + q;
-    float2 v[kMaxRaySegs], lw[kMaxRaySegs];                              // (P, S), (first, last depth weight) of the ray's segments
-#pragma unroll
-    for (int u = 0; u < kMaxRaySegs; u++) {
-        v[u] = b[(size_t)min(u, max(n - 1, 0)) * rr];
-        lw[u] = line_w[(size_t)min(u, max(n - 1, 0)) * rr + q];
-    }
     // gradient of the ray's value: the sum over its padded positions (sph_pad, spherical_proj.py:21-28)
     const float *gi = gout.p + blockIdx.y * gout.s0 + blockIdx.z * gout.s1;
     int i = (int)(((float)q + 0.5f) * __builtin_amdgcn_rcpf((float)D.R));
@@ -431,26 +427,66 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
     else {
         int r_lo, r_n, c0, c1;
         pad_span(D.R, D.pad, i, j, r_lo, r_n, c0, c1);
-        for (int r = 0; r < r_n; r++) {
-            g += (double)gi[(r_lo + r) * gout.s2 + c0 * gout.s3];
-            if (c1 >= 0) g += (double)gi[(r_lo + r) * gout.s2 + c1 * gout.s3];
+        // (eight rows in flight, both columns, loads unconditional: a pole row's 17 x 2 positions one dependent load at a time were
+        // most of this kernel's duration at batch 1)
+        const int c1c = c1 >= 0 ? c1 : c0;
+        for (int r = 0; r < r_n; r += 8) {
+            float ga[8], gb2[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int rw = r_lo + min(r + u, r_n - 1);
+                ga[u] = gi[rw * gout.s2 + c0 * gout.s3];
+                gb2[u] = gi[rw * gout.s2 + c1c * gout.s3];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (r + u < r_n) {
+                    g += (double)ga[u];
+                    if (c1 >= 0) g += (double)gb2[u];
+                }
+            }
         }
     }
+    // Two passes over the ray's lines, eight loads in flight each (the (P, S) pairs of all 32 possible segments plus their depth
+    // weights held in registers -- 160 of them -- ran this kernel at a third of the speed)
+    const int nl = max(n - 1, 0);
     double T = ray_pre[q].x;
     float gT[kMaxRaySegs];
 #pragma unroll
-    for (int u = 0; u < kMaxRaySegs; u++) {
-        gT[u] = (float)(g * T);
-        if (u < n) T *= (double)v[u].x;
+    for (int s0 = 0; s0 < kMaxRaySegs; s0 += NB) {
+        if (s0 < n || s0 == 0) {
+            float P[NB];
+#pragma unroll
+            for (int u = 0; u < NB; u++) P[u] = b[(size_t)min(s0 + u, nl) * rr].x;
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                gT[s0 + u] = (float)(g * T);
+                if (s0 + u < n) T *= (double)P[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NB; u++) gT[s0 + u] = 0.f;
+        }
     }
     // R in fp64; what leaves is the DIFFERENCE seg_scatter_kernel starts from, w_last - R behind the segment (rounded to fp32 relative
     // to itself, not to a depth).  In front of a segment: R = w_first + S + P (R behind - w_first)  (seg_combine_kernel: S is relative)
     double R = 1.0;                                                      // behind the last sample: prod(1-p) * 1  (:69-71)
 #pragma unroll
-    for (int u = kMaxRaySegs - 1; u >= 0; u--) {
-        if (u < n) {
-            t[(size_t)u * rr] = make_float2(gT[u], (float)((double)lw[u].y - R));
-            R = (double)lw[u].x + (double)v[u].y + (double)v[u].x * (R - (double)lw[u].x);
+    for (int s0 = kMaxRaySegs - NB; s0 >= 0; s0 -= NB) {
+        if (s0 < n) {
+            float2 v[NB], lw[NB];                                          // (P, S), (first, last depth weight)
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                v[u] = b[(size_t)min(s0 + u, nl) * rr];
+                lw[u] = line_w[(size_t)min(s0 + u, nl) * rr + q];
+            }
+#pragma unroll
+            for (int u = NB - 1; u >= 0; u--) {
+                if (s0 + u < n) {
+                    t[(size_t)(s0 + u) * rr] = make_float2(gT[s0 + u], (float)((double)lw[u].y - R));
+                    R = (double)lw[u].x + (double)v[u].y + (double)v[u].x * (R - (double)lw[u].x);
+                }
+            }
         }
     }
     // this block's max |g T| in front of a ray's first segment (T only falls along a ray), as a bit pattern -- non-negative floats
@@ -716,6 +752,16 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const bool on = dp != 0.0f;                                   // (NaN != 0: a non-finite gradient goes through)
 #if GENRE_SCATTER_AB == 5                                                 // (A/B: one spill per segment)
             if (on) cur = idx;
+#elif GENRE_SCATTER_AB == 9                                               // (A/B: eight atomics per sample, no register sums)
+            if (on) {
+                unsigned long long *tp = tile + idx;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    atomicAdd(tp + ((j & 1) ? kAT * kAT : 0) + ((j & 2) ? kAT : 0) + ((j & 4) ? 1 : 0),
+                              (unsigned long long)(__double_as_longlong(fma((double)(corner_w(c, j) * dp), scale, 6755399441055744.0)) -
+                                                   0x4338000000000000LL));
+            }
+            continue;
 #else
             if (on && idx != cur) {
                 if (cur >= 0) spill();
@@ -730,6 +776,37 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         st = trimg[e.z];
         d2x = dirs[e.x * 3 + 0]; d2y = dirs[e.x * 3 + 1]; d2z = dirs[e.x * 3 + 2];
     }
+    // the clamp-mask values of the flush below: requested before the barrier (unconditional loads, addresses clamped into the volume)
+    const float *vb = vox.p + blockIdx.y * vox.s0 + blockIdx.z * vox.s1;
+    const bool v4 = D.sz == 1 && ((D.sx | D.sy) & 3) == 0 && (reinterpret_cast<uintptr_t>(vb) & 15) == 0 && gvox.s4 == 1 &&
+                    ((gvox.s2 | gvox.s3) & 3) == 0 && (reinterpret_cast<uintptr_t>(gb) & 15) == 0 && bz0 + kBrick <= D.Z;
+    constexpr int kFlushIt = (kHF * kHF * 4 + kNTs - 1) / kNTs;
+    float4 mvv[kFlushIt];
+    float mvz = 0.f;
+#pragma unroll
+    for (int i = 0; i < kFlushIt; i++) mvv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (D.pre_scale != 0.0f) {
+#pragma unroll
+        for (int i = 0; i < kFlushIt; i++) {
+            const int it = (int)threadIdx.x + i * kNTs;
+            const int r = it >> 2, lz0 = (it & 3) * 4;
+            const int lx = (int)(((float)r + 0.5f) * (1.0f / kHF)), ly = r - lx * kHF;
+            const int x = bx0 + lx, y = by0 + ly, z = bz0 + lz0;
+            const bool ok = it < kHF * kHF * 4 && x < D.X && y < D.Y;
+            const int base = ok ? x * D.sx + y * D.sy : 0;
+            if (v4) mvv[i] = *reinterpret_cast<const float4 *>(vb + base + (ok ? z : 0));
+            else {
+                float m[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) m[c] = vb[base + ((ok && z + c < D.Z) ? (z + c) * D.sz : 0)];
+                mvv[i] = make_float4(m[0], m[1], m[2], m[3]);
+            }
+        }
+        const int r = min((int)threadIdx.x, kHF * kHF - 1);
+        const int lx = (int)(((float)r + 0.5f) * (1.0f / kHF)), ly = r - lx * kHF;
+        const int x = bx0 + lx, y = by0 + ly, z = bz0 + kBrick;
+        mvz = vb[(x < D.X && y < D.Y && z < D.Z) ? x * D.sx + y * D.sy + z * D.sz : 0];
+    }
     __syncthreads();
 #if GENRE_SCATTER_AB == 6                                                 // (A/B: no flush)
     if (tile[threadIdx.x] != 0x123456789ull) return;
@@ -738,10 +815,7 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     // clamp(vox * pre_scale) -- a per-voxel select and scale, so it distributes over the partial sums of a voxel that several tiles
     // reach.  The brick's own voxels go to grad_vox (16-byte stores when the rows allow it; atomics in a split brick), the cells
     // beyond its high faces to the row's halo record (zeros for cells outside the volume) ----------------------------------------------
-    const float *vb = vox.p + blockIdx.y * vox.s0 + blockIdx.z * vox.s1;
     float *rec = halo + ((size_t)img * gridDim.x + blockIdx.x) * kHaloRec;
-    const bool v4 = D.sz == 1 && ((D.sx | D.sy) & 3) == 0 && (reinterpret_cast<uintptr_t>(vb) & 15) == 0 && gvox.s4 == 1 &&
-                    ((gvox.s2 | gvox.s3) & 3) == 0 && (reinterpret_cast<uintptr_t>(gb) & 15) == 0 && bz0 + kBrick <= D.Z;
     auto cell = [&](const unsigned long long raw, const float mv, const bool ok) {
         float val = (float)((double)(long long)raw * inv_scale);
         if (nonfinite) val = __uint_as_float(0x7fc00000u);                // the reference chain would return NaN here too
@@ -751,21 +825,15 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         return ok ? val : 0.0f;
     };
-    for (int it = threadIdx.x; it < kHF * kHF * 4; it += kNTs) {
+#pragma unroll
+    for (int i = 0; i < kFlushIt; i++) {
+        const int it = (int)threadIdx.x + i * kNTs;
+        if (it >= kHF * kHF * 4) break;
         const int r = it >> 2, lz0 = (it & 3) * 4;
         const int lx = (int)(((float)r + 0.5f) * (1.0f / kHF)), ly = r - lx * kHF;
         const int x = bx0 + lx, y = by0 + ly, z = bz0 + lz0;
         const bool in_xy = x < D.X && y < D.Y;
-        float mv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (D.pre_scale != 0.0f && in_xy) {
-            if (v4) {
-                const float4 t = *reinterpret_cast<const float4 *>(vb + x * D.sx + y * D.sy + z);
-                mv[0] = t.x; mv[1] = t.y; mv[2] = t.z; mv[3] = t.w;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; c++) mv[c] = z + c < D.Z ? vb[x * D.sx + y * D.sy + (z + c) * D.sz] : 0.f;
-            }
-        }
+        const float mv[4] = {mvv[i].x, mvv[i].y, mvv[i].z, mvv[i].w};
         const unsigned long long *tp = tile + ((lx + 1) * kAT + ly + 1) * kAT + lz0 + 1;
         float val[4];
 #pragma unroll
@@ -791,12 +859,12 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             for (int c = 0; c < 4; c++) h[c] = val[c];
         }
     }
-    for (int r = threadIdx.x; r < kHF * kHF; r += kNTs) {                 // the cells at local z = 16
+    if ((int)threadIdx.x < kHF * kHF) {                                   // the cells at local z = 16
+        const int r = threadIdx.x;
         const int lx = (int)(((float)r + 0.5f) * (1.0f / kHF)), ly = r - lx * kHF;
         const int x = bx0 + lx, y = by0 + ly, z = bz0 + kBrick;
         const bool ok = x < D.X && y < D.Y && z < D.Z;
-        const float mv = (D.pre_scale != 0.0f && ok) ? vb[x * D.sx + y * D.sy + z * D.sz] : 0.f;
-        const float val = cell(tile[((lx + 1) * kAT + ly + 1) * kAT + kBrick + 1], mv, ok);
+        const float val = cell(tile[((lx + 1) * kAT + ly + 1) * kAT + kBrick + 1], mvz, ok);
         rec[lx == kBrick ? kHaloX + ly * kHF + kBrick : (ly == kBrick ? kHaloY + lx * kHF + kBrick : kHaloZ + lx * kBrick + ly)] = val;
     }
 }
@@ -970,11 +1038,11 @@ extern "C" int genre_render_seg_backward(const genre_tensor *vox, const genre_te
     seg_zero_split_kernel<<<rgrid, kNT, 0, st>>>(D, view5(grad_vox), (const int4 *)bwd_rows->data);
     GENRE_LAUNCH_CHECK("render_seg backward (zero split bricks)");
     if (big)
-        seg_combine_bwd_kernel<256><<<dim3((rr + 255) / 256, D.N, D.NC), 256, 0, st>>>(
+        seg_combine_bwd_kernel<256, 8><<<dim3((rr + 255) / 256, D.N, D.NC), 256, 0, st>>>(
             D, (const float2 *)ps_scratch->data, (const int *)ray_nseg->data, (const double2 *)ray_pre->data, lines,
             view4(grad_out), (float2 *)tr_scratch->data, live_p, nb, (const float2 *)line_w->data, bmax);
     else
-        seg_combine_bwd_kernel<64><<<dim3((rr + 63) / 64, D.N, D.NC), 64, 0, st>>>(
+        seg_combine_bwd_kernel<64, 32><<<dim3((rr + 63) / 64, D.N, D.NC), 64, 0, st>>>(
             D, (const float2 *)ps_scratch->data, (const int *)ray_nseg->data, (const double2 *)ray_pre->data, lines,
             view4(grad_out), (float2 *)tr_scratch->data, live_p, nb, (const float2 *)line_w->data, bmax);
     GENRE_LAUNCH_CHECK("render_seg backward (segment chains)");

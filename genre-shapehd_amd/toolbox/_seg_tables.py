@@ -35,7 +35,8 @@ MAX_SEG = 16                    # samples per segment at most (a run of n is cut
 MAX_SEG_SMALL = int(os.environ.get("GENRE_SEG_MAXSEG_SMALL", "16"))     # ... for batches of fewer than SMALL_BATCH images (A/B switch)
 SPLIT = int(os.environ.get("GENRE_SEG_SPLIT", "1024"))                  # segments per row at most ...
 SPLIT_SMALL = int(os.environ.get("GENRE_SEG_SPLIT_SMALL", "256"))       # ... when fewer than SMALL_BATCH images have to fill 256 CUs
-BWD_SPLIT = int(os.environ.get("GENRE_SEG_BWD_SPLIT", "4096"))          # segments per row of the backward at most
+BWD_SPLIT = int(os.environ.get("GENRE_SEG_BWD_SPLIT", "4096"))          # segments per row of the backward at most ...
+BWD_SPLIT_SMALL = int(os.environ.get("GENRE_SEG_BWD_SPLIT_SMALL", "512"))   # ... for small batches (a row = one workgroup of 8 waves)
 FIXED_COST = 6                  # weight of a row beyond its march steps (tile staging), in 64-segment march steps
 LO = np.float32(1e-5)           # spherical_proj.py:66
 
