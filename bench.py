@@ -290,11 +290,11 @@ def kernel_table(G, dev, B):
                                               kernels="the same volume WITHOUT the occupancy words: every tile is read",
                                               pmc=["seg_sample_kernel<true, false, false>@dense", "seg_combine_kernel<256>@dense"],
                                               src=("common.hpp", "render_common.hpp", "sph_render_seg.hip"))
-        bwd_pmc = ["seg_combine_bwd_kernel<256, 8>", "seg_zero_split_kernel", "seg_scatter_kernel", "seg_halo_kernel"]
+        bwd_pmc = ["seg_combine_bwd_kernel<256, 8>", "seg_scatter_kernel", "seg_halo_kernel"]
         bwd_src = ("common.hpp", "render_common.hpp", "sph_render_seg.hip")
         tr_std = _fused_render.seg_tr_scratch(ps_std, proj, mod._dirs64)
         halo_std = _fused_render.seg_halo_scratch(S, proj)
-        vseg = torch.empty((B * S["segs"].shape[0] * 16,), device=dev)             # saved sample values: one 64-byte slot per segment
+        vseg = _fused_render.seg_v_scratch(S, B, dev)                               # saved sample values: 16 floats per segment
 
         def seg_fwd_grad(vol, hint=True):
             # the forward as autograd runs it when a gradient is wanted: + the raw sample values of the tiles a gradient can

@@ -58,13 +58,22 @@ constexpr int kNT = 256;                                                 // thre
 constexpr int kRowS = 20;                                                // floats per z-row of the LDS tile (see the staging)
 constexpr int kTileF = kTile * kTile * kRowS;                            // floats of the tile
 constexpr int kSegSlot = 16;                                             // samples per segment at most (toolbox/_seg_tables.py: MAX_SEG)
+// Saved sample values: 16 floats per image and segment, laid out so that the lanes of a wave -- 64 consecutive segments -- read or
+// write 1 KB of contiguous memory per instruction: segments in groups of 64 (4 KB), inside a group quarter q (samples 4q .. 4q+3)
+// of segment l at float4 index q * 64 + l.  (One 64-byte slot per segment, a lane's four float4 behind one another, cost the
+// forward's stores and the backward's loads four passes over the same lines.)
+__device__ __forceinline__ size_t seg_groups(int nseg) { return (size_t)((nseg + 63) >> 6); }
+__device__ __forceinline__ const float4 *slot_q0(const float *vbuf, int img, int nseg, int s)
+{
+    return reinterpret_cast<const float4 *>(vbuf) + ((size_t)img * seg_groups(nseg) + ((unsigned)s >> 6)) * 256 + (s & 63);
+}
                                                                          //  = floats per segment slot of the saved sample values
 
 // VEC: the volume's z rows allow 16-byte loads.  SPEC (small batches): the segment entries and the tile are requested BEFORE the
 // occupancy words have answered -- one dependent round trip (1.4 us of a batch-1 forward) less for a live tile; a dead tile's
 // loads are wasted, which is what the words are there to avoid when bandwidth matters (large batches: SPEC off).
 // SAVE_V (a gradient is wanted): the raw value of every sample of a tile through which a gradient CAN come back -- some voxel of the
-// tile passes the pre_scale clamp, or there is no pre_scale -- is also saved (one 64-byte slot per segment), for seg_scatter_kernel.  On GenRe's own
+// tile passes the pre_scale clamp, or there is no pre_scale -- is also saved (16 floats per segment), for seg_scatter_kernel.  On GenRe's own
 // chain no tile qualifies and nothing is written.
 template <bool VEC, bool SPEC, bool SAVE_V>
 __global__ __launch_bounds__(kNT) void seg_sample_kernel(RenderDims D, View5 vox, const double *__restrict__ dirs,
@@ -284,9 +293,9 @@ __global__ __launch_bounds__(kNT) void seg_sample_kernel(RenderDims D, View5 vox
             // 64 slots are 4 KB of contiguous memory) -- written [ray][k], 4 bytes at a time from 64 different rays per store
             // instruction, they cost the forward 250 us at batch 32
             if (save_v && act) {
-                float4 *slot = reinterpret_cast<float4 *>(vbuf + ((size_t)img * nseg_total + (unsigned)(c0 + lane)) * kSegSlot);
+                float4 *slot = const_cast<float4 *>(slot_q0(vbuf, img, nseg_total, c0 + lane));
 #pragma unroll
-                for (int j = 0; j < kSegSlot / 4; j++) slot[j] = make_float4(rawv[4 * j], rawv[4 * j + 1], rawv[4 * j + 2], rawv[4 * j + 3]);
+                for (int j = 0; j < kSegSlot / 4; j++) slot[j * 64] = make_float4(rawv[4 * j], rawv[4 * j + 1], rawv[4 * j + 2], rawv[4 * j + 3]);
             }
         } else {
             for (int i = 0; i < Lmax; i += 2) pair(i);
@@ -389,6 +398,53 @@ void launch_seg_sample(const RenderDims &D, const genre_tensor *vox, const genre
 }
 
 
+// ---- backward: who writes what of grad_vox --------------------------------------------------------------------------------------
+// A row's workgroup (seg_scatter_kernel) accumulates the tile of its brick: the brick's 16^3 voxels, which it WRITES (plain
+// stores; every voxel of grad_vox is written by its brick's row, zeros where nothing comes back), and the 817 cells one step
+// beyond the high faces, voxels of other bricks, which it leaves in its halo record; seg_halo_kernel adds the records onto the
+// voxels behind the first kernel's stores.  Bricks whose segments are divided over several rows (bit 30 of the row's last column;
+// bit 31: the first of them) are zeroed first (by seg_combine_bwd_kernel, on its way) and added to with atomics by all their rows.
+constexpr int kHF = kBrick + 1;                                          // cells per tile edge that exist as voxels: locals 0 .. 16
+constexpr int kHaloX = 0;                                                // x face: local x = 16, [y 0..16][z 0..16]
+constexpr int kHaloY = kHF * kHF;                                        // y face: local y = 16, [x 0..15][z 0..16]
+constexpr int kHaloZ = kHaloY + kBrick * kHF;                            // z face: local z = 16, [x 0..15][y 0..15]
+constexpr int kHaloN = kHaloZ + kBrick * kBrick;                         // 817
+constexpr int kHaloRec = 832;                                            // floats per record
+
+struct RowBits { int bx0, by0, bz0; bool split, first; };
+__device__ __forceinline__ RowBits row_bits(const int4 &row)
+{
+    const unsigned w = (unsigned)row.w;
+    return {(int)(w & 1023u) * kBrick, (int)((w >> 10) & 1023u) * kBrick, (int)((w >> 20) & 1023u) * kBrick, ((w >> 30) & 1u) != 0,
+            (w >> 31) != 0};
+}
+
+// the row's tile holds nothing that comes back (or the row is empty): with live words, no voxel of the tile passes the pre_scale clamp
+__device__ __forceinline__ bool row_dead(const RenderDims &D, const int4 &row, const int *__restrict__ live, int img)
+{
+    if (row.y >= row.z) return true;                                     // a brick no sample is based in (the cube's corners)
+    if (live == nullptr) return false;
+    const int nbricks = ((D.X + kBrick - 1) >> 4) * ((D.Y + kBrick - 1) >> 4) * ((D.Z + kBrick - 1) >> 4);
+    const int *lv = live + (int64_t)img * (nbricks + 1);
+    return lv[0] == 0 || (lv[1 + row.x] & 2) == 0;
+}
+
+__device__ __forceinline__ void zero_brick(const RenderDims &D, const View5 &gvox, float *gb, const RowBits &b, int nthreads)
+{
+    // 16-byte stores where the z rows allow it.  PLAIN stores: a brick's z row is 64 bytes, half of a 128-byte line whose other
+    // half belongs to the next brick -- nontemporal stores (no merging in L2) measured slower (csrc/sph_render.hip)
+    const bool v4 = gvox.s4 == 1 && ((gvox.s2 | gvox.s3) & 3) == 0 && (reinterpret_cast<uintptr_t>(gb) & 15) == 0 && b.bz0 + kBrick <= D.Z;
+    for (int it = threadIdx.x; it < kBrick * kBrick * 4; it += nthreads) {
+        const int x = b.bx0 + (it >> 6), y = b.by0 + ((it >> 2) & 15), z = b.bz0 + (it & 3) * 4;
+        if (x >= D.X || y >= D.Y) continue;
+        float *dst = gb + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
+        if (v4) *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else
+            for (int c = 0; c < 4; c++)
+                if (z + c < D.Z) dst[c * gvox.s4] = 0.f;
+    }
+}
+
 // ---- backward, segment form: dL/dp of every sample from per-segment state ------------------------------------------------------------
 //   dL/dp_k = g T_k (w_k - R_{k+1}),   R_k = p_k w_k + (1 - p_k) R_{k+1},   R behind the ray's last sample = 1      (no division, no
 // cancellation: the form of csrc/sph_render_bm.hip).  T_k = transmittance in front of sample k, g = dL/d(map value of the ray).
@@ -406,11 +462,18 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
                                                               const int *__restrict__ ray_nseg,
                                                               const double2 *__restrict__ ray_pre, int lines, View4 gout,
                                                               float2 *__restrict__ tr, const int *__restrict__ live, int nbricks,
-                                                              const float2 *__restrict__ line_w, unsigned *__restrict__ bmax)
+                                                              const float2 *__restrict__ line_w, unsigned *__restrict__ bmax,
+                                                              const int4 *__restrict__ rows, int nrows, View5 gvox)
 {
     __shared__ unsigned red[NT / 64];
     const int rr = D.R * D.R;
     const int img = blockIdx.y * D.NC + blockIdx.z;
+    // on the way: the bricks whose segments are divided over several rows are zeroed here, in front of seg_scatter_kernel whose
+    // rows all ADD to them (also in an image nothing comes back through: its rows then leave such a brick alone)
+    for (int i = blockIdx.x; i < nrows; i += gridDim.x) {
+        const RowBits rb = row_bits(rows[i]);
+        if (rb.first) zero_brick(D, gvox, gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1, rb, NT);
+    }
     if (live != nullptr && live[(int64_t)img * (nbricks + 1)] == 0) return;      // no voxel of this image passes the clamp: nothing reads tr
     const bool ray = (int)(blockIdx.x * NT + threadIdx.x) < rr;
     const int q = min((int)(blockIdx.x * NT + threadIdx.x), rr - 1);              // (lanes beyond the last ray repeat it, store nothing)
@@ -504,61 +567,6 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
     }
 }
 
-// ---- backward: who writes what of grad_vox --------------------------------------------------------------------------------------
-// A row's workgroup (seg_scatter_kernel) accumulates the tile of its brick: the brick's 16^3 voxels, which it WRITES (plain
-// stores; every voxel of grad_vox is written by its brick's row, zeros where nothing comes back), and the 817 cells one step
-// beyond the high faces, voxels of other bricks, which it leaves in its halo record; seg_halo_kernel adds the records onto the
-// voxels behind the first kernel's stores.  Bricks whose segments are divided over several rows (bit 30 of the row's last column;
-// bit 31: the first of them) are zeroed by seg_zero_split_kernel first and added to with atomics by all their rows.
-constexpr int kHF = kBrick + 1;                                          // cells per tile edge that exist as voxels: locals 0 .. 16
-constexpr int kHaloX = 0;                                                // x face: local x = 16, [y 0..16][z 0..16]
-constexpr int kHaloY = kHF * kHF;                                        // y face: local y = 16, [x 0..15][z 0..16]
-constexpr int kHaloZ = kHaloY + kBrick * kHF;                            // z face: local z = 16, [x 0..15][y 0..15]
-constexpr int kHaloN = kHaloZ + kBrick * kBrick;                         // 817
-constexpr int kHaloRec = 832;                                            // floats per record
-
-struct RowBits { int bx0, by0, bz0; bool split, first; };
-__device__ __forceinline__ RowBits row_bits(const int4 &row)
-{
-    const unsigned w = (unsigned)row.w;
-    return {(int)(w & 1023u) * kBrick, (int)((w >> 10) & 1023u) * kBrick, (int)((w >> 20) & 1023u) * kBrick, ((w >> 30) & 1u) != 0,
-            (w >> 31) != 0};
-}
-
-// the row's tile holds nothing that comes back (or the row is empty): with live words, no voxel of the tile passes the pre_scale clamp
-__device__ __forceinline__ bool row_dead(const RenderDims &D, const int4 &row, const int *__restrict__ live, int img)
-{
-    if (row.y >= row.z) return true;                                     // a brick no sample is based in (the cube's corners)
-    if (live == nullptr) return false;
-    const int nbricks = ((D.X + kBrick - 1) >> 4) * ((D.Y + kBrick - 1) >> 4) * ((D.Z + kBrick - 1) >> 4);
-    const int *lv = live + (int64_t)img * (nbricks + 1);
-    return lv[0] == 0 || (lv[1 + row.x] & 2) == 0;
-}
-
-__device__ __forceinline__ void zero_brick(const RenderDims &D, const View5 &gvox, float *gb, const RowBits &b, int nthreads)
-{
-    // 16-byte stores where the z rows allow it.  PLAIN stores: a brick's z row is 64 bytes, half of a 128-byte line whose other
-    // half belongs to the next brick -- nontemporal stores (no merging in L2) measured slower (csrc/sph_render.hip)
-    const bool v4 = gvox.s4 == 1 && ((gvox.s2 | gvox.s3) & 3) == 0 && (reinterpret_cast<uintptr_t>(gb) & 15) == 0 && b.bz0 + kBrick <= D.Z;
-    for (int it = threadIdx.x; it < kBrick * kBrick * 4; it += nthreads) {
-        const int x = b.bx0 + (it >> 6), y = b.by0 + ((it >> 2) & 15), z = b.bz0 + (it & 3) * 4;
-        if (x >= D.X || y >= D.Y) continue;
-        float *dst = gb + x * gvox.s2 + y * gvox.s3 + z * gvox.s4;
-        if (v4) *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
-        else
-            for (int c = 0; c < 4; c++)
-                if (z + c < D.Z) dst[c * gvox.s4] = 0.f;
-    }
-}
-
-__global__ __launch_bounds__(kNT) void seg_zero_split_kernel(RenderDims D, View5 gvox, const int4 *__restrict__ rows)
-{
-    const int4 row = rows[blockIdx.x];
-    const RowBits b = row_bits(row);
-    if (!b.first) return;
-    zero_brick(D, gvox, gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1, b, kNT);
-}
-
 // adds every live row's halo record onto the voxels it belongs to (other bricks' low faces): behind seg_scatter_kernel's stores
 __global__ __launch_bounds__(kNT) void seg_halo_kernel(RenderDims D, View5 gvox, const int4 *__restrict__ rows,
                                                         const float *__restrict__ halo, const int *__restrict__ live)
@@ -634,12 +642,11 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int bx0 = rb.bx0, by0 = rb.by0, bz0 = rb.bz0;
     float *gb = gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1;
     if (row_dead(D, row, live, img)) {                                   // nothing comes back: this brick's voxels are zeros
-        if (!split) zero_brick(D, gvox, gb, rb, kNTs);                   // (a split brick: seg_zero_split_kernel)
+        if (!split) zero_brick(D, gvox, gb, rb, kNTs);                   // (a split brick: seg_combine_bwd_kernel)
         return;
     }
     const int ox = bx0 - 1, oy = by0 - 1, oz = bz0 - 1;                  // tile origin
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const size_t vimg = (size_t)img * nseg;
     const float2 *__restrict__ trimg = tr + (size_t)img * lines;
     // the first chunk's entry and slot (addresses known now), in flight across the set-up below
     int c0 = row.y + wave * 64;
@@ -647,9 +654,9 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     int4 e = segs[sc];
     float4 pv[kSegSlot / 4];
     {
-        const float4 *slot = reinterpret_cast<const float4 *>(vbuf + (vimg + (unsigned)sc) * kSegSlot);
+        const float4 *slot = slot_q0(vbuf, img, nseg, sc);
 #pragma unroll
-        for (int j = 0; j < kSegSlot / 4; j++) pv[j] = slot[j];
+        for (int j = 0; j < kSegSlot / 4; j++) pv[j] = slot[j * 64];
     }
     unsigned mb = 0u;
     for (int i = threadIdx.x; i < nblk; i += kNTs) mb = max(mb, bmax[(size_t)img * nblk + i]);
@@ -690,9 +697,9 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         sc = min(c0 + kNTs + lane, row.z - 1);
         e = segs[sc];
         {
-            const float4 *slot = reinterpret_cast<const float4 *>(vbuf + (vimg + (unsigned)sc) * kSegSlot);
+            const float4 *slot = slot_q0(vbuf, img, nseg, sc);
 #pragma unroll
-            for (int j = 0; j < kSegSlot / 4; j++) pv[j] = slot[j];
+            for (int j = 0; j < kSegSlot / 4; j++) pv[j] = slot[j * 64];
         }
         unsigned pass = 0u;
         float Tlo = 0.f;
@@ -945,8 +952,8 @@ extern "C" int genre_render_seg_forward(const genre_tensor *vox, const genre_ten
     float *vbuf = nullptr;
     if (v_scratch != nullptr) {          // a gradient is wanted: the raw sample values of the tiles a gradient can come back through
         GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && aligned16(v_scratch->data) &&
-                          v_scratch->size[0] >= (int64_t)imgs * segs->size[0] * kSegSlot,
-                      "%s: v_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= N*NC*nseg*%d elements", op, kSegSlot);
+                          v_scratch->size[0] >= (int64_t)imgs * ((segs->size[0] + 63) / 64) * 64 * kSegSlot,
+                      "%s: v_scratch must be a contiguous, 16-byte aligned fp32 buffer of >= N*NC * ceil(nseg/64)*64 * %d elements", op, kSegSlot);
         GENRE_REQUIRE(pre_scale == 0.0f || live_p != nullptr, "%s: v_scratch with pre_scale needs the live words too", op);
         vbuf = (float *)v_scratch->data;
     }
@@ -1016,8 +1023,8 @@ extern "C" int genre_render_seg_backward(const genre_tensor *vox, const genre_te
     GENRE_REQUIRE(is_f32(tr_scratch, 1) && is_contiguous(tr_scratch) && ((uintptr_t)tr_scratch->data & 7u) == 0,
                   "%s: tr_scratch must be a contiguous, 8-byte aligned fp32 buffer", op);
     GENRE_REQUIRE(is_f32(v_scratch, 1) && is_contiguous(v_scratch) && aligned16(v_scratch->data) &&
-                      v_scratch->size[0] >= (int64_t)imgs * segs->size[0] * kSegSlot,
-                  "%s: v_scratch must be the forward's fp32 [N*NC*nseg*%d] buffer (one slot per segment)", op, kSegSlot);
+                      v_scratch->size[0] >= (int64_t)imgs * ((segs->size[0] + 63) / 64) * 64 * kSegSlot,
+                  "%s: v_scratch must be the forward's fp32 [N*NC * ceil(nseg/64)*64 * %d] buffer", op, kSegSlot);
     const int *live_p = nullptr;                                        // the forward's clamp pass words (pre_scale only)
     if (pre_scale != 0.0f) {
         GENRE_REQUIRE(is_i32(live, 1) && is_contiguous(live) && live->size[0] >= (int64_t)imgs * (nb + 1),
@@ -1035,16 +1042,16 @@ extern "C" int genre_render_seg_backward(const genre_tensor *vox, const genre_te
                       halo_scratch->size[0] >= (int64_t)imgs * bwd_rows->size[0] * kHaloRec,
                   "%s: halo_scratch must be a contiguous fp32 buffer of >= N*NC * rows * %d elements", op, kHaloRec);
     const dim3 rgrid((unsigned)bwd_rows->size[0], D.N, D.NC);
-    seg_zero_split_kernel<<<rgrid, kNT, 0, st>>>(D, view5(grad_vox), (const int4 *)bwd_rows->data);
-    GENRE_LAUNCH_CHECK("render_seg backward (zero split bricks)");
     if (big)
         seg_combine_bwd_kernel<256, 8><<<dim3((rr + 255) / 256, D.N, D.NC), 256, 0, st>>>(
             D, (const float2 *)ps_scratch->data, (const int *)ray_nseg->data, (const double2 *)ray_pre->data, lines,
-            view4(grad_out), (float2 *)tr_scratch->data, live_p, nb, (const float2 *)line_w->data, bmax);
+            view4(grad_out), (float2 *)tr_scratch->data, live_p, nb, (const float2 *)line_w->data, bmax,
+            (const int4 *)bwd_rows->data, (int)bwd_rows->size[0], view5(grad_vox));
     else
         seg_combine_bwd_kernel<64, 32><<<dim3((rr + 63) / 64, D.N, D.NC), 64, 0, st>>>(
             D, (const float2 *)ps_scratch->data, (const int *)ray_nseg->data, (const double2 *)ray_pre->data, lines,
-            view4(grad_out), (float2 *)tr_scratch->data, live_p, nb, (const float2 *)line_w->data, bmax);
+            view4(grad_out), (float2 *)tr_scratch->data, live_p, nb, (const float2 *)line_w->data, bmax,
+            (const int4 *)bwd_rows->data, (int)bwd_rows->size[0], view5(grad_vox));
     GENRE_LAUNCH_CHECK("render_seg backward (segment chains)");
     constexpr size_t lds = (size_t)kATn * sizeof(double) + kMaxZR * sizeof(float);
     static_assert(lds <= 64 * 1024, "dynamic LDS beyond 64 KB needs reserve_lds");

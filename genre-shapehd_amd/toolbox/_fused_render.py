@@ -222,6 +222,11 @@ def seg_tr_scratch(ps, vox, dirs64):
     return torch.empty((ps.numel() + imgs * (-(-rr // 64)),), dtype=torch.float32, device=ps.device)
 
 
+def seg_v_scratch(ts, imgs, device):
+    """v_scratch of render_seg_forward / render_seg_backward: 16 floats per image and segment, segments in groups of 64"""
+    return torch.empty((imgs * (-(-ts["segs"].shape[0] // 64)) * 64 * 16,), dtype=torch.float32, device=device)
+
+
 def seg_halo_scratch(ts, vox):
     """halo_scratch of render_seg_backward: 832 floats per image and row of bwd_rows"""
     return torch.empty((vox.shape[0] * vox.shape[1] * ts["bwd_rows"].shape[0] * 832,), dtype=torch.float32, device=vox.device)
@@ -402,7 +407,7 @@ def occupancy_hint_std(vox, t, dirs64, depth_weight, pre_scale, lib, with_grad=F
                                t["ray_pre"], t["line_w"], ps, float(pre_scale),
                                live=(torch.empty((1 + (-(-X // 16)) * (-(-Y // 16)) * (-(-Z // 16)),), dtype=torch.int32,
                                                  device=vox.device) if pre_scale else None),
-                               v_scratch=torch.empty((t["segs"].shape[0] * 16,), dtype=torch.float32, device=vox.device))
+                               v_scratch=seg_v_scratch(t, 1, vox.device))
         t[key] = ps.view(-1, 2)[t["segs"][:, 2].long()].contiguous()            # [nseg, 2], table order
     return words, t[key], cell
 
@@ -468,8 +473,7 @@ class RenderSphericalFused(Function):
                                                  with_grad=bool(ctx.needs_input_grad[0]))
         # a backward will follow: the raw sample values of the tiles a gradient can come back through (on GenRe's own chain:
         # none) -- with the (P, S) pairs all the state the backward's segment form needs
-        v = (torch.empty((imgs * t["segs"].shape[0] * 16,), dtype=torch.float32, device=vox.device)
-             if ctx.needs_input_grad[0] else None)
+        v = seg_v_scratch(t, imgs, vox.device) if ctx.needs_input_grad[0] else None
         lib.render_seg_forward(vox, dirs64.view(torch.float32), depth_weight, out, t["seg_rows"], t["segs"], t["ray_nseg"],
                                t["ray_pre"], t["line_w"], ps, ctx.pre_scale, ctx.live, occ, ps_empty, cell, v)
         if v is not None:

@@ -334,8 +334,9 @@ int genre_render_spherical_backward(const genre_tensor *vox, const genre_tensor 
  *   the pairs of every segment on the CONSTANT volume vox == c (this op's own ps_scratch on such a volume).  A tile none of whose
  *   cells is occupied is not read: its segments get the constants.  The caller guarantees that vox still is what the producer
  *   wrote and, when it passes `live`, that c * pre_scale does not pass the clamp.
- * v_scratch (optional; with pre_scale != 0 also pass `live`): fp32 [>= N*NC*nseg*16], 16-byte aligned, one 64-byte slot per image
- *   and segment (table order) -- a backward will follow: receives the raw (un-clamped) values of the samples of every segment of
+ * v_scratch (optional; with pre_scale != 0 also pass `live`): fp32 [>= N*NC * ceil(nseg/64)*64 * 16], 16-byte aligned, 16 floats
+ *   per image and segment (table order; segments in groups of 64, inside a group quarter q of segment l at float4 index
+ *   q*64 + l) -- a backward will follow: receives the raw (un-clamped) values of the samples of every segment of
  *   every tile some voxel of which passes the pre_scale clamp (every tile when pre_scale == 0): what
  *   genre_render_seg_backward reads.  ps_scratch is the other half of the saved state.  (`live` then
  *   carries two bits per brick: bit 0 a voxel of the brick passes, bit 1 a voxel of its tile does = its values were saved.) */

@@ -9,7 +9,7 @@ TWO = ("genre", "soft")
 PHASES = {
     "seg_combine_kernel": ("genre", "dense", "soft"),
     "bm_combine_fwd_kernel": TWO, "bm_combine_bwd_kernel": TWO, "bm_scatter_kernel": TWO,
-    "bm_zero_shared_kernel": TWO, "seg_combine_bwd_kernel": TWO, "seg_scatter_kernel": TWO, "seg_zero_split_kernel": TWO, "seg_halo_kernel": TWO,
+    "bm_zero_shared_kernel": TWO, "seg_combine_bwd_kernel": TWO, "seg_scatter_kernel": TWO, "seg_halo_kernel": TWO,
     "render_bwd_brick_kernel": TWO, "zero_shared_bricks_kernel": TWO,
 }
 

@@ -68,7 +68,7 @@ occ_std = _fused_render.occupancy_hint_std(proj_std, S, mod._dirs64, mod.depth_w
 
 tr_std = _fused_render.seg_tr_scratch(ps_std, proj_std, mod._dirs64)
 halo_std = _fused_render.seg_halo_scratch(S, proj_std)
-vseg = torch.empty((B * S["segs"].shape[0] * 16,), device=dev)
+vseg = _fused_render.seg_v_scratch(S, B, dev)
 
 
 def seg_fwd(vol, hint, save=True):

@@ -156,23 +156,23 @@ def test_validation_errors_do_not_launch(genre):
     assert rc == 0 and b"ps_empty" in lib.genre_last_error()
     rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), C.byref(desc((1,), 1)), None, None, None, 50.0, 0, None)
     assert rc == 0 and b"live" in lib.genre_last_error()
-    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, None, None, C.byref(desc((10 * 16,))), 50.0, 0, None)
+    rc = lib.genre_render_seg_forward(*sargs, C.byref(pss), None, None, None, C.byref(desc((64 * 16,))), 50.0, 0, None)
     assert rc == 0 and b"v_scratch with pre_scale" in lib.genre_last_error()            # saved samples need the live words
     # ... and its backward's: the state the forward left, one pair of depth weights per scratch line, the live words with pre_scale
     lib.genre_render_seg_backward.argtypes = [C.c_void_p] * 15 + [C.c_float, C.c_void_p]
     g88, gv16, hal = desc((1, 1, 8, 8)), desc((1, 1, 16, 16, 16)), desc((832,))
     bargs = [C.byref(a) for a in (v16, dirs, dw, g88, gv16, srow, sseg, rn, desc((64, 4)), desc((3 * 64, 2)), pss)]
-    rc = lib.genre_render_seg_backward(*bargs, C.byref(pss), C.byref(desc((10 * 16,))), C.byref(hal), None, 0.0, None)
+    rc = lib.genre_render_seg_backward(*bargs, C.byref(pss), C.byref(desc((64 * 16,))), C.byref(hal), None, 0.0, None)
     assert rc == 0 and b"tr_scratch" in lib.genre_last_error()
     trs = desc((3 * 64 * 2 + 1,))                                                       # the lines + one word per image and block
-    rc = lib.genre_render_seg_backward(*bargs, C.byref(trs), C.byref(desc((10 * 16 - 1,))), C.byref(hal), None, 0.0, None)
-    assert rc == 0 and b"v_scratch" in lib.genre_last_error()                           # one 16-float slot per segment
-    rc = lib.genre_render_seg_backward(*bargs, C.byref(trs), C.byref(desc((10 * 16,))), C.byref(hal), None, 50.0, None)
+    rc = lib.genre_render_seg_backward(*bargs, C.byref(trs), C.byref(desc((64 * 16 - 1,))), C.byref(hal), None, 0.0, None)
+    assert rc == 0 and b"v_scratch" in lib.genre_last_error()                           # 16 floats per segment, segments in groups of 64
+    rc = lib.genre_render_seg_backward(*bargs, C.byref(trs), C.byref(desc((64 * 16,))), C.byref(hal), None, 50.0, None)
     assert rc == 0 and b"live" in lib.genre_last_error()                                # which slots hold values
     rc = lib.genre_render_seg_backward(*bargs[:4], C.byref(desc((1, 1, 16, 16, 8))), *bargs[5:], C.byref(trs),
-                                       C.byref(desc((10 * 16,))), C.byref(hal), None, 0.0, None)
+                                       C.byref(desc((64 * 16,))), C.byref(hal), None, 0.0, None)
     assert rc == 0 and b"grad_vox" in lib.genre_last_error()
-    rc = lib.genre_render_seg_backward(*bargs, C.byref(trs), C.byref(desc((10 * 16,))), C.byref(desc((831,))), None, 0.0, None)
+    rc = lib.genre_render_seg_backward(*bargs, C.byref(trs), C.byref(desc((64 * 16,))), C.byref(desc((831,))), None, 0.0, None)
     assert rc == 0 and b"halo_scratch" in lib.genre_last_error()                        # 832 floats per image and row
     # empty problems succeed without launching anything
     e = desc((0, 1, 8, 8))

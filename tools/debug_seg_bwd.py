@@ -29,7 +29,7 @@ for scale in (0.0, 50.0):
     gv_old = torch.empty_like(vox); sc_old = torch.zeros((rays * 256 + n,), device=dev)
     lib.render_spherical_backward(vox, dirs, mod.depth_weight, g, gv_old, sc_old, T["bwd_table"], T["bwd_chunks"], v_old, T["kin"], scale, live)
     ps = torch.zeros((n * S["smax"] * 128 * 128 * 2,), device=dev)
-    v_new = torch.zeros((n * S["segs"].shape[0] * 16,), device=dev)
+    v_new = F.seg_v_scratch(S, n, dev)
     out2 = torch.empty_like(out)
     lib.render_seg_forward(vox, dirs, mod.depth_weight, out2, S["seg_rows"], S["segs"], S["ray_nseg"], S["ray_pre"], S["line_w"], ps, scale, live, None, None, 0, v_new)
     kin = T["kin"].long()

@@ -16,7 +16,7 @@ for B in [int(a) for a in (sys.argv[1:] or ["32"])]:
     S = F.seg_tables_for(vox.shape, dev, mod._dirs64, mod.depth_weight)
     out = torch.empty((B, 1, 160, 160), device=dev); gout = torch.randn_like(out)
     ps = torch.empty((B * S["smax"] * 128 * 128 * 2,), device=dev); tr = F.seg_tr_scratch(ps, vox, mod._dirs64)
-    v = torch.empty((B * S["segs"].shape[0] * 16,), device=dev)
+    v = F.seg_v_scratch(S, B, dev)
     live = torch.empty((B * 513,), dtype=torch.int32, device=dev)
     gv = torch.empty_like(vox)
     halo = F.seg_halo_scratch(S, vox)
