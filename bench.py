@@ -311,8 +311,8 @@ def kernel_table(G, dev, B):
                                              kernels="the same with a gradient wanted (GenRe's volume: no tile's samples are saved)")
         seg_fwd_grad(proj)
         rows["render_bwd_fused"] = dict(us=event_time_us(lambda: std_bwd(proj, live), iters, 5), bytes=B * 128 ** 3 * 4,
-                                        kernels="memset + seg_combine_bwd_kernel + seg_scatter_kernel (both return at once) on GenRe's "
-                                                "volume (the clamp blocks every voxel: grad_vox = 0)",
+                                        kernels="seg_combine_bwd_kernel (returns at once) + seg_scatter_kernel (every row writes its "
+                                                "brick's zeros) + seg_halo_kernel (returns) on GenRe's volume (the clamp blocks every voxel)",
                                         pmc=[k + "@genre" for k in bwd_pmc], src=bwd_src)
         # ... and the same kernels where they do work: the soft volume (every sample passes the clamps)
         gs = torch.Generator(device="cpu").manual_seed(1)
@@ -326,7 +326,7 @@ def kernel_table(G, dev, B):
         seg_fwd_grad(soft, False)
         rows["render_bwd_fused_soft"] = dict(us=event_time_us(lambda: std_bwd(soft, live), iters, 5),
                                              bytes=B * (BYTES_RENDER_FUSED + 128 ** 3 * 4),
-                                             kernels="memset + seg_combine_bwd_kernel + seg_scatter_kernel on the soft volume "
+                                             kernels="seg_combine_bwd_kernel + seg_scatter_kernel + seg_halo_kernel on the soft volume "
                                                      "(gradient everywhere)",
                                              pmc=[k + "@soft" for k in bwd_pmc], src=bwd_src)
         del soft
