@@ -470,8 +470,10 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
     const int img = blockIdx.y * D.NC + blockIdx.z;
     // on the way: the bricks whose segments are divided over several rows are zeroed here, in front of seg_scatter_kernel whose
     // rows all ADD to them (also in an image nothing comes back through: its rows then leave such a brick alone)
+    // (the rows of split bricks are the head of the table: a block stops at the first row that is not one)
     for (int i = blockIdx.x; i < nrows; i += gridDim.x) {
         const RowBits rb = row_bits(rows[i]);
+        if (!rb.split) break;
         if (rb.first) zero_brick(D, gvox, gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1, rb, NT);
     }
     if (live != nullptr && live[(int64_t)img * (nbricks + 1)] == 0) return;      // no voxel of this image passes the clamp: nothing reads tr
@@ -567,22 +569,26 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
     }
 }
 
-// adds every live row's halo record onto the voxels it belongs to (other bricks' low faces): behind seg_scatter_kernel's stores
-__global__ __launch_bounds__(kNT) void seg_halo_kernel(RenderDims D, View5 gvox, const int4 *__restrict__ rows,
+// adds every live row's halo record onto the voxels it belongs to (other bricks' low faces): behind seg_scatter_kernel's stores.
+// A wave per row, four rows per workgroup (a quarter of the workgroups to dispatch when nothing comes back through an image)
+__global__ __launch_bounds__(kNT) void seg_halo_kernel(RenderDims D, View5 gvox, const int4 *__restrict__ rows, int nrows,
                                                         const float *__restrict__ halo, const int *__restrict__ live)
 {
-    const int4 row = rows[blockIdx.x];
+    const int r = blockIdx.x * (kNT / 64) + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= nrows) return;
+    const int4 row = rows[r];
     const int img = blockIdx.y * D.NC + blockIdx.z;
     if (row_dead(D, row, live, img)) return;
     const RowBits b = row_bits(row);
-    const float *rec = halo + ((size_t)img * gridDim.x + blockIdx.x) * kHaloRec;
+    const float *rec = halo + ((size_t)img * nrows + r) * kHaloRec;
     float *gb = gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1;
-    float v[(kHaloN + kNT - 1) / kNT];
+    constexpr int kPer = (kHaloN + 63) / 64;
+    float v[kPer];
 #pragma unroll
-    for (int i = 0; i < (kHaloN + kNT - 1) / kNT; i++) v[i] = rec[min((int)threadIdx.x + i * kNT, kHaloN - 1)];
+    for (int i = 0; i < kPer; i++) v[i] = rec[min(lane + i * 64, kHaloN - 1)];
 #pragma unroll
-    for (int i = 0; i < (kHaloN + kNT - 1) / kNT; i++) {
-        const int idx = (int)threadIdx.x + i * kNT;
+    for (int i = 0; i < kPer; i++) {
+        const int idx = lane + i * 64;
         if (idx >= kHaloN || v[i] == 0.0f) continue;                      // (cells outside the volume were recorded as zeros)
         int lx, ly, lz;
         if (idx < kHaloY) { lx = kBrick; ly = (int)(((float)idx + 0.5f) * (1.0f / kHF)); lz = idx - ly * kHF; }
@@ -1060,7 +1066,8 @@ extern "C" int genre_render_seg_backward(const genre_tensor *vox, const genre_te
         (const int4 *)bwd_rows->data, (const int4 *)segs->data, (int)segs->size[0], (const float2 *)tr_scratch->data, lines,
         (const float *)v_scratch->data, live_p, bmax, nblk, (float *)halo_scratch->data);
     GENRE_LAUNCH_CHECK("render_seg backward (scatter)");
-    seg_halo_kernel<<<rgrid, kNT, 0, st>>>(D, view5(grad_vox), (const int4 *)bwd_rows->data, (const float *)halo_scratch->data, live_p);
+    seg_halo_kernel<<<dim3((rgrid.x + kNT / 64 - 1) / (kNT / 64), D.N, D.NC), kNT, 0, st>>>(
+        D, view5(grad_vox), (const int4 *)bwd_rows->data, (int)bwd_rows->size[0], (const float *)halo_scratch->data, live_p);
     GENRE_LAUNCH_CHECK("render_seg backward (halo records)");
     return 1;
 }

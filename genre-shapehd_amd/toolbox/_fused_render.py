@@ -202,7 +202,7 @@ def seg_tables_for(vox_shape, device, dirs64, depth_weight):
             return _seg_tables.build_seg_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, max_seg=max_seg,
                                                 split=split, bwd_split=bwd_split)
         build.__module__ = _seg_tables.__name__
-        np_t = _disk_cached("seg", (tuple(vox_shape[2:]), split, max_seg, _seg_tables.BRICK, bwd_split, "r6f"), [d64, dw], build)
+        np_t = _disk_cached("seg", (tuple(vox_shape[2:]), split, max_seg, _seg_tables.BRICK, bwd_split, "r6g"), [d64, dw], build)
         t = {"smax": int(np_t["smax"][0])}
         for k, v in np_t.items():
             if k == "smax":

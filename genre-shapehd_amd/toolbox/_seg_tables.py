@@ -23,7 +23,7 @@ Formats (int32 unless noted; see include/genre_hip.h, "segment renderer"):
   kin       [RR]       first in-volume sample of every ray
   line_w    float32 [smax*RR,2]  per scratch line: depth weight of its segment's first and of its last sample
   bwd_rows  [rows,4]   like seg_rows with pieces of <= bwd_split segments; bit 30 of the last column: the brick is split over several rows,
-                        bit 31: the first of them -- the workgroups of the backward (seg_scatter_kernel)
+                        bit 31: the first of them; the rows of split bricks come first -- the workgroups of the backward (seg_scatter_kernel)
   smax      [1]        scratch lines per ray (= max(ray_nseg)): the scratch holds smax*RR (P, S) pairs per image
 """
 import os
@@ -128,7 +128,9 @@ def build_seg_tables(X, Y, Z, dirs64, z_res, depth_weight, max_seg=MAX_SEG, spli
                 if flag_split and nparts > 1:
                     bxyz |= (1 << 30) | ((1 << 31) if r0 == b0 else 0)      # split brick; the first of its rows
                 rows.append((bid, r0, r1, bxyz, steps + FIXED_COST))
-        rows.sort(key=lambda r: -r[4])
+        # heaviest first; the rows of split bricks in front of all others (they are the heaviest pieces anyway): the per-ray pass of
+        # the backward, which zeroes those bricks on its way, then finds them at the head of the table
+        rows.sort(key=lambda r: (-((r[3] >> 30) & 1), -r[4]))
         return (np.asarray([r[:4] for r in rows], np.int64).reshape(-1, 4) & 0xffffffff).astype(np.uint32).view(np.int32)
     seg_rows = rows_for(split, False)
     # the backward's rows: the same segments, longer pieces (a workgroup of the backward carries a 46 KB accumulation tile that it

@@ -66,6 +66,8 @@ def test_segments_partition_the_in_volume_samples(res, sph, zr, max_seg, split):
         covered[beg:end] += 1
         assert (brick[beg:end] == b).all()
     assert (covered == 1).all()
+    flags = (brows[:, 3].astype(np.int64) >> 30) & 1
+    assert (np.diff(flags) <= 0).all()                                   # the rows of split bricks form the head of the table
 
 
 def test_segment_algebra_reproduces_the_ray_integral():
