@@ -1014,6 +1014,10 @@ __global__ __launch_bounds__(NT) void cam_backward_kernel(Dims D, View4 depth, V
             if (live[u]) {
                 ptnum[u] = cimg[ix[u] * cnt.s2 + iy[u] * cnt.s3 + iz[u] * cnt.s4];
                 gd[u] = gimg[ix[u] * gin.s2 + iy[u] * gin.s3 + iz[u] * gin.s4];
+                // a voxel whose incoming gradient is exactly zero gives its pixel exactly zero (every other factor below is finite:
+                // L, Dn >= 1e-5, k >= 1) -- on GenRe's own chain (the x50 clamp blocks every voxel) that is every pixel, and the
+                // divisions and square roots below are this kernel's duration.  (A NaN is not zero and goes through.)
+                live[u] = gd[u] != 0.0f;
             }
         }
 #pragma unroll
