@@ -445,7 +445,11 @@ def kernel_table(G, dev, B):
                                                                                         tile_live=tl, sparse_cnt=True)),
                ("render_fwd_bm", lambda: bm_fwd(True)),
                ("render_bwd_bm", bm_bwd_scatter),
-               ("cam_bp_bwd_bm", lambda: cam_bp_lib.back_projection_backward_shifted(d, fl, cd, cnt_bm, gvox_bm, gd, gcd, gfl))]
+               # (as the step's autograd chain runs it: the renderer's backward hangs "this group's gradient is identically zero" --
+               # the trailing words of its clamp mask -- on the gradient it returns, and the layer's backward passes them on)
+               ("cam_bp_bwd_bm", lambda: cam_bp_lib.back_projection_backward_hinted(d, fl, cd, cnt_bm, gvox_bm, gd, gcd, gfl, mask, 1,
+                                                                                    groups * 128 ** 3, 32)),
+               ("cam_bp_bwd_bm_nohint", lambda: cam_bp_lib.back_projection_backward_shifted(d, fl, cd, cnt_bm, gvox_bm, gd, gcd, gfl))]
         for _ in range(3):
             for _, fn in seq:
                 fn()
@@ -465,7 +469,10 @@ def kernel_table(G, dev, B):
                 rows[name]["us_in_step_order"] = us
             else:
                 rows[name] = dict(us=us, us_in_step_order=us, bytes=B * 670000,       # depth + grad_depth + 8 B per in-grid point
-                                  kernels="cam_backward_kernel (+ its two scalar zero fills), timed in step order only")
+                                  kernels=("cam_backward_kernel (+ its two scalar zero fills), timed in step order only; " +
+                                           ("with the renderer's zero-gradient words, as the step runs it: every group of GenRe's "
+                                            "chain is blocked by the clamp, grad_depth = 0 is written without reading anything"
+                                            if name == "cam_bp_bwd_bm" else "without the words: every pixel's gather and arithmetic")))
         cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True)     # (cnt dense again)
     for r in rows.values():
         r["GBs"] = r["bytes"] / r["us"] / 1e3

@@ -43,10 +43,12 @@ def _load():
                "genre_render_seg_forward": [C.c_float, C.c_int], "genre_render_seg_backward": [C.c_float],
                "genre_render_bm_forward": [C.c_float], "genre_render_bm_backward": [C.c_float, C.c_int],
                "genre_abs_depth_forward": [C.c_float], "genre_abs_depth_backward": [C.c_float],
-               "genre_back_projection_forward_const": [C.c_float, C.c_float, C.c_int]}
+               "genre_back_projection_forward_const": [C.c_float, C.c_float, C.c_int],
+               "genre_back_projection_backward_hinted": [C.c_int64, C.c_int64, C.c_int, C.c_int]}
     for name, nargs in (("genre_back_projection_forward", 5), ("genre_back_projection_backward", 8),
                         ("genre_get_surface_mask", 5), ("genre_back_projection_forward_shifted", 5),
                         ("genre_back_projection_backward_shifted", 8), ("genre_back_projection_forward_const", 4),
+                        ("genre_back_projection_backward_hinted", 9),
                         ("genre_spherical_back_proj_forward", 4),
                         ("genre_spherical_back_proj_backward", 5), ("genre_spherical_back_proj_forward_shifted", 4),
                         ("genre_spherical_back_proj_backward_shifted", 5), ("genre_calc_prob_forward", 2),
@@ -98,7 +100,7 @@ def _desc(t, what, host=False):
     return d
 
 
-_HINTS = ("_genre_brick_hint", "_genre_cell_hint")       # occupancy words a producer hung on its volume (toolbox/_fused_render.py)
+_HINTS = ("_genre_brick_hint", "_genre_cell_hint", "_genre_zero_hint")   # words a producer hung on a tensor it wrote (toolbox/_fused_render.py)
 
 
 def _call(name, *tensors, scalars=(), out=()):
@@ -184,6 +186,15 @@ class _CamBpLib:
     def back_projection_backward_shifted(depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl):
         return _call("genre_back_projection_backward_shifted", depth, fl, camdist, cnt, grad_in, grad_depth,
                      grad_camdist, grad_fl, out=(5, 6, 7))
+
+    @staticmethod
+    def back_projection_backward_hinted(depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl, zero_words,
+                                        word_stride, word_offset, group, shifted=True):
+        """back_projection_backward[_shifted] for a grad_in whose producer says which images' gradient is identically zero
+        (word [(image // group) * word_stride + word_offset] == 0): their grad_depth is zeros, nothing is read"""
+        return _call("genre_back_projection_backward_hinted", depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist,
+                     grad_fl, zero_words, scalars=(C.c_int64(word_stride), C.c_int64(word_offset), C.c_int(group),
+                                                   C.c_int(1 if shifted else 0)), out=(5, 6, 7))
 
     @staticmethod
     def get_surface_mask(depth, camdist, fl, cnt, mask):

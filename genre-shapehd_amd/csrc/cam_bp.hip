@@ -962,14 +962,30 @@ constexpr int kBwdUnroll = 4;
 // batch 32, back to back, either layout.  (1024-thread workgroups that take their pixels in ONE pass instead of four: 30.0 us --
 // the kernel is bound by its correctly rounded divisions and square roots at two waves per SIMD, not by the passes; the random
 // 4-byte gathers do not show either: the image-minor and the NCXYZ volume, a random and an all-zero gradient time the same.)
+// "this image's incoming gradient is identically zero": word [(image / group) * stride + offset] == 0 (genre_hip.h:
+// genre_back_projection_backward_hinted); words == nullptr: no hint
+struct ZeroHint { const int *words; int64_t stride, offset; int group; };
+
 template <int NT>
 __global__ __launch_bounds__(NT) void cam_backward_kernel(Dims D, View4 depth, View2 fl, View2 camdist,
                                                            View5 cnt, View5 gin, View4 gdepth,
-                                                           View2 gcam, View2 gfl, float gscale)
+                                                           View2 gcam, View2 gfl, float gscale, ZeroHint zh)
 {
     __shared__ double red[2][NT / 64];
     const int n = blockIdx.y, c = blockIdx.z;
     const int npix = D.H * D.W;
+    if (zh.words != nullptr && zh.words[(int64_t)((n * D.NC + c) / zh.group) * zh.stride + zh.offset] == 0) {
+        // the producer of grad_in says this image's incoming gradient is identically zero (the renderer's backward where the clamp
+        // in front of it blocks every voxel: GenRe's own chain): grad_depth = 0, nothing for grad_fl / grad_camdist
+        float *gz = gdepth.p + n * gdepth.s0 + c * gdepth.s1;
+        const float inv = 1.0f / (float)D.W;
+        for (int p = blockIdx.x * NT + threadIdx.x; p < npix; p += gridDim.x * NT) {
+            int h, w;
+            divmod_px(p, D.W, inv, h, w);
+            gz[h * gdepth.s2 + w * gdepth.s3] = 0.0f;
+        }
+        return;
+    }
     const float inv_w = 1.0f / (float)D.W;
     double acc_fl = 0.0, acc_cd = 0.0;
     const float f = fl.p[n * fl.s0 + c * fl.s1];
@@ -1402,7 +1418,8 @@ extern "C" int genre_spherical_back_proj_forward(const genre_tensor *depth, cons
 static int backward_impl(const char *op, const genre_tensor *depth, const genre_tensor *fl,
                          const genre_tensor *camdist, const genre_tensor *cnt, const genre_tensor *grad_in,
                          const genre_tensor *grad_depth, const genre_tensor *grad_camdist,
-                         const genre_tensor *grad_fl, void *stream, bool shifted)
+                         const genre_tensor *grad_fl, void *stream, bool shifted, const genre_tensor *zero_words = nullptr,
+                         int64_t word_stride = 0, int64_t word_offset = 0, int group = 1)
 {
     Dims D{};
     if (!check_image(op, depth, D) || !check_scalar(op, "fl", fl, D) || !check_scalar(op, "camdist", camdist, D) ||
@@ -1427,9 +1444,16 @@ static int backward_impl(const char *op, const genre_tensor *depth, const genre_
         GENRE_REQUIRE(D.X == D.Y && D.Y == D.Z, "%s: the fused shift needs a cubic grid", op);
         gscale = -(float)D.X;
     }
+    ZeroHint zh{nullptr, 0, 0, 1};
+    if (zero_words != nullptr) {
+        GENRE_REQUIRE(group >= 1 && word_stride >= 0 && word_offset >= 0 && is_i32(zero_words, 1) && is_contiguous(zero_words) &&
+                          zero_words->size[0] > (int64_t)((imgs - 1) / group) * word_stride + word_offset,
+                      "%s: zero_words must be a contiguous int32 buffer holding word (image / group) * stride + offset of every image", op);
+        zh = ZeroHint{(const int *)zero_words->data, word_stride, word_offset, group};
+    }
     cam_backward_kernel<kBlock><<<dim3(bx, D.N, D.NC), kBlock, 0, st>>>(D, view4(depth), view2(fl), view2(camdist), view5(cnt),
                                                                         view5(grad_in), view4(grad_depth), view2(grad_camdist),
-                                                                        view2(grad_fl), gscale);
+                                                                        view2(grad_fl), gscale, zh);
     GENRE_LAUNCH_CHECK("projection backward");
     return 1;
 }
@@ -1480,6 +1504,17 @@ extern "C" int genre_back_projection_backward_shifted(const genre_tensor *depth,
 {
     return backward_impl("back_projection_backward_shifted", depth, fl, camdist, cnt, grad_in, grad_depth,
                          grad_camdist, grad_fl, stream, true);
+}
+
+extern "C" int genre_back_projection_backward_hinted(const genre_tensor *depth, const genre_tensor *fl,
+                                                     const genre_tensor *camdist, const genre_tensor *cnt,
+                                                     const genre_tensor *grad_in, const genre_tensor *grad_depth,
+                                                     const genre_tensor *grad_camdist, const genre_tensor *grad_fl,
+                                                     const genre_tensor *zero_words, int64_t word_stride, int64_t word_offset,
+                                                     int group, int shifted, void *stream)
+{
+    return backward_impl("back_projection_backward_hinted", depth, fl, camdist, cnt, grad_in, grad_depth, grad_camdist, grad_fl,
+                         stream, shifted != 0, zero_words, word_stride, word_offset, group);
 }
 
 extern "C" int genre_get_surface_mask(const genre_tensor *depth, const genre_tensor *camdist,

@@ -232,6 +232,24 @@ def seg_halo_scratch(ts, vox):
     return torch.empty((vox.shape[0] * vox.shape[1] * ts["bwd_rows"].shape[0] * 832,), dtype=torch.float32, device=vox.device)
 
 
+def attach_zero_hint(grad, words, stride, offset, group):
+    """hangs "the gradient of these images is identically zero" on a gradient tensor this module just wrote: int32 `words`,
+    word [(image // group) * stride + offset] == 0 <=> all zeros -- the renderer's backward knows it from the forward's clamp
+    words (on GenRe's own chain the x50 clamp blocks every voxel of every image).  The consumer (the camera layer's backward,
+    cam_back_projection.py) then writes zeros for those images without reading anything.  Guarded like the occupancy hint: the
+    tensor's version counter (ATen writes) and _loader._call (raw C-ABI writes drop it)."""
+    grad._genre_zero_hint = (words, int(stride), int(offset), int(group), grad._version)
+    return grad
+
+
+def zero_hint_of(grad):
+    """(words, stride, offset, group) a producer hung on this gradient tensor, or None"""
+    h = getattr(grad, "_genre_zero_hint", None)
+    if h is None or h[4] != grad._version or h[0].device != grad.device:
+        return None
+    return h[:4]
+
+
 def _bm_tables_module():
     from . import _bm_tables
     return _bm_tables
@@ -492,6 +510,10 @@ class RenderSphericalFused(Function):
             lib.render_bm_backward(grad_out, grad_vox, t["segs"], t["ray_ptr"], t["ray_seg"], t["ray_pre"], t["ent"],
                                    t["rec_b"], t["bwd_rows"], depth_weight, ps, torch.empty_like(ps), stash, ctx.mask,
                                    ctx.pre_scale, t["pull_code"])
+            if ctx.mask is not None and ctx.pre_scale:
+                # the trailing word of a group of 32 images: does any of its voxels pass the clamp?
+                nvox = ctx.vox_shape[2] * ctx.vox_shape[3] * ctx.vox_shape[4]
+                attach_zero_hint(grad_vox, ctx.mask, 1, groups * nvox, 32)
             return grad_vox, None, None, None, None
         vox, dirs64, depth_weight, ps, v = ctx.saved_tensors
         ts = seg_tables_for(vox.shape, vox.device, dirs64, depth_weight)
@@ -501,4 +523,8 @@ class RenderSphericalFused(Function):
         lib.render_seg_backward(vox, dirs64.view(torch.float32), depth_weight, grad_out, grad_vox, ts["bwd_rows"], ts["segs"],
                                 ts["ray_nseg"], ts["ray_pre"], ts["line_w"], ps, seg_tr_scratch(ps, vox, dirs64), v,
                                 seg_halo_scratch(ts, vox), ctx.pre_scale, ctx.live)
+        if ctx.live is not None and ctx.pre_scale and vox.shape[1] == 1:
+            # word 0 of an image's live words: does any of its voxels pass the clamp?
+            nb = (-(-vox.shape[2] // 16)) * (-(-vox.shape[3] // 16)) * (-(-vox.shape[4] // 16))
+            attach_zero_hint(grad_vox, ctx.live, 1 + nb, 0, 1)
         return grad_vox, None, None, None, None

@@ -121,6 +121,14 @@ class ShiftedCameraBackProjection(Function):
         grad_depth = torch.empty(ctx.depth_shape, dtype=grad_output.dtype, device=grad_output.device)
         grad_fl = torch.empty((n, nc), dtype=grad_output.dtype, device=grad_output.device)
         grad_camdist = torch.empty_like(grad_fl)
-        cam_bp_lib.back_projection_backward_shifted(depth_t, fl, cam_dist, cnt, grad_output,
-                                                    grad_depth, grad_camdist, grad_fl)
+        # the renderer's backward says which images' gradient is identically zero (the clamp in front of it blocked every voxel:
+        # GenRe's own chain) -- toolbox/_fused_render.py: attach_zero_hint
+        from ...._fused_render import zero_hint_of
+        zh = zero_hint_of(grad_output)
+        if zh is not None:
+            cam_bp_lib.back_projection_backward_hinted(depth_t, fl, cam_dist, cnt, grad_output, grad_depth, grad_camdist,
+                                                       grad_fl, *zh, shifted=True)
+        else:
+            cam_bp_lib.back_projection_backward_shifted(depth_t, fl, cam_dist, cnt, grad_output,
+                                                        grad_depth, grad_camdist, grad_fl)
         return grad_depth, grad_fl, grad_camdist, None, None, None, None

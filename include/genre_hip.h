@@ -99,6 +99,18 @@ int genre_back_projection_backward_shifted(const genre_tensor *depth, const genr
                                            const genre_tensor *grad_camdist, const genre_tensor *grad_fl,
                                            void *stream);
 
+/* Extension: genre_back_projection_backward[_shifted] (shifted != 0) for a grad_in whose PRODUCER knows that the gradient of some
+ * images is identically zero -- the renderer's backward where the caller's clamp in front of it blocks every voxel (GenRe's own
+ * chain, depth_pred_with_sph_inpaint.py:124): it still writes those zeros to grad_in, and says so in words it owns anyway.
+ * zero_words int32, contiguous: word [(image / group) * word_stride + word_offset] == 0 <=> the gradient of that image (N*NC
+ * order) is all zeros: its grad_depth is written as zeros without reading grad_in, cnt or depth.  Other images: as without the
+ * words.  (toolbox/_fused_render.py hangs the words on the gradient tensor it returns, guarded by the tensor's version.) */
+int genre_back_projection_backward_hinted(const genre_tensor *depth, const genre_tensor *fl, const genre_tensor *camdist,
+                                          const genre_tensor *cnt, const genre_tensor *grad_in,
+                                          const genre_tensor *grad_depth, const genre_tensor *grad_camdist,
+                                          const genre_tensor *grad_fl, const genre_tensor *zero_words, int64_t word_stride,
+                                          int64_t word_offset, int group, int shifted, void *stream);
+
 /* Extension: the camera forward with ONE focal length and ONE camera distance for every image, passed by value --
  * exactly what Camera_back_projection_layer fills its [N,NC] tensors with when it is called with Python floats
  * (camera_backprojection_module.py:16-21).  The kernel then has the camera in its arguments instead of behind two

@@ -182,3 +182,64 @@ def test_segment_form_backward_equals_the_per_sample_backward(genre, dev):
         assert torch.count_nonzero(x.grad[1]).item() == 0 and x.grad[0].abs().max().item() > 0
         if scale:
             assert torch.count_nonzero(x.grad[2, :, 32:64, 48:80, 16:96]).item() == 0      # saturated bricks: blocked
+
+
+def test_zero_gradient_words_reach_the_camera_backward(genre, dev):
+    """the renderer's backward knows from the forward's clamp words which images' gradient is identically zero and hangs that on
+    the gradient tensor it returns (toolbox/_fused_render.py: attach_zero_hint); the camera layer's backward then writes zeros for
+    those images without reading anything (genre_back_projection_backward_hinted).  Same gradients as without the words -- on
+    GenRe's own chain (pre_scale 50: every image blocked), on a chain with a live gradient (0.9: words say "alive", nothing is
+    skipped), both layouts --, the hinted entry IS what runs, and words alone decide: a raw call with mixed words"""
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    from genre_shapehd_amd.toolbox.cam_bp.cam_bp._ext import cam_bp_lib
+    calls = []
+    real = cam_bp_lib.back_projection_backward_hinted
+    real_attach = F.attach_zero_hint
+    cam_bp_lib.back_projection_backward_hinted = staticmethod(lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    rng = np.random.default_rng(12)
+    try:
+        for n, batch_minor in ((3, False), (32, True)):
+            d0 = torch.from_numpy(inputs.batch_depth(n, seed=5)).to(dev)
+            g = torch.from_numpy(rng.standard_normal((n, 1, 160, 160)).astype(np.float32)).to(dev)
+            layer = genre.Camera_back_projection_layer(batch_minor=batch_minor).to(dev)
+            mod = genre.render_spherical().to(dev)
+            for scale in (50.0, 0.9):
+                grads = []
+                for hinted in (True, False):
+                    F.attach_zero_hint = real_attach if hinted else (lambda grad, *a: grad)
+                    d = d0.clone().requires_grad_(True)
+                    before = len(calls)
+                    mod(layer(d), pre_scale=scale, pad=16).backward(g)
+                    assert (len(calls) > before) == hinted
+                    grads.append(d.grad.clone())
+                # (a live gradient: the renderer's backward sums a brick's low faces with atomics -- two runs differ in last bits)
+                top = grads[1].abs().max().item()
+                assert (grads[0] - grads[1]).abs().max().item() <= 1e-5 * top
+                assert (top == 0) == (scale == 50.0) and (grads[0].abs().max().item() == 0) == (scale == 50.0)
+    finally:
+        cam_bp_lib.back_projection_backward_hinted = staticmethod(real)
+        F.attach_zero_hint = real_attach
+    # the entry itself: words decide, image by image (group 1) and in groups of two
+    n = 4
+    d = torch.from_numpy(inputs.batch_depth(n, seed=6)).to(dev)
+    fl = torch.full((n, 1), 418.3, device=dev); cd = torch.full((n, 1), 2.2, device=dev)
+    vol, cnt = torch.empty((n, 1, 128, 128, 128), device=dev), torch.empty((n, 1, 128, 128, 128), device=dev)
+    cam_bp_lib.back_projection_forward_shifted(d, cd, fl, vol, cnt)
+    gin = torch.from_numpy(rng.standard_normal((n, 1, 128, 128, 128)).astype(np.float32)).to(dev)
+    ref = [torch.empty_like(d), torch.empty((n, 1), device=dev), torch.empty((n, 1), device=dev)]
+    cam_bp_lib.back_projection_backward_shifted(d, fl, cd, cnt, gin, *ref)
+    words = torch.tensor([7, 1, 7, 0, 7, 1, 7, 1], dtype=torch.int32, device=dev)       # stride 2, offset 1: images 0, 2, 3 alive, 1 dead
+    got = [torch.full_like(d, float("nan")), torch.empty((n, 1), device=dev), torch.empty((n, 1), device=dev)]
+    cam_bp_lib.back_projection_backward_hinted(d, fl, cd, cnt, gin, *got, words, 2, 1, 1, shifted=True)
+    for i in range(n):
+        if i == 1:
+            assert torch.count_nonzero(got[0][i]).item() == 0 and got[1][i].item() == 0 and got[2][i].item() == 0
+        else:
+            assert torch.equal(got[0][i], ref[0][i])
+            for k in (1, 2):                                                  # (block partials meet in fp32 atomics: order is not fixed)
+                assert abs(got[k][i].item() - ref[k][i].item()) <= 1e-5 * abs(ref[k][i].item())
+    words2 = torch.tensor([0, 5], dtype=torch.int32, device=dev)                          # groups of two images: 0, 1 dead
+    cam_bp_lib.back_projection_backward_hinted(d, fl, cd, cnt, gin, *got, words2, 1, 0, 2, shifted=True)
+    assert torch.count_nonzero(got[0][:2]).item() == 0 and torch.equal(got[0][2:], ref[0][2:])
+    with pytest.raises(RuntimeError, match="zero_words"):
+        cam_bp_lib.back_projection_backward_hinted(d, fl, cd, cnt, gin, *got, words2, 1, 0, 1, shifted=True)   # four images, two words

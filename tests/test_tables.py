@@ -142,3 +142,18 @@ def test_row_splitting_keeps_order_and_flags():
         assert (bt[bt[:, 0] == b, 3] == 1).all()                              # split bricks accumulate with atomics
     for b in np.nonzero(counts == 1)[0]:
         assert (bt[bt[:, 0] == b, 3] == 0).all()
+
+
+def test_zero_gradient_hint_is_guarded_by_the_tensor_version():
+    """toolbox/_fused_render.py: attach_zero_hint / zero_hint_of -- the words a producer hangs on a gradient tensor are honoured
+    only as long as nobody wrote to the tensor since (ATen bumps the version; raw C-ABI writes drop the attribute in _loader._call)"""
+    import torch
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    g = torch.zeros(4, 1, 2, 2, 2)
+    words = torch.zeros(5, dtype=torch.int32)
+    assert F.zero_hint_of(g) is None
+    F.attach_zero_hint(g, words, 1, 1, 1)
+    h = F.zero_hint_of(g)
+    assert h is not None and h[0] is words and h[1:] == (1, 1, 1)
+    g.add_(1.0)
+    assert F.zero_hint_of(g) is None
