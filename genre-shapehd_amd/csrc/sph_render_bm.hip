@@ -517,17 +517,22 @@ __global__ __launch_bounds__(256, 4) void bm_combine_bwd_kernel(BmDims D, const 
 // The backward's bricks ("pull bricks", PX x PY x PZ voxels) need not be the forward's: a bigger one lowers the number of
 // bricks a segment touches (every touching brick re-reads the segment's saved samples) at the price of LDS.
 template <int PX, int PY, int PZ>
-__global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, float *__restrict__ gvox)
+__global__ __launch_bounds__(kThreads) void bm_zero_shared_kernel(BmDims D, const int4 *__restrict__ rows, int nrows,
+                                                                 float *__restrict__ gvox)
 {
-    const int4 row = rows[blockIdx.x];
-    if (row_flag(row) != 1) return;
-    int ox, oy, oz;
-    brick_origin<PX, PY, PZ>(row, ox, oy, oz);
-    const int n0 = blockIdx.y * kImgs;
-    for (int e = threadIdx.x; e < PX * PY * PZ * kImgs; e += kThreads) {
-        const int line = e >> 5, n = n0 + (e & 31);
-        const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
-        if (x < D.X && y < D.Y && z < D.Z && n < D.N) gvox[x * D.gx + y * D.gy + z * D.gz + n] = 0.f;
+    // the rows of split bricks are the head of the table (toolbox/_bm_tables.py: _split_rows): a workgroup stops at the first row that
+    // is not one.  (Launched over all 16 k rows to find ~200, this kernel took 14 us of the step's zero backward.)
+    for (int i = blockIdx.x; i < nrows; i += gridDim.x) {
+        const int4 row = rows[i];
+        if (row_flag(row) != 1) break;
+        int ox, oy, oz;
+        brick_origin<PX, PY, PZ>(row, ox, oy, oz);
+        const int n0 = blockIdx.y * kImgs;
+        for (int e = threadIdx.x; e < PX * PY * PZ * kImgs; e += kThreads) {
+            const int line = e >> 5, n = n0 + (e & 31);
+            const int x = ox + line / (PY * PZ), y = oy + (line / PZ) % PY, z = oz + line % PZ;
+            if (x < D.X && y < D.Y && z < D.Z && n < D.N) gvox[x * D.gx + y * D.gy + z * D.gz + n] = 0.f;
+        }
     }
 }
 
@@ -1011,8 +1016,8 @@ extern "C" int genre_render_bm_backward(const genre_tensor *grad_out, const genr
 #define GENRE_BM_SCATTER(PSV, PXV, NTV)                                                                                   \
     do {                                                                                                                  \
         if (split) {                                                                                                      \
-            bm_zero_shared_kernel<PXV, 8, 8><<<grid, kThreads, 0, st>>>(D, (const int4 *)bwd_rows->data,                  \
-                                                                        (float *)grad_vox->data);                         \
+            bm_zero_shared_kernel<PXV, 8, 8><<<dim3(grid.x < 1024u ? grid.x : 1024u, grid.y), kThreads, 0, st>>>(        \
+                D, (const int4 *)bwd_rows->data, (int)bwd_rows->size[0], (float *)grad_vox->data);                        \
             GENRE_LAUNCH_CHECK("render_bm backward (zero shared bricks)");                                                \
         }                                                                                                                 \
         constexpr size_t lds = (size_t)PXV * 64 * kImgs * 8 + (size_t)(NTV / 64) * kMaxSeg * kRecL * 4 + (size_t)(PXV * 64 + PXV + 4) * 4; \

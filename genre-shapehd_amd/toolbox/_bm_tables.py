@@ -264,10 +264,16 @@ def _split_rows(begin, end, cum, split, shared_mode):
             cuts.append(nxt)
         for c0, c1 in zip(cuts[:-1], cuts[1:]):
             rows.append((b, c0, c1, shared_mode, int(cum[c1] - cum[c0])))
+    # the rows of split bricks (flag 1: they add to their brick atomically, which bm_zero_shared_kernel zeroes first) form the HEAD of
+    # the table in every order, heaviest first: the zero kernel then stops at the first row that is not one instead of being
+    # launched over all 16 k rows to find ~200
+    head = sorted((r for r in rows if r[3] == 1), key=lambda r: -r[4])
+    rest = [r for r in rows if r[3] != 1]
     if ROW_ORDER == "heaviest":
-        rows.sort(key=lambda r: -r[4])
-        return np.asarray([r[:4] for r in rows], np.int32).reshape(-1, 4)
-    return _xcd_order(rows)
+        rest.sort(key=lambda r: -r[4])
+        return np.asarray([r[:4] for r in head + rest], np.int32).reshape(-1, 4)
+    tail = _xcd_order(rest)
+    return np.concatenate([np.asarray([r[:4] for r in head], np.int32).reshape(-1, 4), tail]) if head else tail
 
 
 # Row order.  "heaviest": rows sorted by weight, heaviest first (best tail).  "xcd": weight classes, brick order inside a

@@ -276,7 +276,7 @@ def bm_tables_for(vox_shape, device, dirs64, depth_weight):
             return _bm_tables.build_bm_tables(vox_shape[2], vox_shape[3], vox_shape[4], d64, dw.shape[0], dw, pull=pull)
         build.__module__ = _bm_tables.__name__
         np_t = _disk_cached("bm", (tuple(vox_shape[2:]), pull, _bm_tables.ROW_ORDER, _bm_tables.SPLIT_F,
-                                   _bm_tables.SPLIT_B, _bm_tables.MAXSEG, (_bm_tables.BX, _bm_tables.BY, _bm_tables.BZ), "r6"), [d64, dw], build)
+                                   _bm_tables.SPLIT_B, _bm_tables.MAXSEG, (_bm_tables.BX, _bm_tables.BY, _bm_tables.BZ), "r6b"), [d64, dw], build)
         t = {"pull_code": int(np_t["pull"][0]) * 100 + int(np_t["pull"][1]) * 10 + int(np_t["pull"][2])}
         for k, v in np_t.items():
             if k == "pull":

@@ -101,6 +101,9 @@ def test_bm_listing_names_every_touching_sample_once_per_brick(res, sph, zr, pul
         bid = ((xyz[0][ok] // bs[0]) * nbr[1] + xyz[1][ok] // bs[1]) * nbr[2] + xyz[2][ok] // bs[2]
         for b_, q_, k_ in zip(bid.tolist(), qs[ok].tolist(), ks[ok].tolist()):
             expect.setdefault((b_, q_ * zr + k_), set()).add(c)
+    # the rows of split bricks (flag 1) are the head of the backward's table: bm_zero_shared_kernel stops at the first other row
+    flags = np.asarray([B.row_flag(w) for w in t["bwd_rows"][:, 3]])
+    assert (np.diff((flags == 1).astype(int)) <= 0).all()
     got = {}
     for b_, e0, e1, shared in t["bwd_rows"]:
         if B.row_flag(shared) == B.SKIP:
