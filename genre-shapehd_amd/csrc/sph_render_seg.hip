@@ -468,15 +468,15 @@ __global__ __launch_bounds__(NT) void seg_combine_bwd_kernel(RenderDims D, const
     __shared__ unsigned red[NT / 64];
     const int rr = D.R * D.R;
     const int img = blockIdx.y * D.NC + blockIdx.z;
+    if (live != nullptr && live[(int64_t)img * (nbricks + 1)] == 0) return;      // no voxel of this image passes the clamp: nothing reads tr
     // on the way: the bricks whose segments are divided over several rows are zeroed here, in front of seg_scatter_kernel whose
-    // rows all ADD to them (also in an image nothing comes back through: its rows then leave such a brick alone)
-    // (the rows of split bricks are the head of the table: a block stops at the first row that is not one)
+    // rows all ADD to them (in an image nothing comes back through, the first row of such a brick writes its zeros there: all rows
+    // of a brick are dead together).  The rows of split bricks are the head of the table: a block stops at the first other row
     for (int i = blockIdx.x; i < nrows; i += gridDim.x) {
         const RowBits rb = row_bits(rows[i]);
         if (!rb.split) break;
         if (rb.first) zero_brick(D, gvox, gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1, rb, NT);
     }
-    if (live != nullptr && live[(int64_t)img * (nbricks + 1)] == 0) return;      // no voxel of this image passes the clamp: nothing reads tr
     const bool ray = (int)(blockIdx.x * NT + threadIdx.x) < rr;
     const int q = min((int)(blockIdx.x * NT + threadIdx.x), rr - 1);              // (lanes beyond the last ray repeat it, store nothing)
     const int n = ray ? min(ray_nseg[q], kMaxRaySegs) : 0;
@@ -576,8 +576,12 @@ __global__ __launch_bounds__(kNT) void seg_halo_kernel(RenderDims D, View5 gvox,
 {
     const int r = blockIdx.x * (kNT / 64) + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= nrows) return;
-    const int4 row = rows[r];
     const int img = blockIdx.y * D.NC + blockIdx.z;
+    if (live != nullptr) {                                               // (the image's word before the row: one round trip for a dead image)
+        const int nbricks = ((D.X + kBrick - 1) >> 4) * ((D.Y + kBrick - 1) >> 4) * ((D.Z + kBrick - 1) >> 4);
+        if (live[(int64_t)img * (nbricks + 1)] == 0) return;
+    }
+    const int4 row = rows[r];
     if (row_dead(D, row, live, img)) return;
     const RowBits b = row_bits(row);
     const float *rec = halo + ((size_t)img * nrows + r) * kHaloRec;
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int bx0 = rb.bx0, by0 = rb.by0, bz0 = rb.bz0;
     float *gb = gvox.p + blockIdx.y * gvox.s0 + blockIdx.z * gvox.s1;
     if (row_dead(D, row, live, img)) {                                   // nothing comes back: this brick's voxels are zeros
-        if (!split) zero_brick(D, gvox, gb, rb, kNTs);                   // (a split brick: seg_combine_bwd_kernel)
+        if (!split || rb.first) zero_brick(D, gvox, gb, rb, kNTs);       // (a split brick: its first row; all its rows are dead together)
         return;
     }
     const int ox = bx0 - 1, oy = by0 - 1, oz = bz0 - 1;                  // tile origin
