@@ -243,3 +243,25 @@ def test_zero_gradient_words_reach_the_camera_backward(genre, dev):
     assert torch.count_nonzero(got[0][:2]).item() == 0 and torch.equal(got[0][2:], ref[0][2:])
     with pytest.raises(RuntimeError, match="zero_words"):
         cam_bp_lib.back_projection_backward_hinted(d, fl, cd, cnt, gin, *got, words2, 1, 0, 1, shifted=True)   # four images, two words
+
+
+@pytest.mark.parametrize("pre_scale", [None, 3.0])
+def test_segment_renderer_on_strided_volumes_and_two_channels(pre_scale, genre, dev):
+    """the standard-layout segment forward / backward read the volume through its strides (rows that are no float4, permuted
+    axes, NC = 2): same map and gradient as on a contiguous copy"""
+    rng = np.random.default_rng(21)
+    big = torch.from_numpy(rng.uniform(0.0, 0.4, (2, 2, 40, 44, 49)).astype(np.float32)).to(dev)
+    mod = genre.render_spherical(sph_res=24, z_res=64).to(dev)
+    g = torch.from_numpy(rng.standard_normal((2, 2, 24 + 8, 24 + 8)).astype(np.float32)).to(dev)
+    for view in (big[:, :, :, :40, 3:43], big[:, :, :, :40, :40].transpose(2, 3)):
+        assert not view.is_contiguous()
+        res = []
+        for v in (view, view.contiguous()):
+            x = v.detach().clone(memory_format=torch.preserve_format) if v.is_contiguous() else v.detach()
+            x = x.requires_grad_(True)
+            y = mod(x, pre_scale=pre_scale, pad=4)
+            y.backward(g)
+            res.append((y.detach(), x.grad.detach()))
+        assert torch.equal(res[0][0], res[1][0])
+        top = res[1][1].abs().max().item()
+        assert top > 0 and (res[0][1] - res[1][1]).abs().max().item() <= 2e-6 * top
