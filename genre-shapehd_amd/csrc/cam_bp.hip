@@ -642,9 +642,13 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
     __shared__ float s_min[kBlock / 64], s_max[kBlock / 64];
     __shared__ int s_any[kBlock / 64];
     __shared__ int s_hit;
-    const int nbz = (D.Z + kQZ - 1) / kQZ, nby = (D.Y + kQY - 1) / kQY;
-    const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bx = blockIdx.x / (nbz * nby);
-    const int img = blockIdx.y, n = img / D.NC, c = img % D.NC;
+    // (no runtime integer division: gfx950 has no divide instruction, ~40 instructions each, and five of them stood in front of
+    // every workgroup's first load -- the image is (blockIdx.y, blockIdx.z) = (n, c), the brick's coordinates come from two
+    // float-reciprocal quotients, exact for these sizes: csrc/sph_render_seg.hip)
+    const int nbz = (D.Z + kQZ - 1) / kQZ, nby = (D.Y + kQY - 1) / kQY;       // (constant divisors: shifts)
+    const int t1 = (int)(((float)blockIdx.x + 0.5f) * __builtin_amdgcn_rcpf((float)nbz)), bz = (int)blockIdx.x - t1 * nbz;
+    const int bx = (int)(((float)t1 + 0.5f) * __builtin_amdgcn_rcpf((float)nby)), by = t1 - bx * nby;
+    const int n = blockIdx.y, c = blockIdx.z, img = n * D.NC + c;
     const float f = BYVAL ? fl_val : fl.p[n * fl.s0 + c * fl.s1];
     const float cam_dist = BYVAL ? cd_val : camdist.p[n * camdist.s0 + c * camdist.s1];
     const float *dimg = depth.p + n * depth.s0 + c * depth.s1;
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
     // occupancy for the consumer (the segment renderer, csrc/sph_render_seg.hip, does not read tiles none of whose cells
     // received a point): one word per image and cell = this workgroup's brick, written by its owner -- no clearing pass, no
     // atomics.  0 => every voxel of the cell holds fill_val.
-    if (cell_live != nullptr && threadIdx.x == 0) cell_live[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = live ? 1 : 0;
+    if (cell_live != nullptr && threadIdx.x == 0) cell_live[(size_t)img * gridDim.x + blockIdx.x] = live ? 1 : 0;
     // ---- (c) normalise (:291-305) and write the brick; a dead brick streams the fill values ---------------------
     auto value = [&](int l, float &k) {
         k = (float)s_cnt[l];
@@ -1356,7 +1360,8 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         if (mode == kBrick) {
             const int64_t bricks = (int64_t)((D.X + kQX - 1) / kQX) * ((D.Y + kQY - 1) / kQY) * ((D.Z + kQZ - 1) / kQZ);
             GENRE_REQUIRE(bricks < ((int64_t)1 << 31), "%s: volume too large", op);
-            const dim3 bgrid((unsigned)bricks, D.N * D.NC);
+            GENRE_REQUIRE(bricks < ((int64_t)1 << 20), "%s: more than 2^20 bricks", op);     // (the kernel's float quotients)
+            const dim3 bgrid((unsigned)bricks, D.N, D.NC);
             const bool pixelscreen = D.N * D.NC <= GENRE_CAMQ_PIXELSCREEN_MAXN;
 #define GENRE_CAMQ_LAUNCH(BV, PXS, A, B_)                                                                                 \
             cam_brick_kernel<BV, PXS><<<bgrid, kBlock, 0, st>>>(D, view4(depth), vcd, vfl, view5(voxel), view5(cnt), prefill, bias, \
