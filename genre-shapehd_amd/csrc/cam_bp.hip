@@ -794,13 +794,19 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
 // deterministic, and tdf / cnt BIT-IDENTICAL to a serial evaluation of the reference on every voxel
 // (tests/test_gpu_cam_bp.py::test_image_minor_camera_forward_is_deterministic_and_bit_identical_to_the_serial_reference).
 // Replaces round 4's opt-in cam_bm_brick_kernel (LDS bricks over 32 images: 335 us at batch 32 against 149 for the atomics).
-struct BrickFlags { int *p; int per_group, nbx, nby, nbz, bx, by, bz; };   // int32 [groups, nbx, nby, nbz]; p == nullptr: none
+struct BrickFlags { int *p; int per_group, nbx, nby, nbz, bx, by, bz, sg, sx, sy, sz; };   // int32 [groups, nbx, nby, nbz]; p == nullptr: none
+                                                                    // (sg, sx, sy, sz: log2 of per_group, bx, by, bz, or -1)
 
 template <int HALO>
 __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth, View5 vox, View5 cnt, float cam_dist, float f,
                                                             float prefill, float bias, float post_scale, float post_bias,
-                                                            BrickFlags flags, float d_screen)
+                                                            BrickFlags flags, float d_screen, int fast_idx)
 {
+    // fast_idx: fewer than 2^20 tiles and a grid of <= 1024 voxels per axis.  Then nothing in this kernel divides integers at run
+    // time (gfx950 has no divide instruction: ~40 instructions each; four per tile to take its number apart, three per leader to
+    // take its voxel's index apart and four more for its brick were a third of a tile's instructions): tile -> (tx, ty, c, n) by
+    // float-reciprocal quotients (exact for these sizes), the window's keys are the voxel's coordinates PACKED (x | y << 10 |
+    // z << 20: only equality is ever asked of a key), bricks and image groups of power-of-two size by shifts
     constexpr int TW = 8 + 2 * HALO, TN = TW * TW, kWaves = kBlock / 64;
     __shared__ int s_key[kWaves][TN];
     __shared__ float s_dist[kWaves][TN];
@@ -811,10 +817,20 @@ __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth,
     float *dist_w = s_dist[wave];
     const int my = (HALO + (lane >> 3)) * TW + HALO + (lane & 7);
     for (int tile = blockIdx.x * kWaves + wave; tile < tiles; tile += gridDim.x * kWaves) {
-        int t = tile;
-        const int tx = t % tw; t /= tw;
-        const int ty = t % th; t /= th;
-        const int c = t % D.NC, n = t / D.NC;
+        int tx, ty, c, n;
+        if (fast_idx) {
+            const int t1 = (int)(((float)tile + 0.5f) * __builtin_amdgcn_rcpf((float)tw));
+            tx = tile - t1 * tw;
+            const int t2 = (int)(((float)t1 + 0.5f) * __builtin_amdgcn_rcpf((float)th));
+            ty = t1 - t2 * th;
+            n = (int)(((float)t2 + 0.5f) * __builtin_amdgcn_rcpf((float)D.NC));
+            c = t2 - n * D.NC;
+        } else {
+            int t = tile;
+            tx = t % tw; t /= tw;
+            ty = t % th; t /= th;
+            c = t % D.NC; n = t / D.NC;
+        }
         const int h0 = ty * 8 - HALO, w0 = tx * 8 - HALO;
         const float *dimg = depth.p + n * depth.s0 + c * depth.s1;
         // phase 1: the window's pixels, all depth loads of a lane in flight together
@@ -840,6 +856,7 @@ __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth,
             // front of the cube skip the arithmetic -- two thirds of a GenRe depth map, whole rounds of a wave at a time
             if (d_raw[r] >= d_screen)
                 key = pixel_voxel<false>(D, e < TN, d_raw[r], 0.f, 0.f, 0.f, f, cam_dist, hh[r], ww[r], ix, iy, iz, dist);
+            if (fast_idx && key >= 0) key = ix | (iy << 10) | (iz << 20);
             if (e < TN) { key_w[e] = key; dist_w[e] = dist; }
             any |= key >= 0;
         }
@@ -865,7 +882,9 @@ __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth,
                     }
                 }
                 if (leader) {
-                    const int iz = key % D.Z, iy = (key / D.Z) % D.Y, ix = key / (D.Z * D.Y);
+                    int ix, iy, iz;
+                    if (fast_idx) { ix = key & 1023; iy = (key >> 10) & 1023; iz = key >> 20; }
+                    else { iz = key % D.Z; iy = (key / D.Z) % D.Y; ix = key / (D.Z * D.Y); }
                     vox.p[n * vox.s0 + c * vox.s1 + vox_off(vox, ix, iy, iz)] = post_bias + post_scale * ((sum - bias) / k);   // :304
                     cnt.p[n * cnt.s0 + c * cnt.s1 + vox_off(cnt, ix, iy, iz)] = k;
                     // occupancy for the consumer (the batch-minor renderer skips tiles -- a brick plus the voxels one step beyond
@@ -873,8 +892,9 @@ __global__ __launch_bounds__(kBlock) void cam_leader_kernel(Dims D, View4 depth,
                     // cleared by the host entry, set for the voxel's brick and its <= 7 neighbours on the LOW side (whose tiles
                     // may reach this voxel); every writer stores 1
                     if (flags.p) {
-                        int *fg = flags.p + (size_t)(n / flags.per_group) * flags.nbx * flags.nby * flags.nbz;
-                        const int b0 = ix / flags.bx, b1 = iy / flags.by, b2 = iz / flags.bz;
+                        int *fg = flags.p + (size_t)(flags.sg >= 0 ? n >> flags.sg : n / flags.per_group) * flags.nbx * flags.nby * flags.nbz;
+                        const int b0 = flags.sx >= 0 ? ix >> flags.sx : ix / flags.bx, b1 = flags.sy >= 0 ? iy >> flags.sy : iy / flags.by,
+                                  b2 = flags.sz >= 0 ? iz >> flags.sz : iz / flags.bz;
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
                             const int x = b0 - (q & 1), y = b1 - ((q >> 1) & 1), z = b2 - (q >> 2);
@@ -1307,7 +1327,7 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         const float prefill = (float)(1.0 / (double)D.X);               // cam_back_projection.py:23-24 (res = X)
         const float bias = 1.0f / (float)mx;                             // K2: dist_bias / max(res)  (:304,:829)
         const int g = grid_for(tiles * 64, 1 << 16);
-        BrickFlags flags{nullptr, 1, 1, 1, 1, 1, 1, 1};
+        BrickFlags flags{nullptr, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0};
         if (tile_live) {         // int32 [groups, nbx, nby, nbz]: word (g, b) <- 1 iff brick b or a high-side neighbour received a point
             GENRE_REQUIRE(is_i32(tile_live, 4) && is_contiguous(tile_live) && tile_live->size[0] >= 1 && tile_live->size[1] >= 1 &&
                               tile_live->size[2] >= 1 && tile_live->size[3] >= 1 && D.NC == 1 && D.N >= 1,
@@ -1321,12 +1341,15 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
             flags.nbx = (int)tile_live->size[1]; flags.nby = (int)tile_live->size[2]; flags.nbz = (int)tile_live->size[3];
             flags.bx = (D.X + flags.nbx - 1) / flags.nbx; flags.by = (D.Y + flags.nby - 1) / flags.nby;
             flags.bz = (D.Z + flags.nbz - 1) / flags.nbz;
+            auto log2_or = [](int v) { int l = 0; while ((1 << l) < v) l++; return (1 << l) == v ? l : -1; };
+            flags.sg = log2_or(flags.per_group); flags.sx = log2_or(flags.bx); flags.sy = log2_or(flags.by); flags.sz = log2_or(flags.bz);
             GENRE_REQUIRE(hipMemsetAsync(flags.p, 0, (size_t)numel(tile_live) * 4, st) == hipSuccess,
                           "%s: hipMemsetAsync of the brick flags failed", op);
         }
 #define GENRE_CAM_LEADER(HV)                                                                                              \
         cam_leader_kernel<HV><<<g, kBlock, 0, st>>>(D, view4(depth), view5(voxel), view5(cnt), byval[1], byval[0], prefill, bias, \
-                                                    post_scale, post_bias, flags, (byval[1] - 0.5f) * (1.0f - 1e-5f))
+                                                    post_scale, post_bias, flags, (byval[1] - 0.5f) * (1.0f - 1e-5f),     \
+                                                    (tiles < (1 << 20) && D.X <= 1024 && D.Y <= 1024 && D.Z <= 1024) ? 1 : 0)
         switch (halo < 1 ? 1 : halo) {
             case 1: GENRE_CAM_LEADER(1); break;
             case 2: GENRE_CAM_LEADER(2); break;
