@@ -646,8 +646,15 @@ __global__ __launch_bounds__(kBlock) void cam_brick_kernel(Dims D, View4 depth, 
     // every workgroup's first load -- the image is (blockIdx.y, blockIdx.z) = (n, c), the brick's coordinates come from two
     // float-reciprocal quotients, exact for these sizes: csrc/sph_render_seg.hip)
     const int nbz = (D.Z + kQZ - 1) / kQZ, nby = (D.Y + kQY - 1) / kQY;       // (constant divisors: shifts)
-    const int t1 = (int)(((float)blockIdx.x + 0.5f) * __builtin_amdgcn_rcpf((float)nbz)), bz = (int)blockIdx.x - t1 * nbz;
-    const int bx = (int)(((float)t1 + 0.5f) * __builtin_amdgcn_rcpf((float)nby)), by = t1 - bx * nby;
+    int t1, bx;
+    if (gridDim.x < (1u << 20)) {
+        t1 = (int)(((float)blockIdx.x + 0.5f) * __builtin_amdgcn_rcpf((float)nbz));
+        bx = (int)(((float)t1 + 0.5f) * __builtin_amdgcn_rcpf((float)nby));
+    } else {                                                             // (volumes of more than 2^20 bricks: the quotients as such)
+        t1 = (int)(blockIdx.x / (unsigned)nbz);
+        bx = t1 / nby;
+    }
+    const int bz = (int)blockIdx.x - t1 * nbz, by = t1 - bx * nby;
     const int n = blockIdx.y, c = blockIdx.z, img = n * D.NC + c;
     const float f = BYVAL ? fl_val : fl.p[n * fl.s0 + c * fl.s1];
     const float cam_dist = BYVAL ? cd_val : camdist.p[n * camdist.s0 + c * camdist.s1];
@@ -1383,7 +1390,6 @@ int forward_impl(const char *op, const genre_tensor *depth, const genre_tensor *
         if (mode == kBrick) {
             const int64_t bricks = (int64_t)((D.X + kQX - 1) / kQX) * ((D.Y + kQY - 1) / kQY) * ((D.Z + kQZ - 1) / kQZ);
             GENRE_REQUIRE(bricks < ((int64_t)1 << 31), "%s: volume too large", op);
-            GENRE_REQUIRE(bricks < ((int64_t)1 << 20), "%s: more than 2^20 bricks", op);     // (the kernel's float quotients)
             const dim3 bgrid((unsigned)bricks, D.N, D.NC);
             const bool pixelscreen = D.N * D.NC <= GENRE_CAMQ_PIXELSCREEN_MAXN;
 #define GENRE_CAMQ_LAUNCH(BV, PXS, A, B_)                                                                                 \
