@@ -290,7 +290,7 @@ def kernel_table(G, dev, B):
                                               kernels="the same volume WITHOUT the occupancy words: every tile is read",
                                               pmc=["seg_sample_kernel<true, false, false>@dense", "seg_combine_kernel<256>@dense"],
                                               src=("common.hpp", "render_common.hpp", "sph_render_seg.hip"))
-        bwd_pmc = ["seg_combine_bwd_kernel<256, 8>", "seg_scatter_kernel", "seg_halo_kernel"]
+        bwd_pmc = ["seg_combine_bwd_kernel<256, 8>", "seg_scatter_kernel<%d>" % (256 if B >= 16 else 512), "seg_halo_kernel"]
         bwd_src = ("common.hpp", "render_common.hpp", "sph_render_seg.hip")
         tr_std = _fused_render.seg_tr_scratch(ps_std, proj, mod._dirs64)
         halo_std = _fused_render.seg_halo_scratch(S, proj)

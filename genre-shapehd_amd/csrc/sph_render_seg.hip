@@ -630,9 +630,10 @@ __global__ __launch_bounds__(kNT) void seg_halo_kernel(RenderDims D, View5 gvox,
 #endif
 constexpr int kAT = kBrick + 2;                                          // tile edge: voxel locals -1 .. 16
 constexpr int kATn = kAT * kAT * kAT;
-constexpr int kNTs = 512;                                               // threads of seg_scatter_kernel: two workgroups (99 KB of LDS) per
-                                                                         // CU = four waves per SIMD, at <= 128 VGPRs
-
+// Threads per workgroup (template): 512 = two workgroups (99 KB of LDS) per CU for small batches, where a row's eight waves finish
+// it in one chunk each (batch 1: 50.6 us against 52.9); 256 = three per CU for batches of 16 images and more, where the smaller
+// workgroups turn over better (batch 32: 792 -> 740 us).  Both at <= 128 VGPRs (four waves per SIMD); 128 and 384 threads: slower.
+template <int kNTs>
 __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) void seg_scatter_kernel(RenderDims D, View5 vox, View5 gvox, const double *__restrict__ dirs,
                                                            const float *__restrict__ dw, const int4 *__restrict__ rows,
                                                            const int4 *__restrict__ segs, int nseg,
@@ -798,8 +799,11 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const bool v4 = D.sz == 1 && ((D.sx | D.sy) & 3) == 0 && (reinterpret_cast<uintptr_t>(vb) & 15) == 0 && gvox.s4 == 1 &&
                     ((gvox.s2 | gvox.s3) & 3) == 0 && (reinterpret_cast<uintptr_t>(gb) & 15) == 0 && bz0 + kBrick <= D.Z;
     constexpr int kFlushIt = (kHF * kHF * 4 + kNTs - 1) / kNTs;
+    constexpr int kZIt = (kHF * kHF + kNTs - 1) / kNTs;
     float4 mvv[kFlushIt];
-    float mvz = 0.f;
+    float mvz[kZIt];
+#pragma unroll
+    for (int i = 0; i < kZIt; i++) mvz[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < kFlushIt; i++) mvv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (D.pre_scale != 0.0f) {
@@ -819,10 +823,13 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 mvv[i] = make_float4(m[0], m[1], m[2], m[3]);
             }
         }
-        const int r = min((int)threadIdx.x, kHF * kHF - 1);
-        const int lx = (int)(((float)r + 0.5f) * (1.0f / kHF)), ly = r - lx * kHF;
-        const int x = bx0 + lx, y = by0 + ly, z = bz0 + kBrick;
-        mvz = vb[(x < D.X && y < D.Y && z < D.Z) ? x * D.sx + y * D.sy + z * D.sz : 0];
+#pragma unroll
+        for (int i = 0; i < kZIt; i++) {
+            const int r = min((int)threadIdx.x + i * kNTs, kHF * kHF - 1);
+            const int lx = (int)(((float)r + 0.5f) * (1.0f / kHF)), ly = r - lx * kHF;
+            const int x = bx0 + lx, y = by0 + ly, z = bz0 + kBrick;
+            mvz[i] = vb[(x < D.X && y < D.Y && z < D.Z) ? x * D.sx + y * D.sy + z * D.sz : 0];
+        }
     }
     __syncthreads();
 #if GENRE_SCATTER_AB == 6                                                 // (A/B: no flush)
@@ -876,12 +883,14 @@ __global__ __launch_bounds__(kNTs) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             for (int c = 0; c < 4; c++) h[c] = val[c];
         }
     }
-    if ((int)threadIdx.x < kHF * kHF) {                                   // the cells at local z = 16
-        const int r = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < kZIt; i++) {                                      // the cells at local z = 16
+        const int r = (int)threadIdx.x + i * kNTs;
+        if (r >= kHF * kHF) break;
         const int lx = (int)(((float)r + 0.5f) * (1.0f / kHF)), ly = r - lx * kHF;
         const int x = bx0 + lx, y = by0 + ly, z = bz0 + kBrick;
         const bool ok = x < D.X && y < D.Y && z < D.Z;
-        const float val = cell(tile[((lx + 1) * kAT + ly + 1) * kAT + kBrick + 1], mvz, ok);
+        const float val = cell(tile[((lx + 1) * kAT + ly + 1) * kAT + kBrick + 1], mvz[i], ok);
         rec[lx == kBrick ? kHaloX + ly * kHF + kBrick : (ly == kBrick ? kHaloY + lx * kHF + kBrick : kHaloZ + lx * kBrick + ly)] = val;
     }
 }
@@ -1065,7 +1074,8 @@ extern "C" int genre_render_seg_backward(const genre_tensor *vox, const genre_te
     GENRE_LAUNCH_CHECK("render_seg backward (segment chains)");
     constexpr size_t lds = (size_t)kATn * sizeof(double) + kMaxZR * sizeof(float);
     static_assert(lds <= 64 * 1024, "dynamic LDS beyond 64 KB needs reserve_lds");
-    seg_scatter_kernel<<<rgrid, kNTs, lds, st>>>(
+    const auto scatter = imgs >= 16 ? &seg_scatter_kernel<256> : &seg_scatter_kernel<512>;
+    scatter<<<rgrid, imgs >= 16 ? 256 : 512, lds, st>>>(
         D, view5(vox), view5(grad_vox), (const double *)dirs->data, (const float *)depth_weight->data,
         (const int4 *)bwd_rows->data, (const int4 *)segs->data, (int)segs->size[0], (const float2 *)tr_scratch->data, lines,
         (const float *)v_scratch->data, live_p, bmax, nblk, (float *)halo_scratch->data);
