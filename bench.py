@@ -90,6 +90,28 @@ def pmc_traffic(kernel_names, batch, sources=("common.hpp",)):
     return total, "profiles/" + name
 
 
+def rocprof_m2():
+    """the two M2 kernels in the newest committed rocprofv3 trace (profiles/*_kernel_stats_phases.txt: profiles/pmc_targets.py, the
+    same inputs, but each launch there follows calc_prob's 2 GB backward stream instead of its own kind) -- the figure a reader
+    of the trace finds, beside the event figures above"""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats_phases.txt")))
+    out = {"what": "rocprofv3 kernel trace of profiles/pmc_targets.py (same inputs; every launch there follows other kernels' streams, "
+                   "not its own kind back to back)"}
+    if not files:
+        return out
+    out["file"] = "profiles/" + os.path.basename(files[-1])
+    for key, pat in (("cam_brick_kernel<false, true>", "cam_brick_kernel<false, true>"), ("stop_fwd_vec4_kernel<true>", "stop_fwd_vec4_kernel<true>")):
+        for line in open(files[-1]):
+            if pat in line:
+                m = re.search(r"\)?\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s+\d+\s+\d+\s+\d+\s*$", line)
+                if m:
+                    out[key] = {"calls": int(m.group(1)), "avg_us": float(m.group(3)), "min_us": float(m.group(4)), "max_us": float(m.group(5))}
+                break
+    return out
+
+
 def miopen_find_db_state():
     """`shipped` when MIOpen reads its find-db from the tree (genre-shapehd_amd/.miopen/db/*.txt, tracked since round 5: the measured
     solver choices of tools/warm_miopen.py -- worth 154 -> 180 forward passes/s in round 4), `absent` when a clone has none and
@@ -1126,8 +1148,7 @@ def main():
                                             "timing": "HIP events, the two kernels launched alternately on one stream",
                                             "us_sum_of_back_to_back_figures": m2_us_b2b,
                                             "frac_sum_of_back_to_back_figures": m2_bytes / m2_us_b2b / 1e3 / HBM_PEAK_GBS,
-                                            "rocprof": "profiles/r06*_kernel_stats_phases.txt: cam_brick_kernel<false, true> + "
-                                                       "stop_fwd_vec4_kernel<true>, same inputs (profiles/pmc_targets.py)"}},
+                                            "rocprof": rocprof_m2()}},
             "m2": {"what": "cam_bp fwd + calc_prob fwd, algorithmic bytes / time, batch %d" % B,
                    "achieved": m2_bytes / m2_us / 1e3, "unit": "GB/s", "frac": m2_bytes / m2_us / 1e3 / HBM_PEAK_GBS,
                    "us_per_image": m2_us / B},
