@@ -114,3 +114,36 @@ def test_segment_algebra_reproduces_the_ray_integral():
     assert np.abs(got - want).max() < 1e-12
     # R in front of the first in-volume sample = (the ray's value - what the samples before the volume contribute) / T there
     assert np.abs(R_front - (want - t["ray_pre"][:, 1]) / t["ray_pre"][:, 0]).max() < 1e-10
+
+
+def test_fixed_point_bound_of_the_segment_backward():
+    """csrc/sph_render_seg.hip: seg_scatter_kernel scales its 64-bit fixed-point tile by a BOUND of the image's |dL/dp| that needs no
+    pass over the samples: max over rays of |g T| in front of the ray's first segment, times the span of the depth weights and 1.
+    dL/dp_k = g T_k (w_k - R_{k+1}) with T_k <= T in front and R a convex combination of depth weights and 1 -- checked here on
+    random rays (any probabilities in the clamp's range, any weights), and so is the difference recurrence the kernel carries:
+    d_{k-1} = (w_{k-1} - w_k) + (1 - p_k) d_k"""
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        n = int(rng.integers(2, 300))
+        p = np.clip(rng.uniform(-0.2, 1.2, n) ** rng.choice([1, 3]), 1e-5, 1 - 1e-5)
+        w = rng.uniform(-2, 5, n) if trial % 3 else np.linspace(0.5, 1.5, n)
+        g, t_pre = rng.standard_normal() * 10 ** rng.uniform(-3, 3), rng.uniform(0.01, 1.0)
+        T = t_pre * np.concatenate(([1.0], np.cumprod(1 - p[:-1])))
+        R = np.empty(n + 1)
+        R[n] = 1.0
+        for k in range(n - 1, -1, -1):
+            R[k] = p[k] * w[k] + (1 - p[k]) * R[k + 1]
+        dldp = g * T * (w - R[1:])
+        # finite differences of the ray's value  pre + sum_k T_k p_k w_k + T_end: the formula is the derivative
+        def value(pp):
+            Tq = t_pre * np.concatenate(([1.0], np.cumprod(1 - pp)))
+            return (Tq[:-1] * pp * w).sum() + Tq[-1]
+        k = int(rng.integers(0, n))
+        e = np.zeros(n); e[k] = 1e-7
+        assert abs((value(p + e) - value(p - e)) / 2e-7 * g - dldp[k]) <= 1e-5 * max(1.0, abs(dldp).max())
+        span = max(w.max(), 1.0) - min(w.min(), 1.0)
+        assert np.abs(dldp).max() <= abs(g * t_pre) * span * (1 + 1e-12)
+        d = w[n - 1] - R[n]
+        for k in range(n - 1, 0, -1):
+            assert abs(d - (w[k] - R[k + 1])) <= 1e-9 * (1 + abs(d))
+            d = (w[k - 1] - w[k]) + (1 - p[k]) * d
