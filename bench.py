@@ -394,6 +394,7 @@ def kernel_table(G, dev, B):
             # (The timing calls above re-wrote proj_bm through the raw C ABI -- same depth maps, same values -- and a raw write
             # drops a volume's hint (_loader._call, round 6): the words `tl` of the last hinted call are hung on it again.)
             _fused_render.attach_hint(proj_bm, tl, 128)
+            blocked = _fused_render.provably_blocked(proj_bm, 50.0)     # the step's renderer saves nothing, its backward launches nothing
             words, ps_empty = _fused_render.occupancy_hint(proj_bm, TB, 50.0, render_lib, with_grad=True)
             # (None when GENRE_CAMBP_MODE pins another camera forward: every tile is read then)
             tiles_live = (words != 0).float().mean().item() if words is not None else 1.0   # share of the tiles that are read
@@ -412,8 +413,16 @@ def kernel_table(G, dev, B):
                                                  "(occupancy words of the camera forward)" % (100 * tiles_live),
                                          pmc=["bm_sample_kernel<true, true, true, 1024>@genre", "bm_combine_fwd_kernel@genre"],
                                          src=("common.hpp", "sph_render_bm.hip"))
+            # ... and as the STEP runs it when the layer's value range proves on the host that the x50 clamp blocks every voxel
+            # (toolbox/_fused_render.py: provably_blocked -- GenRe's own chain): nothing is saved for a backward that launches nothing
             rows["render_fwd_bm_nosave"] = dict(us=event_time_us(lambda: bm_fwd(False), iters, 5),
-                                                bytes=rows["render_fwd_bm"]["bytes"], kernels="the same without saved state (inference)")
+                                                bytes=rows["render_fwd_bm"]["bytes"], bytes_needed=rows["render_fwd_bm"]["bytes_needed"],
+                                                tiles_live_frac=tiles_live,
+                                                kernels="bm_sample_kernel+bm_combine_fwd_kernel on GenRe's volume without saved state "
+                                                        "(inference; the step too when the clamp provably blocks every voxel), "
+                                                        "%.0f %% of the tiles live" % (100 * tiles_live),
+                                                pmc=["bm_sample_kernel<true, false, true, 1024>", "bm_combine_fwd_kernel@nosave"],
+                                                src=("common.hpp", "sph_render_bm.hip"))
             rows["render_fwd_bm_dense"] = dict(us=event_time_us(lambda: bm_fwd(True, False), iters, 5), bytes=B * BYTES_RENDER_FUSED,
                                                kernels="the same volume WITHOUT the occupancy words: every tile is read")
             def bm_bwd_scatter():
@@ -463,15 +472,25 @@ def kernel_table(G, dev, B):
         # the back-to-back figure above is the warm one.  Both are in the line (`us`, `us_in_step_order`).
         gd = torch.empty_like(d)
         gfl, gcd = torch.empty((B, 1), device=dev), torch.empty((B, 1), device=dev)
+        zero_word = torch.zeros((1,), dtype=torch.int32, device=dev)
         seq = [("cam_bp_fwd_bm_layer", lambda: cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True,
-                                                                                        tile_live=tl, sparse_cnt=True)),
-               ("render_fwd_bm", lambda: bm_fwd(True)),
-               ("render_bwd_bm", bm_bwd_scatter),
-               # (as the step's autograd chain runs it: the renderer's backward hangs "this group's gradient is identically zero" --
-               # the trailing words of its clamp mask -- on the gradient it returns, and the layer's backward passes them on)
-               ("cam_bp_bwd_bm", lambda: cam_bp_lib.back_projection_backward_hinted(d, fl, cd, cnt_bm, gvox_bm, gd, gcd, gfl, mask, 1,
-                                                                                    groups * 128 ** 3, 32)),
-               ("cam_bp_bwd_bm_nohint", lambda: cam_bp_lib.back_projection_backward_shifted(d, fl, cd, cnt_bm, gvox_bm, gd, gcd, gfl))]
+                                                                                        tile_live=tl, sparse_cnt=True))]
+        if blocked:
+            # the step as its autograd chain runs it on GenRe's volume: the layer's value range proves on the host that the x50 clamp
+            # blocks every voxel -- the renderer saves nothing, its backward launches nothing (the gradient is a stride-0 view of one
+            # zero), the layer's backward gets "every image's gradient is zero" in one word
+            seq += [("render_fwd_bm_nosave", lambda: bm_fwd(False)),
+                    ("cam_bp_bwd_bm", lambda: cam_bp_lib.back_projection_backward_hinted(d, fl, cd, cnt_bm, gvox_bm, gd, gcd, gfl, zero_word,
+                                                                                         0, 0, 1 << 30))]
+        else:
+            # (GENRE_LAZY_ZERO_GRAD=0: the kernels find the zeros themselves -- the renderer's backward writes them and hangs "this
+            # group's gradient is identically zero", the trailing words of its clamp mask, on the gradient it returns)
+            seq += [("render_fwd_bm", lambda: bm_fwd(True)),
+                    ("render_bwd_bm", bm_bwd_scatter),
+                    ("cam_bp_bwd_bm", lambda: cam_bp_lib.back_projection_backward_hinted(d, fl, cd, cnt_bm, gvox_bm, gd, gcd, gfl, mask, 1,
+                                                                                         groups * 128 ** 3, 32))]
+        seq += [("cam_bp_bwd_bm_nohint", lambda: cam_bp_lib.back_projection_backward_shifted(d, fl, cd, cnt_bm, gvox_bm, gd, gcd, gfl))]
+        rows["_step_groups"] = [name for name, _ in seq[:-1]]
         for _ in range(3):
             for _, fn in seq:
                 fn()
@@ -497,6 +516,8 @@ def kernel_table(G, dev, B):
                                             if name == "cam_bp_bwd_bm" else "without the words: every pixel's gather and arithmetic")))
         cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True)     # (cnt dense again)
     for r in rows.values():
+        if not isinstance(r, dict):         # ("_step_groups": the names of the step's groups)
+            continue
         r["GBs"] = r["bytes"] / r["us"] / 1e3
         if "bytes_needed" in r:
             r["GBs_needed"] = r["bytes_needed"] / r["us"] / 1e3
@@ -1037,9 +1058,15 @@ def main():
            "per_rank_shapes_per_s": [B * args.steps / t for t in hot_per_rank],
            "render_spherical": "fused" if fused else "reference op sequence (grid_sample + CalcStopProb)",
            "volume_layout": "batch-minor (image index fastest)" if bm else "NCXYZ",
-           "note": "on GenRe's own volume the x50 clamp blocks every voxel: the gradient through render_spherical is "
-                   "identically zero (as in the reference) and its backward only writes zeros; kernels.render_bwd_bm_soft "
-                   "and `roofline` describe the same kernels where they do work"}
+           "note": "on GenRe's own volume the x50 clamp blocks every voxel: the gradient through render_spherical is identically "
+                   "zero, as in the reference.  The camera layer hangs its value range ({0} u [0.13, 1]) on the volume, the fused "
+                   "renderer sees on the HOST that clamp(x * 50) blocks both ends, saves nothing for a backward and launches "
+                   "nothing in it: the gradient is a stride-0 view of one zero carrying 'every image's gradient is zero' for the "
+                   "camera layer's backward (toolbox/_fused_render.py: provably_blocked; GENRE_LAZY_ZERO_GRAD=0 switches it off -- "
+                   "the kernels then find and write the same zeros: kernels.render_bwd_bm / render_bwd_fused).  "
+                   "kernels.render_bwd_bm_soft and `roofline_soft` describe the backward kernels where they do work",
+           "renderer_backward": "none launched (volume provably blocked)" if os.environ.get("GENRE_LAZY_ZERO_GRAD", "1") != "0"
+                                else "kernels write the zeros"}
     # ---- the headline: BASELINE.json's metric -- GenRe full-model forward passes per second, batch 1 per GPU -------
     del graph_holder[:]
     torch.cuda.empty_cache()
@@ -1070,9 +1097,12 @@ def main():
         if not fused:
             in_step = ["cam_bp_fwd", "calc_prob_fwd", "calc_prob_bwd_fused"]
         elif bm:
-            in_step = ["cam_bp_fwd_bm_layer", "render_fwd_bm", "render_bwd_bm", "cam_bp_bwd_bm"]
+            in_step = rows.pop("_step_groups", ["cam_bp_fwd_bm_layer", "render_fwd_bm", "render_bwd_bm", "cam_bp_bwd_bm"])
         else:
-            in_step = ["cam_bp_fwd", "render_fwd_fused", "render_bwd_fused"]
+            # (render_bwd_fused: only when GENRE_LAZY_ZERO_GRAD=0 -- otherwise the clamp provably blocks every voxel of the step's
+            # volume and the renderer's backward launches nothing: toolbox/_fused_render.py: provably_blocked)
+            in_step = ["cam_bp_fwd", "render_fwd_fused"] + (["render_bwd_fused"] if os.environ.get("GENRE_LAZY_ZERO_GRAD", "1") == "0" else [])
+        rows.pop("_step_groups", None)
         for k in ("m2_pair_alternating",):
             rows[k]["GBs"] = rows[k]["bytes"] / rows[k]["us"] / 1e3
         # `roofline` = the slowest hand-written kernel group OF THE TIMED hot-path step, on the volume the step renders (round 5;

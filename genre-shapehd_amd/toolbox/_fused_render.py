@@ -325,7 +325,44 @@ def attach_hint(vol, words, res, cell=None):
         vol._genre_brick_hint = (words, shifted_fill(res), vol._version)
     else:
         vol._genre_cell_hint = (words, shifted_fill(res), vol._version, int(cell))
+    # ... and the producer's VALUE RANGE: an empty voxel holds the fill value, an occupied one 1 - res * tdf with tdf the mean
+    # distance of the points inside the voxel from its centre (camera_backprojection_module.py:25-28, back_projection_kernel.cu
+    # :215-305) -- at most half the voxel's diagonal, sqrt(3)/2 / res: occupied voxels hold >= 0.1339 (0.13 here, generously)
+    vol._genre_range_hint = (shifted_fill(res), _VMIN_SHIFTED, vol._version)
     return vol
+
+
+_VMIN_SHIFTED = 0.13
+_LAZY_ZEROS = {}
+
+
+def provably_blocked(vox, pre_scale):
+    """True when the HOST can tell that clamp(vox * pre_scale, lo, hi) blocks every voxel: the producer's value range hangs on the
+    volume (attach_hint: fill value, lower bound of every other value), the volume still is what the producer wrote, and both ends
+    of the range land outside the clamp -- GenRe's own chain, depth_pred_with_sph_inpaint.py:120-126: clamp(proj * 50) of values in
+    {0} u [0.13, 1].  The gradient of render_spherical w.r.t. such a volume is identically zero whatever comes from above (the
+    reference computes exactly these zeros): the forward then saves nothing for a backward and the backward launches nothing
+    (lazy_zero_grad).  GENRE_LAZY_ZERO_GRAD=0 switches it off (the kernels then find the same zeros themselves)."""
+    import os
+    if not pre_scale or os.environ.get("GENRE_LAZY_ZERO_GRAD", "1") == "0":
+        return False
+    h = _live_hint(vox, "_genre_range_hint")
+    if h is None:
+        return False
+    fill, vmin = float(np.float32(h[0]) * np.float32(pre_scale)), float(np.float32(h[1]) * np.float32(pre_scale))
+    return pre_scale > 0 and (fill < _LO or fill > _HI) and vmin > _HI
+
+
+def lazy_zero_grad(shape, device):
+    """the gradient of a provably blocked volume: zeros of the volume's shape that occupy four bytes (a stride-0 view of one
+    zero -- every reader sees zeros; nothing is written per step) with the zero-gradient words of attach_zero_hint saying so for
+    every image (one word, group = everything), so that the camera layer's backward does not even read it"""
+    z = _LAZY_ZEROS.get(str(device))
+    if z is None:
+        z = (torch.zeros((1,), dtype=torch.float32, device=device), torch.zeros((1,), dtype=torch.int32, device=device))
+        _LAZY_ZEROS[str(device)] = z
+    g = z[0].expand(tuple(shape))
+    return attach_zero_hint(g, z[1], 0, 0, 1 << 30)
 
 
 _LO, _HI = float(np.float32(1e-5)), float(np.float32(1 - 1e-5))            # spherical_proj.py:66
@@ -458,6 +495,10 @@ class RenderSphericalFused(Function):
         out = torch.empty((vox.shape[0], vox.shape[1], res + 2 * pad, res + 2 * pad), dtype=vox.dtype, device=vox.device)
         ctx.pre_scale = float(pre_scale)
         ctx.batch_minor = is_batch_minor(vox)
+        # a volume whose every voxel the folded clamp provably blocks (GenRe's own chain): zero gradient, nothing to save
+        ctx.blocked = bool(ctx.needs_input_grad[0]) and provably_blocked(vox, ctx.pre_scale)
+        want_grad = bool(ctx.needs_input_grad[0]) and not ctx.blocked
+        ctx.vox_shape = vox.shape
         if ctx.batch_minor:
             # image index fastest in memory: tile renderer, lanes = images (csrc/sph_render_bm.hip)
             t = bm_tables_for(vox.shape, vox.device, dirs64, depth_weight)
@@ -465,7 +506,7 @@ class RenderSphericalFused(Function):
             f32 = dict(dtype=torch.float32, device=vox.device)
             ps = torch.empty((groups * t["segs"].shape[0] * 64,), **f32)
             stash = mask = None
-            if ctx.needs_input_grad[0]:
+            if want_grad:
                 stash = torch.empty((groups * t["rec_f"].shape[0] * 32,), **f32)
                 if pre_scale:
                     mask = torch.empty((groups * vox.shape[2] * vox.shape[3] * vox.shape[4] + groups,), dtype=torch.int32,
@@ -473,9 +514,9 @@ class RenderSphericalFused(Function):
             words, ps_empty = occupancy_hint(vox, t, ctx.pre_scale, lib, with_grad=stash is not None)
             lib.render_bm_forward(vox, out, t["segs"], t["rec_f"], t["fwd_rows"], t["ray_ptr"], t["ray_seg"],
                                   t["ray_pre"], ps, stash, mask, ctx.pre_scale, words, ps_empty)
-            ctx.vox_shape = vox.shape
             ctx.mask = mask
-            ctx.save_for_backward(dirs64, depth_weight, ps, stash)
+            if want_grad:
+                ctx.save_for_backward(dirs64, depth_weight, ps, stash)
             return out
         # standard layout: the segment forward (csrc/sph_render_seg.hip) -- one (P, S) pair per segment, nothing saved
         t = seg_tables_for(vox.shape, vox.device, dirs64, depth_weight)
@@ -484,14 +525,13 @@ class RenderSphericalFused(Function):
         # with pre_scale and a backward to come: the clamp's pass words per image and per 16^3 brick -- what the clamp blocks
         # is then written as zeros by the backward, not computed (GenRe's own volumes: everything)
         ctx.live = None
-        if pre_scale and ctx.needs_input_grad[0]:
+        if pre_scale and want_grad:
             nb = -(-vox.shape[2] // BRICK) * -(-vox.shape[3] // BRICK) * -(-vox.shape[4] // BRICK)
             ctx.live = torch.empty((imgs * (1 + nb),), dtype=torch.int32, device=vox.device)
-        occ, ps_empty, cell = occupancy_hint_std(vox, t, dirs64, depth_weight, ctx.pre_scale, lib,
-                                                 with_grad=bool(ctx.needs_input_grad[0]))
-        # a backward will follow: the raw sample values of the tiles a gradient can come back through (on GenRe's own chain:
-        # none) -- with the (P, S) pairs all the state the backward's segment form needs
-        v = seg_v_scratch(t, imgs, vox.device) if ctx.needs_input_grad[0] else None
+        occ, ps_empty, cell = occupancy_hint_std(vox, t, dirs64, depth_weight, ctx.pre_scale, lib, with_grad=want_grad)
+        # a backward will follow: the raw sample values of the tiles a gradient can come back through -- with the (P, S) pairs
+        # all the state the backward's segment form needs
+        v = seg_v_scratch(t, imgs, vox.device) if want_grad else None
         lib.render_seg_forward(vox, dirs64.view(torch.float32), depth_weight, out, t["seg_rows"], t["segs"], t["ray_nseg"],
                                t["ray_pre"], t["line_w"], ps, ctx.pre_scale, ctx.live, occ, ps_empty, cell, v)
         if v is not None:
@@ -502,6 +542,8 @@ class RenderSphericalFused(Function):
     @once_differentiable
     def backward(ctx, grad_out):
         lib = _loader().render_lib
+        if ctx.blocked:                  # the clamp provably blocks every voxel (provably_blocked): nothing to launch
+            return lazy_zero_grad(ctx.vox_shape, grad_out.device), None, None, None, None
         if ctx.batch_minor:
             dirs64, depth_weight, ps, stash = ctx.saved_tensors
             t = bm_tables_for(ctx.vox_shape, grad_out.device, dirs64, depth_weight)

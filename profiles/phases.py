@@ -4,11 +4,12 @@ remainder is set-up (the constants of an occupancy hint are built by rendering a
 reported as "name@phase":
   genre  GenRe's own volume as the step's layer hands it over (with its occupancy words): what the timed steps render
   dense  the same volume without the words (segment forward only)
+  nosave the image-minor forward on GenRe's volume without saved state (what the step runs: the clamp provably blocks every voxel)
   soft   a volume whose every sample passes the clamps: a gradient everywhere"""
 TWO = ("genre", "soft")
 PHASES = {
     "seg_combine_kernel": ("genre", "dense", "soft"),
-    "bm_combine_fwd_kernel": TWO, "bm_combine_bwd_kernel": TWO, "bm_scatter_kernel": TWO,
+    "bm_combine_fwd_kernel": ("genre", "nosave", "soft"), "bm_combine_bwd_kernel": TWO, "bm_scatter_kernel": TWO,
     "bm_zero_shared_kernel": TWO, "seg_combine_bwd_kernel": TWO, "seg_scatter_kernel": TWO, "seg_halo_kernel": TWO,
     "render_bwd_brick_kernel": TWO, "zero_shared_bricks_kernel": TWO,
 }

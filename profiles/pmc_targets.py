@@ -90,9 +90,15 @@ for _ in range(ITERS):
         cam_bp_lib.back_projection_forward_const(d, 2.2, 418.3, proj_bm, cnt_bm, shifted=True,   # ... as the layer calls it in the step
                                                  tile_live=tl_bm, sparse_cnt=True)
 for vol_std, vol_bm in ((proj_std, proj_bm), (None, None), (soft_std, soft_bm)):
-    if vol_std is None:                      # @dense: the segment forward on GenRe's volume without the occupancy words
+    if vol_std is None:                      # @dense: the segment forward on GenRe's volume without the occupancy words ...
         for _ in range(ITERS):
             seg_fwd(proj_std, False, save=False)
+        if TB is not None:                   # ... @nosave: the image-minor forward as the step runs it on GenRe's volume (the clamp provably
+            for _ in range(ITERS):           # blocks every voxel: nothing saved; toolbox/_fused_render.py: provably_blocked)
+                _fused_render.attach_hint(proj_bm, tl_bm, 128)
+                words, ps_empty = _fused_render.occupancy_hint(proj_bm, TB, 50.0, lib, with_grad=False)
+                lib.render_bm_forward(proj_bm, out_p, TB["segs"], TB["rec_f"], TB["fwd_rows"], TB["ray_ptr"], TB["ray_seg"],
+                                      TB["ray_pre"], ps, None, None, 50.0, words, ps_empty)
         continue
     for _ in range(ITERS):
         seg_fwd(vol_std, vol_std is proj_std)

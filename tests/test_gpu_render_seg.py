@@ -265,3 +265,43 @@ def test_segment_renderer_on_strided_volumes_and_two_channels(pre_scale, genre, 
         assert torch.equal(res[0][0], res[1][0])
         top = res[1][1].abs().max().item()
         assert top > 0 and (res[0][1] - res[1][1]).abs().max().item() <= 2e-6 * top
+
+
+@pytest.mark.parametrize("n,batch_minor", [(2, False), (32, True)])
+def test_provably_blocked_chain_launches_no_renderer_backward(n, batch_minor, genre, dev, monkeypatch):
+    """GenRe's own chain (layer -> clamp(x50) folded into render_spherical): the layer hangs its value range on the volume, the
+    renderer sees on the host that the clamp blocks every voxel, saves nothing and its backward launches nothing -- the gradient
+    is a stride-0 view of one zero that every reader sees as zeros and the camera layer's backward does not read at all.  Same
+    map, same (zero) gradient as with GENRE_LAZY_ZERO_GRAD=0, where the kernels find the zeros themselves; a pre_scale that lets
+    occupied voxels through takes the usual path."""
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    lib = F._loader().render_lib
+    calls = []
+    for name in ("render_seg_backward", "render_bm_backward"):
+        real = getattr(lib, name)
+        monkeypatch.setattr(lib, name, staticmethod(lambda *a, _r=real, _n=name, **k: (calls.append(_n), _r(*a, **k))[1]))
+    d0 = torch.from_numpy(inputs.batch_depth(n, seed=9)).to(dev)
+    g = torch.randn((n, 1, 160, 160), device=dev)
+    layer = genre.Camera_back_projection_layer(batch_minor=batch_minor).to(dev)
+    mod = genre.render_spherical().to(dev)
+    res = {}
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("GENRE_LAZY_ZERO_GRAD", lazy)
+        d = d0.clone().requires_grad_(True)
+        proj = layer(d)
+        proj.retain_grad()
+        before = len(calls)
+        out = mod(proj, pre_scale=50.0, pad=16)
+        out.backward(g)
+        assert (len(calls) == before) == (lazy == "1")
+        assert proj.grad.shape == proj.shape and torch.count_nonzero(proj.grad).item() == 0
+        assert torch.count_nonzero(d.grad).item() == 0
+        res[lazy] = out.detach().clone()
+    # (the standard layout's forward rounds a segment's transmittance product once when it saves for a backward, per factor when
+    # it does not: the two maps agree to a few 1e-7)
+    assert (res["1"] - res["0"]).abs().max().item() <= 1e-6
+    monkeypatch.setenv("GENRE_LAZY_ZERO_GRAD", "1")
+    d = d0.clone().requires_grad_(True)
+    before = len(calls)
+    mod(layer(d), pre_scale=0.9, pad=16).backward(g)
+    assert len(calls) == before + 1 and d.grad.abs().max().item() > 0

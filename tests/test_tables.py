@@ -160,3 +160,28 @@ def test_zero_gradient_hint_is_guarded_by_the_tensor_version():
     assert h is not None and h[0] is words and h[1:] == (1, 1, 1)
     g.add_(1.0)
     assert F.zero_hint_of(g) is None
+
+
+def test_provably_blocked_volumes_are_recognised_on_the_host(monkeypatch):
+    """toolbox/_fused_render.py: provably_blocked / lazy_zero_grad -- the producer's value range ({fill} u [0.13, 1]) hangs on the
+    volume; when both ends land outside clamp(x * pre_scale, 1e-5, 1 - 1e-5) the renderer's gradient is identically zero and is
+    returned as a stride-0 view of one zero with the zero-gradient words.  Not without the hint, not after a write, not for a
+    pre_scale that lets occupied voxels through, not when switched off."""
+    import torch
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    v = torch.zeros(2, 1, 4, 4, 4)
+    assert not F.provably_blocked(v, 50.0)
+    F.attach_hint(v, torch.zeros(1, dtype=torch.int32), 128)
+    assert F.provably_blocked(v, 50.0) and F.provably_blocked(v, 8.0)
+    assert not F.provably_blocked(v, 5.0) and not F.provably_blocked(v, 0.9) and not F.provably_blocked(v, 0.0)
+    monkeypatch.setenv("GENRE_LAZY_ZERO_GRAD", "0")
+    assert not F.provably_blocked(v, 50.0)
+    monkeypatch.delenv("GENRE_LAZY_ZERO_GRAD")
+    v.mul_(2.0)
+    assert not F.provably_blocked(v, 50.0)
+    # the bound itself: an occupied voxel holds 1 - res * (mean distance to its centre of points inside it) >= 1 - sqrt(3)/2
+    assert F._VMIN_SHIFTED < 1 - np.sqrt(3) / 2
+    g = F.lazy_zero_grad((3, 1, 4, 4, 4), torch.device("cpu"))
+    assert g.shape == (3, 1, 4, 4, 4) and g.stride() == (0, 0, 0, 0, 0) and float(g.abs().sum()) == 0.0
+    words, stride, off, group = F.zero_hint_of(g)
+    assert int(words[(2 // group) * stride + off]) == 0
