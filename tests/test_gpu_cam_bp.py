@@ -421,3 +421,26 @@ def test_image_minor_layer_backward_with_the_sparse_count(genre, dev):
     ya.backward(g)
     yb.backward(g)
     assert xa.grad.abs().max().item() > 0 and torch.equal(xa.grad, xb.grad)
+
+
+@pytest.mark.parametrize("batch_minor", [False, True])
+def test_layer_values_stay_in_the_range_it_declares(batch_minor, genre, dev):
+    """Camera_back_projection_layer hangs its value range on the volume it returns (toolbox/_fused_render.py: attach_hint --
+    an empty voxel holds the fill value, an occupied one 1 - res * tdf >= 1 - sqrt(3)/2 = 0.1339...: tdf is the mean distance of
+    the points INSIDE the voxel from its centre), and the fused renderer builds on it (provably_blocked): checked here on depth
+    maps that put many points into one voxel and points near voxel corners"""
+    from genre_shapehd_amd.toolbox import _fused_render as F
+    rng = np.random.default_rng(17)
+    n = 32 if batch_minor else 6
+    d = inputs.batch_depth(n, seed=23)
+    d[1] = rng.uniform(1.75, 2.65, d[1].shape).astype(np.float32)               # noise through the whole cube: multi-hit voxels
+    d[2] = np.float32(2.2) + np.float32(0.4) * np.sin(np.linspace(0, 40, 256, dtype=np.float32))[None, None, :] * np.ones((1, 256, 1), np.float32)
+    d[3] = np.float32(1.7001)                                                    # a plane a hair behind the cube's near face
+    layer = genre.Camera_back_projection_layer(batch_minor=batch_minor).to(dev)
+    vol = layer(torch.from_numpy(d).to(dev))
+    h = getattr(vol, "_genre_range_hint", None)
+    assert h is not None and h[0] == 0.0 and h[1] == F._VMIN_SHIFTED
+    occupied = vol[vol != h[0]]
+    assert occupied.numel() > 1000
+    assert occupied.min().item() >= 1 - np.sqrt(3) / 2 - 1e-5 > h[1] and occupied.max().item() <= 1.0
+    assert F.provably_blocked(vol, 50.0) and not F.provably_blocked(vol, 5.0)
