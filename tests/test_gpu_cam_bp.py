@@ -424,12 +424,13 @@ def test_image_minor_layer_backward_with_the_sparse_count(genre, dev):
 
 
 @pytest.mark.parametrize("batch_minor", [False, True])
-def test_layer_values_stay_in_the_range_it_declares(batch_minor, genre, dev):
+def test_layer_values_stay_in_the_range_it_declares(batch_minor, genre, dev, monkeypatch):
     """Camera_back_projection_layer hangs its value range on the volume it returns (toolbox/_fused_render.py: attach_hint --
     an empty voxel holds the fill value, an occupied one 1 - res * tdf >= 1 - sqrt(3)/2 = 0.1339...: tdf is the mean distance of
     the points INSIDE the voxel from its centre), and the fused renderer builds on it (provably_blocked): checked here on depth
     maps that put many points into one voxel and points near voxel corners"""
     from genre_shapehd_amd.toolbox import _fused_render as F
+    monkeypatch.setenv("GENRE_LAZY_ZERO_GRAD", "1")
     rng = np.random.default_rng(17)
     n = 32 if batch_minor else 6
     d = inputs.batch_depth(n, seed=23)
